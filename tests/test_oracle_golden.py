@@ -1,0 +1,109 @@
+"""CPU: pins oracle/esrgan_oracle.py (the restatement) against the golden vectors the unmodified
+reference classes produced (oracle/make_golden.py).  No GPU, no /root/reference needed."""
+import copy
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import esrgan_oracle as O
+
+TOL = 2e-5  # fp32 CPU vs fp32 CPU: only summation order differs
+
+
+@pytest.mark.parametrize("name", ["g_tiny_ragged", "g_mid_24ch", "g_scale2", "g_scale1"])
+def test_generator_forward_backward(name):
+    fx = load_golden(name)
+    sd = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in fx["state_dict"].items())
+    x = fx["x"].clone().requires_grad_(True)
+    y = O.generator_forward(sd, x, fx["kwargs"]["scale"])
+    assert y.shape == fx["y"].shape
+    assert rel_err(y, fx["y"]) < TOL
+    (y * fx["r"]).sum().backward()
+    assert rel_err(x.grad, fx["dx"]) < TOL
+    for k, g in fx["grads"].items():
+        assert rel_err(sd[k].grad, g) < 5e-5, k
+
+
+@pytest.mark.parametrize("name", ["d_tiny", "d_in6_noskip"])
+def test_discriminator_forward_backward(name):
+    fx = load_golden(name)
+    sd = OrderedDict((k, (v.clone().requires_grad_(True) if k in O.D_PARAM_KEYS else v.clone()))
+                     for k, v in fx["state_dict_before"].items())
+    x = fx["x"].clone().requires_grad_(True)
+    y = O.discriminator_forward(sd, x, train=True, skip_connection=fx["kwargs"]["skip_connection"])
+    assert rel_err(y, fx["y"]) < TOL
+    (y * fx["r"]).sum().backward()
+    assert rel_err(x.grad, fx["dx"]) < TOL
+    for k, g in fx["grads"].items():
+        assert rel_err(sd[k].grad, g) < 5e-5, k
+    # power-iteration buffers after one train-mode forward
+    for n in O.SN_LAYERS:
+        for s in (".weight_u", ".weight_v"):
+            assert rel_err(sd[n + s], fx["state_dict_after"][n + s]) < TOL, n + s
+    # eval: no power iteration, uses the stored u, v
+    sd_eval = OrderedDict((k, v.clone()) for k, v in fx["state_dict_after"].items())
+    with torch.no_grad():
+        y_eval = O.discriminator_forward(sd_eval, fx["x"], train=False,
+                                         skip_connection=fx["kwargs"]["skip_connection"])
+    assert rel_err(y_eval, fx["y_eval"]) < TOL
+    for n in O.SN_LAYERS:
+        assert torch.equal(sd_eval[n + ".weight_u"], fx["state_dict_after"][n + ".weight_u"])
+
+
+@pytest.mark.parametrize("name", ["step_tiny", "step_tiny_feedlr"])
+def test_train_step(name):
+    fx = load_golden(name)
+    cfg = O.StepConfig(l1_weight=fx["l1_weight"], gan_weight=fx["gan_weight"], lr_g=fx["lr"], lr_d=fx["lr"],
+                       betas=tuple(fx["betas"]), ema_decay=fx["ema_decay"], feed_disc_lr=fx["feed_disc_lr"])
+    m = O.ESRGANOracle(fx["g0"], fx["d0"], cfg)
+    for it, (lr, gt) in enumerate(fx["data"], start=1):
+        log = m.step(lr, gt, it)
+        for k, v in fx["logs"][it - 1].items():
+            assert abs(log[k] - v) <= 2e-5 * max(1.0, abs(v)), (it, k, log[k], v)
+        if it == 1:
+            for k, g in fx["g_grads_iter1"].items():
+                assert rel_err(m.g_grads[k], g) < 1e-4, k
+            for k, g in fx["d_grads_iter1"].items():
+                assert rel_err(m.d_grads[k], g) < 1e-4, k
+    # Adam with tiny grads amplifies rounding through g/sqrt(v): compare the parameter *update*
+    for k, v in fx["g_final"].items():
+        upd_ref = v - fx["g0"][k]
+        upd = m.g[k] - fx["g0"][k]
+        assert (upd - upd_ref).abs().max() <= 2e-2 * upd_ref.abs().max() + 1e-9, k
+    for k, v in fx["d_final"].items():
+        ref0 = fx["d0"][k]
+        assert (m.d[k] - v).abs().max() <= 2e-2 * (v - ref0).abs().max() + 1e-6, k
+    for k, v in fx["g_ema_final"].items():
+        assert rel_err(m.g_ema[k], v) < 1e-5, k
+    assert rel_err(m.output, fx["output_last"]) < 1e-4
+
+
+def test_index_maps():
+    fx = load_golden("index_maps")
+    for key, ref in fx.items():
+        if key.startswith("unshuffle"):
+            c, hh, hw, s = map(int, key.split("_")[1:])
+            x = torch.arange(c * hh * hw, dtype=torch.float32).view(1, c, hh, hw)
+            assert torch.equal(O.pixel_unshuffle(x, s).to(torch.int64), ref)
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32).view(1, 2, 3, 5)
+    for f, key in ((2, "nearest2_2_3_5"), (4, "nearest4_2_3_5")):
+        iy = torch.arange(3 * f) // f
+        ix = torch.arange(5 * f) // f
+        assert torch.equal(x[:, :, iy][:, :, :, ix].to(torch.int64), fx[key])
+    assert torch.equal(O.nearest_up2_index(6), torch.tensor([0, 0, 1, 1, 2, 2]))
+    offs = O.stitch_offsets(16, 128)
+    assert offs[3][5] == (384, 640) and offs[15][15] == (1920, 1920)
+    q = O.quantize_u8_truncate(torch.tensor([-0.1, 0.0, 0.5, 0.999, 1.0, 1.5]))
+    assert q.tolist() == [0, 0, 127, 254, 255, 255]
+
+
+def test_flop_model_matches_baseline_md():
+    # BASELINE.md §3 table
+    assert abs(O.step_gflop_per_image(3, 3) - 213.71) < 0.02
+    assert abs(O.step_gflop_per_image(24, 3) - 213.76) < 0.02
+    assert abs(O.step_gflop_per_image(96, 3) - 213.93) < 0.02
+    assert abs(O.step_gflop_per_image(24, 27) - 216.48) < 0.02
+    assert abs(2 * sum(O.generator_conv_macs(3).values()) / 1e9 - 36.714) < 0.005
+    assert abs(2 * sum(O.discriminator_conv_macs(3).values()) / 1e9 - 12.960) < 0.005

@@ -1,0 +1,208 @@
+/*
+ * ssr_hip.h — C ABI of libssr_hip.so: the MI355X (gfx950) kernels under the ESRGAN hot path of
+ * allenai/satlas-super-resolution.
+ *
+ * The reference has no native layer: its "kernels" are the ATen/cuDNN ops that its Python issues
+ * (SURVEY.md §2.3).  Each entry point below names the reference call site(s) (file:line, relative
+ * to /root/reference) whose device work it replaces.  All entry points
+ *   - take raw device pointers, sizes and a hipStream_t (as void*); no torch types;
+ *   - never allocate, never synchronise, are hipGraph-capturable;
+ *   - return 0 on success, a negative SSR_E* code on a bad descriptor, or the positive hipError_t
+ *     of a failed launch.
+ *
+ * Data layout: activations are NHWC ("pixel-major"), element type fp32 (SSR_F32) or bf16
+ * (SSR_BF16); a tensor is described by (base pointer, channel stride `cs` = channels of the
+ * underlying buffer, channel offset `coff`), so a conv can read/write a channel slice of a wider
+ * buffer — this is how the dense blocks run without torch.cat (rrdbnet_arch.py:39-42).
+ * Channel strides/offsets are multiples of 8 elements.  Master weights are fp32 OIHW exactly as in
+ * the reference's state_dict; kernels consume packed copies produced by ssr_pack_weights.
+ */
+#ifndef SSR_HIP_H
+#define SSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSR_F32 0
+#define SSR_BF16 1
+
+#define SSR_OK 0
+#define SSR_EINVAL (-1)   /* bad descriptor (unsupported geometry / alignment) */
+#define SSR_EUNSUP (-2)   /* combination not instantiated */
+
+#define SSR_ACT_NONE 0
+#define SSR_ACT_LRELU 1   /* LeakyReLU(0.2): rrdbnet_arch.py:32, discriminator_arch.py:44-68 */
+
+/* A channel-sliced NHWC view. */
+typedef struct ssr_view {
+    void* p;          /* base pointer of the buffer (element type = desc dtype) */
+    int32_t cs;       /* channels of the underlying buffer (pixel stride, in elements) */
+    int32_t coff;     /* first channel of the slice */
+} ssr_view;
+
+/*
+ * Direct (im2col-free) convolution on MFMA.  One descriptor covers
+ *   forward:  nn.Conv2d 3x3 s1 p1 (rrdbnet_arch.py:26-30,99-112; discriminator_arch.py:28,34-40),
+ *             4x4 s2 p1 (discriminator_arch.py:30-32), with F.interpolate(x2,'nearest') folded into
+ *             the input read (`up`=2; rrdbnet_arch.py:127-128: source index = floor(o/2)),
+ *   dgrad:    the same kernel with flipped/transposed packed weights; the stride-2 transposed conv is
+ *             run as four 2x2 output-parity classes (oys/oyo/oxs/oxo),
+ * plus the fused epilogue that replaces the reference's elementwise ops:
+ *   s0 = alpha * act(acc + bias)                     -> y0 (optional)
+ *   s1 = s0 + beta1*r1[c<r1_nc] + beta2*r2[c<r2_nc] (+ y_old if accumulate) -> y1 (optional)
+ *   s2 = s1 * lrelu'(m) for channels in [m_c0, m_c1) -> y
+ * (bias+LeakyReLU: rrdbnet_arch.py:38-41; x5*0.2+x and out*0.2+x: :44,:68; feat+body_feat: :125;
+ *  lrelu(...)+skip: discriminator_arch.py:53-64; LeakyReLU backward masks and grad fan-in sums for
+ *  autograd's backward of all of the above.)
+ */
+typedef struct ssr_conv_desc {
+    int32_t dtype;            /* SSR_F32 | SSR_BF16 (x, w, y*, r*, m element type) */
+    /* input side */
+    ssr_view x;
+    int32_t N, Hi, Wi;        /* stored input dims */
+    int32_t up;               /* 1, or 2 = nearest x2 upsample on read (logical dims Hi*up x Wi*up) */
+    int32_t Cin;              /* channels contracted (multiple of 8) */
+    /* packed weights [KH*KW][CoutPad][CinPad], CinPad = roundup(Cin, 16 (f32) | 32 (bf16)) */
+    const void* w;
+    int32_t CoutPad;          /* multiple of 32 */
+    const float* bias;        /* Cout floats or NULL */
+    /* geometry: grid position (gy,gx), tap (ty,tx) reads logical input (gy*stride+ty-pad_y, gx*stride+tx-pad_x) */
+    int32_t KH, KW, stride, pad_y, pad_x;
+    int32_t Gh, Gw;           /* output grid */
+    /* output side: grid (gy,gx) -> stored pixel (gy*oys+oyo, gx*oxs+oxo) of Ho x Wo buffers */
+    int32_t Ho, Wo, oys, oyo, oxs, oxo;
+    int32_t Cout;             /* valid output channels (<= CoutPad) */
+    ssr_view y, y0, y1;       /* y required; y0/y1 optional (p == NULL) */
+    float alpha;
+    int32_t act;
+    ssr_view r1; int32_t r1_nc; float beta1;
+    ssr_view r2; int32_t r2_nc; float beta2;
+    int32_t accumulate;
+    ssr_view m; int32_t m_c0, m_c1;   /* mask source: m[p, m.coff + c] for output channel c */
+} ssr_conv_desc;
+
+int ssr_conv2d(const ssr_conv_desc* d, void* stream);
+
+/*
+ * Weight gradient (autograd's convolution_backward weight/bias part, triggered at
+ * ssr_esrgan_model.py:192,221,227):
+ *   dW[co][ci][ky][kx] += alpha * sum_{n,gy,gx} dY[n, gy, gx, co] * X[n, gy*stride+ky-pad_y, gx*stride+kx-pad_x, ci]
+ *   db[co]             += alpha * sum dY
+ * dW/db are fp32 in the reference's OIHW layout.  Many layers can be processed by one launch: the
+ * host passes device tables of layer descriptors and of work items (layer, co/ci tile, pixel-tile range).
+ */
+typedef struct ssr_wgrad_layer {
+    ssr_view x;               /* forward input (same meaning as ssr_conv_desc.x) */
+    ssr_view dy;              /* gradient w.r.t. the conv output (pre-activation), Gh x Gw pixels */
+    int32_t N, Hi, Wi, up, Cin, Cout;
+    int32_t pad_y, pad_x, Gh, Gw;
+    float alpha;
+    float* dw;                /* [Cout][Cin_w][KH][KW] fp32 */
+    int32_t Cin_w;            /* Cin of the weight tensor (== real input channels; <= Cin) */
+    float* db;                /* [Cout] or NULL */
+} ssr_wgrad_layer;
+
+typedef struct ssr_wgrad_item {
+    int32_t layer, co0, ci0, tile_begin, tile_end, atomic;
+} ssr_wgrad_item;
+
+int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
+                     int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream);
+/* pixel tiles per image for the wgrad tiling (host helper for building items) */
+int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw);
+
+/*
+ * Weight packing (once per optimizer step; replaces cuDNN's internal filter transforms).
+ * Table entry: src fp32 OIHW -> fwd [tap][CoutPad][CinPad] and dgrad layouts, optionally scaled by
+ * 1/sigma (spectral norm, W_orig/sigma: torch.nn.utils.spectral_norm at discriminator_arch.py:30-39).
+ */
+typedef struct ssr_pack_item {
+    const float* src;         /* [Cout][Cin][KH][KW] */
+    const float* inv_scale;   /* device scalar sigma (weights are divided by it) or NULL */
+    void* dst_fwd;            /* [KH*KW][CoutPad][CinPad] or NULL */
+    void* dst_dgrad;          /* stride 1: [KH*KW][CinPadO][CoutPadI] (taps flipped); stride 2 (4x4):
+                                 [4 parity classes][4 taps][CinPadO][CoutPadI]; or NULL */
+    int32_t Cout, Cin, KH, KW, stride;
+    int32_t CoutPad, CinPad;      /* fwd padding */
+    int32_t CinPadO, CoutPadI;    /* dgrad: "output" channels (=Cin) padded to 32, "input" (=Cout) padded to CK */
+} ssr_pack_item;
+
+int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream);
+
+/* ---- layout conversion at the plugin boundary (NCHW fp32 tensors of the reference API) ---- */
+/* dst NHWC[n,h,w,coff+c] = src NCHW fp32 [n,c,h,w] * scale, optionally through pixel_unshuffle
+ * (arch_util.py:769-785; `unshuffle` = 1 none | 2 | 4) and nearest upsampling by `up`
+ * (lr_resized, ssr_esrgan_model.py:133). */
+int ssr_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, ssr_view dst, int32_t dtype,
+                     int32_t unshuffle, int32_t up, float scale, void* stream);
+int ssr_nhwc_to_nchw(ssr_view src, int32_t dtype, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                     void* stream);
+/* inverse for gradients: dst NCHW fp32 [n,c,h,w] (+)= src NHWC slice */
+int ssr_fill(void* p, int64_t n_elems, int32_t dtype, float value, void* stream);
+
+/* ---- bilinear x2 (align_corners=False): discriminator_arch.py:50,55,60 ---- */
+/* y[n,2H,2W,C] = bilinear(a (+ b)) ; b optional (skip-add folded into the read) */
+int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                       void* stream);
+/* s1 = bilinear2x^T(dy) (+ r if r.p) -> y1 (optional); y = s1 * lrelu'(m) (m optional) */
+int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,
+                       int32_t H, int32_t W, int32_t C, void* stream);
+/* nearest x2 backward (2x2 sum) with the same epilogue: rrdbnet_arch.py:127-128 backward */
+int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,
+                      int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---- spectral norm (torch.nn.utils.spectral_norm, discriminator_arch.py:7,26,30-39) ---- */
+typedef struct ssr_sn_item {
+    const float* w;           /* weight_orig as [rows = Cout][cols = Cin*KH*KW] */
+    float* u;                 /* [rows] in/out */
+    float* v;                 /* [cols] in/out */
+    float* sigma;             /* out: scalar */
+    float* tmp;               /* [rows + cols + 4] scratch */
+    int32_t rows, cols;
+} ssr_sn_item;
+/* one power iteration (train mode) for every layer in the table, then sigma = u.(W v);
+ * with power_iter = 0 only sigma is recomputed (eval mode) */
+int ssr_spectral_norm(const ssr_sn_item* items_dev, int32_t n_items, int32_t max_rows, int32_t max_cols,
+                      int32_t power_iter, void* stream);
+/* backward through W_sn = W/sigma: dW_orig += (dW_sn - <dW_sn, W_sn> u v^T) / sigma */
+typedef struct ssr_sn_bwd_item {
+    const float* dw_sn; const float* w; const float* u; const float* v; const float* sigma;
+    float* dw; float* tmp; int32_t rows, cols;
+} ssr_sn_bwd_item;
+int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n_items, int32_t max_elems, void* stream);
+
+/* ---- losses (BasicSR L1Loss / GANLoss('vanilla'); call sites ssr_esrgan_model.py:148,182,218,224) ---- */
+/* loss_out[0] += weight * mean|a-b| over (N,H,W,C valid); grad (optional) = weight*sign(a-b)/numel */
+int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
+                float* loss_out, void* stream);
+/* BCE-with-logits against constant target t: loss_out[0] += weight*mean(softplus(x) - x*t);
+ * mean_out[0] += mean(x) (optional); grad = weight*(sigmoid(x)-t)/numel (optional) */
+int ssr_bce_logits_loss(ssr_view x, ssr_view grad, int32_t dtype, int64_t npix, float target, float weight,
+                        float* loss_out, float* mean_out, void* stream);
+
+/* ---- optimizer: torch.optim.Adam (weight_decay 0, eps 1e-8) over a flat fp32 arena, with the
+ *      BasicSR model_ema update fused (ssr_esrgan_model.py:193,228,230-231) ---- */
+typedef struct ssr_adam_args {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    float* ema;               /* NULL or EMA arena: ema = ema*decay + p*(1-decay) */
+    int64_t n;
+    const float* lr;          /* device scalar */
+    int32_t* step;            /* device counter, incremented by the kernel launch */
+    float beta1, beta2, eps, ema_decay, grad_scale;
+} ssr_adam_args;
+int ssr_adam_step(const ssr_adam_args* a, void* stream);
+
+/* y = a*x + b*y over n fp32 elements (grad averaging / accumulation helpers) */
+int ssr_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
+
+/* library / device info: writes "gfx950 CUs=256 ..." style text */
+int ssr_device_info(char* buf, int32_t buflen);
+int ssr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSR_HIP_H */

@@ -1,0 +1,51 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 32x32 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define LRELU_SLOPE 0.2f
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int VEC = 4; };
+template <> struct DT<__bf16> { static constexpr int VEC = 8; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLOPE * v; }
+// derivative recovered from the *output* of LeakyReLU (sign is preserved for slope > 0);
+// at exactly 0 torch's leaky_relu_backward uses (x > 0 ? 1 : slope).
+__device__ __forceinline__ float lrelu_grad_from_out(float out) { return out > 0.f ? 1.f : LRELU_SLOPE; }
+
+// One 16-byte LDS/global operand read feeds the matrix core:
+//   fp32 : 4 x v_mfma_f32_32x32x2_f32  (lane (i,g) holds channels g*4+s, s = 0..3  -> 8 channels / read)
+//   bf16 : 1 x v_mfma_f32_32x32x16_bf16 (lane (i,g) holds channels g*8+t, t = 0..7 -> 16 channels / read)
+template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<__bf16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                  0, 0, 0);
+}
+
+// C/D fragment of a 32x32 MFMA: lane l holds column (l & 31), rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+__device__ __forceinline__ int mfma32_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+#define SSR_LAUNCH_CHECK()                       \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)

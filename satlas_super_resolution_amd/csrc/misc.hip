@@ -1,0 +1,572 @@
+// Bandwidth-bound kernels around the convolutions: weight packing, NCHW<->NHWC boundary conversion,
+// bilinear/nearest x2 (backward), spectral norm, losses, fused Adam+EMA.  All are coalesced over the
+// channel (fastest NHWC) axis; reductions are wave-shuffle (64 lanes) -> LDS -> one atomic per block.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// sum over a workgroup of up to 1024 threads; result valid in thread 0 (and broadcast through LDS)
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x < 64) {
+        s = (threadIdx.x < nw) ? sh[threadIdx.x] : 0.f;
+        s = wave_sum(s);
+        if (threadIdx.x == 0) sh[0] = s;
+    }
+    __syncthreads();
+    return sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restrict__ items) {
+    const ssr_pack_item it = items[blockIdx.y];
+    const int KK = it.KH * it.KW;
+    const float inv = it.inv_scale ? 1.0f / it.inv_scale[0] : 1.0f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it.dst_fwd) {
+        T* __restrict__ dst = reinterpret_cast<T*>(it.dst_fwd);
+        const long total = (long)KK * it.CoutPad * it.CinPad;
+        for (long e = t0; e < total; e += stride) {
+            const int ci = (int)(e % it.CinPad);
+            const long q = e / it.CinPad;
+            const int co = (int)(q % it.CoutPad), tap = (int)(q / it.CoutPad);
+            float v = 0.f;
+            if (co < it.Cout && ci < it.Cin) v = it.src[((long)co * it.Cin + ci) * KK + tap] * inv;
+            dst[e] = from_f32<T>(v);
+        }
+    }
+    if (it.dst_dgrad) {
+        T* __restrict__ dst = reinterpret_cast<T*>(it.dst_dgrad);
+        if (it.stride == 1) {
+            // Wd[tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
+            const long total = (long)KK * it.CinPadO * it.CoutPadI;
+            for (long e = t0; e < total; e += stride) {
+                const int k = (int)(e % it.CoutPadI);
+                const long q = e / it.CoutPadI;
+                const int o = (int)(q % it.CinPadO), tap = (int)(q / it.CinPadO);
+                float v = 0.f;
+                if (k < it.Cout && o < it.Cin) v = it.src[((long)k * it.Cin + o) * KK + (KK - 1 - tap)] * inv;
+                dst[e] = from_f32<T>(v);
+            }
+        } else {
+            // 4x4 stride-2 transposed conv as four output-parity classes of 2x2 taps:
+            // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x)
+            const long total = (long)16 * it.CinPadO * it.CoutPadI;
+            for (long e = t0; e < total; e += stride) {
+                const int k = (int)(e % it.CoutPadI);
+                long q = e / it.CoutPadI;
+                const int o = (int)(q % it.CinPadO); q /= it.CinPadO;
+                const int t = (int)(q & 3), cls = (int)(q >> 2);
+                const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
+                const int ky = py ? 2 - 2 * ty : 3 - 2 * ty, kx = px ? 2 - 2 * tx : 3 - 2 * tx;
+                float v = 0.f;
+                if (k < it.Cout && o < it.Cin) v = it.src[((long)k * it.Cin + o) * 16 + ky * 4 + kx] * inv;
+                dst[e] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// boundary layout conversion
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int N, int C, int H, int W,
+                                                           ssr_view dst, int s, int up, float scale) {
+    // logical output: C2 = C*s*s channels, H2 = H/s*up, W2 = W/s*up
+    const int C2 = C * s * s, H2 = H / s * up, W2 = W / s * up;
+    const long total = (long)N * H2 * W2 * C2;
+    T* __restrict__ d = reinterpret_cast<T*>(dst.p);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c2 = (int)(e % C2);
+        long q = e / C2;
+        const int x = (int)(q % W2); q /= W2;
+        const int y = (int)(q % H2);
+        const int n = (int)(q / H2);
+        const int ys = y / up, xs = x / up;              // nearest: floor(o / up)
+        const int c = c2 / (s * s), i = (c2 / s) % s, j = c2 % s;  // pixel_unshuffle index map
+        const float v = src[(((long)n * C + c) * H + ys * s + i) * W + xs * s + j] * scale;
+        d[(((long)n * H2 + y) * W2 + x) * dst.cs + dst.coff + c2] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(ssr_view src, float* __restrict__ dst, int N, int C, int H,
+                                                           int W) {
+    const long total = (long)N * C * H * W;
+    const T* __restrict__ s = reinterpret_cast<const T*>(src.p);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W);
+        long q = e / W;
+        const int y = (int)(q % H); q /= H;
+        const int c = (int)(q % C);
+        const int n = (int)(q / C);
+        dst[e] = to_f32(s[(((long)n * H + y) * W + x) * src.cs + src.coff + c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* __restrict__ p, long n, float v) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        p[e] = from_f32<T>(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear x2, align_corners=False (ATen upsample_bilinear2d semantics: src = max(0.5*o - 0.25, 0))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_src(int o, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    float s = 0.5f * (float)o - 0.25f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(ssr_view a, ssr_view b, ssr_view y, int N, int H, int W,
+                                                             int C) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const long total = (long)N * H2 * W2 * C;
+    const T* __restrict__ ap = reinterpret_cast<const T*>(a.p);
+    const T* __restrict__ bp = reinterpret_cast<const T*>(b.p);
+    T* __restrict__ yp = reinterpret_cast<T*>(y.p);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long q = e / C;
+        const int ox = (int)(q % W2); q /= W2;
+        const int oy = (int)(q % H2);
+        const int n = (int)(q / H2);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bil_src(oy, H, y0, y1, ly0, ly1);
+        bil_src(ox, W, x0, x1, lx0, lx1);
+        auto rd = [&](int yy, int xx) {
+            const long p = ((long)n * H + yy) * W + xx;
+            float v = to_f32(ap[p * a.cs + a.coff + c]);
+            if (bp) v += to_f32(bp[p * b.cs + b.coff + c]);
+            return v;
+        };
+        const float v = ly0 * (lx0 * rd(y0, x0) + lx1 * rd(y0, x1)) + ly1 * (lx0 * rd(y1, x0) + lx1 * rd(y1, x1));
+        yp[(((long)n * H2 + oy) * W2 + ox) * y.cs + y.coff + c] = from_f32<T>(v);
+    }
+}
+
+__device__ __forceinline__ float bil_w(int o, int n_in, int i) {  // weight of input i in output o
+    int i0, i1;
+    float l0, l1;
+    bil_src(o, n_in, i0, i1, l0, l1);
+    return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// MODE 0: bilinear x2 transpose; MODE 1: nearest x2 transpose (2x2 sum)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m,
+                                                       int N, int H, int W, int C) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const long total = (long)N * H * W * C;
+    const T* __restrict__ dp = reinterpret_cast<const T*>(dy.p);
+    const T* __restrict__ rp = reinterpret_cast<const T*>(r.p);
+    const T* __restrict__ mp = reinterpret_cast<const T*>(m.p);
+    T* __restrict__ y1p = reinterpret_cast<T*>(y1.p);
+    T* __restrict__ yp = reinterpret_cast<T*>(y.p);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long q = e / C;
+        const int ix = (int)(q % W); q /= W;
+        const int iy = (int)(q % H);
+        const int n = (int)(q / H);
+        float s = 0.f;
+        if (MODE == 0) {
+#pragma unroll
+            for (int dyy = -1; dyy <= 2; ++dyy) {
+                const int oy = 2 * iy + dyy;
+                if (oy < 0 || oy >= H2) continue;
+                const float wy = bil_w(oy, H, iy);
+                if (wy == 0.f) continue;
+#pragma unroll
+                for (int dxx = -1; dxx <= 2; ++dxx) {
+                    const int ox = 2 * ix + dxx;
+                    if (ox < 0 || ox >= W2) continue;
+                    const float wx = bil_w(ox, W, ix);
+                    if (wx == 0.f) continue;
+                    s += wy * wx * to_f32(dp[(((long)n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    s += to_f32(dp[(((long)n * H2 + 2 * iy + a) * W2 + 2 * ix + b) * dy.cs + dy.coff + c]);
+        }
+        const long p = ((long)n * H + iy) * W + ix;
+        if (rp) s += to_f32(rp[p * r.cs + r.coff + c]);
+        if (y1p) y1p[p * y1.cs + y1.coff + c] = from_f32<T>(s);
+        if (mp) s *= lrelu_grad_from_out(to_f32(mp[p * m.cs + m.coff + c]));
+        if (yp) yp[p * y.cs + y.coff + c] = from_f32<T>(s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectral norm power iteration (torch.nn.utils.spectral_norm, eps = 1e-12)
+//   tmp layout: [0..rows) = s = W v ; [rows..rows+cols) = t = W^T u ; [rows+cols] = scratch
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const ssr_sn_item* __restrict__ items) {
+    const ssr_sn_item it = items[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= it.cols) return;
+    float s = 0.f;
+    for (int i = 0; i < it.rows; ++i) s += it.w[(long)i * it.cols + j] * it.u[i];
+    it.tmp[it.rows + j] = s;
+}
+
+// one wave per row: s_i = sum_j W[i][j] * vhat[j], vhat = t / max(|t|, eps) (power_iter) or v (eval)
+__global__ __launch_bounds__(256) void sn_wv_kernel(const ssr_sn_item* __restrict__ items, int power_iter) {
+    __shared__ float sh[16];
+    const ssr_sn_item it = items[blockIdx.y];
+    const float* vsrc = power_iter ? it.tmp + it.rows : it.v;
+    float inv = 1.f;
+    if (power_iter) {
+        float ss = 0.f;
+        for (int j = threadIdx.x; j < it.cols; j += blockDim.x) ss += vsrc[j] * vsrc[j];
+        ss = block_sum(ss, sh);
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        if (blockIdx.x == 0)
+            for (int j = threadIdx.x; j < it.cols; j += blockDim.x) it.v[j] = vsrc[j] * inv;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= it.rows) return;
+    float s = 0.f;
+    for (int j = lane; j < it.cols; j += 64) s += it.w[(long)row * it.cols + j] * vsrc[j];
+    s = wave_sum(s) * inv;
+    if (lane == 0) it.tmp[row] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_finish_kernel(const ssr_sn_item* __restrict__ items, int power_iter) {
+    __shared__ float sh[16];
+    const ssr_sn_item it = items[blockIdx.x];
+    if (power_iter) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < it.rows; i += blockDim.x) ss += it.tmp[i] * it.tmp[i];
+        ss = block_sum(ss, sh);
+        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int i = threadIdx.x; i < it.rows; i += blockDim.x) it.u[i] = it.tmp[i] * inv;
+        if (threadIdx.x == 0) it.sigma[0] = ss * inv;  // u . (W v) with u = s/|s|
+    } else {
+        float d = 0.f;
+        for (int i = threadIdx.x; i < it.rows; i += blockDim.x) d += it.tmp[i] * it.u[i];
+        d = block_sum(d, sh);
+        if (threadIdx.x == 0) it.sigma[0] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const ssr_sn_bwd_item* __restrict__ items) {
+    __shared__ float sh[16];
+    const ssr_sn_bwd_item it = items[blockIdx.y];
+    const long n = (long)it.rows * it.cols;
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        s += it.dw_sn[e] * it.w[e];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(it.tmp, s);
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const ssr_sn_bwd_item* __restrict__ items) {
+    const ssr_sn_bwd_item it = items[blockIdx.y];
+    const long n = (long)it.rows * it.cols;
+    const float sigma = it.sigma[0];
+    const float coef = it.tmp[0] / (sigma * sigma);  // <dW_sn, W> / sigma^2 = <dW_sn, W_sn> / sigma
+    const float inv = 1.f / sigma;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / it.cols), j = (int)(e - (long)i * it.cols);
+        it.dw[e] += it.dw_sn[e] * inv - coef * it.u[i] * it.v[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l1_loss_kernel(ssr_view a, ssr_view b, ssr_view grad, long npix, int C,
+                                                      float weight, float* __restrict__ loss_out) {
+    __shared__ float sh[16];
+    const long total = npix * C;
+    const float invn = 1.f / (float)total;
+    const T* __restrict__ ap = reinterpret_cast<const T*>(a.p);
+    const T* __restrict__ bp = reinterpret_cast<const T*>(b.p);
+    T* __restrict__ gp = reinterpret_cast<T*>(grad.p);
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long p = e / C;
+        const int c = (int)(e - p * C);
+        const float d = to_f32(ap[p * a.cs + a.coff + c]) - to_f32(bp[p * b.cs + b.coff + c]);
+        s += fabsf(d);
+        if (gp) gp[p * grad.cs + grad.coff + c] = from_f32<T>(d > 0.f ? weight * invn : (d < 0.f ? -weight * invn : 0.f));
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, s * weight * invn);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_loss_kernel(ssr_view x, ssr_view grad, long npix, float target,
+                                                       float weight, float* __restrict__ loss_out,
+                                                       float* __restrict__ mean_out) {
+    __shared__ float sh[16];
+    const float invn = 1.f / (float)npix;
+    const T* __restrict__ xp = reinterpret_cast<const T*>(x.p);
+    T* __restrict__ gp = reinterpret_cast<T*>(grad.p);
+    float s = 0.f, sm = 0.f;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const float v = to_f32(xp[p * x.cs + x.coff]);
+        // BCEWithLogits: max(x,0) - x*t + log1p(exp(-|x|))
+        s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+        sm += v;
+        if (gp) {
+            const float sig = 1.f / (1.f + expf(-v));
+            gp[p * grad.cs + grad.coff] = from_f32<T>((sig - target) * weight * invn);
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, s * weight * invn);
+    if (mean_out) {
+        sm = block_sum(sm, sh);
+        if (threadIdx.x == 0) atomicAdd(mean_out, sm * invn);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor math) + EMA, one launch per flat arena
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const ssr_adam_args a) {
+    const int t = a.step[0] + 1;
+    const float lr = a.lr[0];
+    const float bc1 = 1.f - powf(a.beta1, (float)t);
+    const float bc2 = 1.f - powf(a.beta2, (float)t);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += (long)gridDim.x * blockDim.x) {
+        const float g = a.grad[e] * a.grad_scale;
+        float m = a.exp_avg[e], v = a.exp_avg_sq[e];
+        m = m + (g - m) * (1.f - a.beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + (1.f - a.beta2) * g * g;         // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+        const float p = a.param[e] - step_size * (m / denom);
+        a.exp_avg[e] = m;
+        a.exp_avg_sq[e] = v;
+        a.param[e] = p;
+        if (a.ema) a.ema[e] = a.ema[e] * a.ema_decay + p * (1.f - a.ema_decay);
+    }
+}
+__global__ void bump_kernel(int32_t* step) { step[0] += 1; }
+
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b,
+                                                    float* __restrict__ y, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        y[e] = a * x[e] + (b == 0.f ? 0.f : b * y[e]);
+}
+
+inline int grid_for(long total, int per_block = 256, int cap = 4096) {
+    long g = (total + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream) {
+    if (!items_dev || n_items <= 0) return SSR_EINVAL;
+    dim3 grid(64, n_items);
+    if (dtype == SSR_F32) hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, ssr_view dst,
+                                int32_t dtype, int32_t unshuffle, int32_t up, float scale, void* stream) {
+    if (!src || !dst.p || unshuffle < 1 || up < 1 || H % unshuffle || W % unshuffle) return SSR_EINVAL;
+    const long total = (long)N * C * H * W * up * up;
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST(stream), src, N, C, H, W,
+                           dst, unshuffle, up, scale);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, ST(stream), src, N, C, H,
+                           W, dst, unshuffle, up, scale);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_nhwc_to_nchw(ssr_view src, int32_t dtype, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                                void* stream) {
+    if (!src.p || !dst) return SSR_EINVAL;
+    const long total = (long)N * C * H * W;
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST(stream), src, dst, N, C,
+                           H, W);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, ST(stream), src, dst, N, C,
+                           H, W);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_fill(void* p, int64_t n, int32_t dtype, float value, void* stream) {
+    if (!p || n < 0) return SSR_EINVAL;
+    if (n == 0) return SSR_OK;
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(fill_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), (float*)p, (long)n, value);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(fill_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, ST(stream), (__bf16*)p, (long)n, value);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, void* stream) {
+    if (!a.p || !y.p) return SSR_EINVAL;
+    const long total = (long)N * H * W * 4 * C;
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
+                           b, y, N, H, W, C);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(bilinear2x_fwd_kernel<__bf16>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
+                           b, y, N, H, W, C);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+template <int MODE>
+static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N, int32_t H,
+                    int32_t W, int32_t C, void* stream) {
+    if (!dy.p || (!y.p && !y1.p)) return SSR_EINVAL;
+    const long total = (long)N * H * W * C;
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL((up2x_bwd_kernel<float, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
+                           dy, r, y1, y, m, N, H, W, C);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL((up2x_bwd_kernel<__bf16, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
+                           dy, r, y1, y, m, N, H, W, C);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+extern "C" int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,
+                                  int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    return up2x_bwd<0>(dy, r, y1, y, m, dtype, N, H, W, C, stream);
+}
+extern "C" int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,
+                                 int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    return up2x_bwd<1>(dy, r, y1, y, m, dtype, N, H, W, C, stream);
+}
+
+extern "C" int ssr_spectral_norm(const ssr_sn_item* items_dev, int32_t n_items, int32_t max_rows, int32_t max_cols,
+                                 int32_t power_iter, void* stream) {
+    if (!items_dev || n_items <= 0 || max_rows <= 0 || max_cols <= 0) return SSR_EINVAL;
+    if (power_iter) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((max_cols + 255) / 256, n_items), dim3(256), 0, ST(stream), items_dev);
+        SSR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sn_wv_kernel, dim3((max_rows + 3) / 4, n_items), dim3(256), 0, ST(stream), items_dev, power_iter);
+    SSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_finish_kernel, dim3(n_items), dim3(256), 0, ST(stream), items_dev, power_iter);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n_items, int32_t max_elems,
+                                     void* stream) {
+    if (!items_dev || n_items <= 0) return SSR_EINVAL;
+    const int gx = grid_for(max_elems, 256 * 8, 256);
+    // NOTE: every item's tmp[0] must be zero on entry (host memsets the scratch arena in-stream)
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(gx, n_items), dim3(256), 0, ST(stream), items_dev);
+    SSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(gx, n_items), dim3(256), 0, ST(stream), items_dev);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
+                           float* loss_out, void* stream) {
+    if (!a.p || !b.p || npix <= 0 || C <= 0) return SSR_EINVAL;
+    const int g = grid_for(npix * C, 256 * 4, 1024);
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(l1_loss_kernel<float>, dim3(g), dim3(256), 0, ST(stream), a, b, grad, (long)npix, C, weight,
+                           loss_out);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(l1_loss_kernel<__bf16>, dim3(g), dim3(256), 0, ST(stream), a, b, grad, (long)npix, C, weight,
+                           loss_out);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_bce_logits_loss(ssr_view x, ssr_view grad, int32_t dtype, int64_t npix, float target, float weight,
+                                   float* loss_out, float* mean_out, void* stream) {
+    if (!x.p || npix <= 0) return SSR_EINVAL;
+    const int g = grid_for(npix, 256 * 4, 1024);
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(bce_loss_kernel<float>, dim3(g), dim3(256), 0, ST(stream), x, grad, (long)npix, target,
+                           weight, loss_out, mean_out);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(bce_loss_kernel<__bf16>, dim3(g), dim3(256), 0, ST(stream), x, grad, (long)npix, target,
+                           weight, loss_out, mean_out);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_adam_step(const ssr_adam_args* a, void* stream) {
+    if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || !a->lr || !a->step || a->n <= 0)
+        return SSR_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a->n, 256 * 4, 2048)), dim3(256), 0, ST(stream), *a);
+    SSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, ST(stream), a->step);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return SSR_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, ST(stream), a, x, b, y, (long)n);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_device_info(char* buf, int32_t buflen) {
+    if (!buf || buflen <= 0) return SSR_EINVAL;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        snprintf(buf, buflen, "no HIP device");
+        return SSR_EINVAL;
+    }
+    snprintf(buf, buflen, "%s arch=%s CUs=%d lds=%zu clock=%dMHz mem=%zuGiB", p.name, p.gcnArchName,
+             p.multiProcessorCount, p.sharedMemPerBlock, p.clockRate / 1000, p.totalGlobalMem >> 30);
+    return SSR_OK;
+}
+
+extern "C" int ssr_abi_version(void) { return 1; }

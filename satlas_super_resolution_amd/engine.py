@@ -1,0 +1,679 @@
+"""Launch plans for the ESRGAN hot path on one MI355X.
+
+A *plan* is a static list of C-ABI calls (include/ssr_hip.h) over preallocated NHWC device buffers:
+  GeneratorPlan      SSR_RRDBNet forward / backward        (/root/reference/ssr/archs/rrdbnet_arch.py:116-137)
+  DiscriminatorPlan  SSR_UNetDiscriminatorSN fwd / bwd     (/root/reference/ssr/archs/discriminator_arch.py:42-71)
+Because shapes are static, a whole plan (or the whole train step built from plans) can be captured in
+one hipGraph.  Dense blocks are concat-free: every RDB owns one [B,H,W,nf+4*gc] buffer, conv_k reads the
+channel prefix and writes its own 32-channel slice; the matching gradient buffer receives dgrad
+fan-in by in-place accumulation with the LeakyReLU-backward mask applied by the *last* contributor.
+All weight gradients of the 3x3 layers are computed by ONE batched wgrad launch at the end.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import hip
+from .hip import ConvDesc, View, WgradItem, WgradLayer, PackItem, SNItem, SNBwdItem, view
+
+
+def rup(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def ck_of(dt: int) -> int:
+    return 16 if dt == hip.F32 else 32
+
+
+@dataclass
+class ConvSpec:
+    name: str
+    cout: int
+    cin: int
+    k: int = 3
+    stride: int = 1
+    bias: bool = True
+    sn: bool = False  # spectral-normalised (weight stored as weight_orig)
+
+
+class ParamStore:
+    """Flat fp32 arenas (param, grad) for one network in the reference's state_dict layout, plus the
+    packed compute-dtype weight copies the kernels read.
+
+    Reference key layout: `<conv>.weight`/`.bias`, or `.weight_orig` (+ buffers
+    `.weight_u`, `.weight_v`) for spectral-normalised layers."""
+
+    def __init__(self, specs: List[ConvSpec], dtype: int, device="cuda"):
+        self.specs = OrderedDict((s.name, s) for s in specs)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.offsets: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        for s in specs:
+            wname = s.name + (".weight_orig" if s.sn else ".weight")
+            shape = (s.cout, s.cin, s.k, s.k)
+            self.offsets[wname] = (off, shape)
+            off += s.cout * s.cin * s.k * s.k
+            off = rup(off, 4)  # 16-byte aligned tensors
+            if s.bias:
+                self.offsets[s.name + ".bias"] = (off, (s.cout,))
+                off += rup(s.cout, 4)
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # spectral-norm state
+        self.sn_names = [s.name for s in specs if s.sn]
+        self.u: Dict[str, torch.Tensor] = {}
+        self.v: Dict[str, torch.Tensor] = {}
+        for s in specs:
+            if s.sn:
+                self.u[s.name] = torch.zeros(s.cout, device=self.device)
+                self.v[s.name] = torch.zeros(s.cin * s.k * s.k, device=self.device)
+        if self.sn_names:
+            self.sigma = torch.ones(len(self.sn_names), device=self.device)
+            mx = max(self.specs[n].cout + self.specs[n].cin * self.specs[n].k ** 2 for n in self.sn_names)
+            self.sn_tmp = torch.zeros(len(self.sn_names), rup(mx + 4, 4), device=self.device)
+            # dW w.r.t. the normalised weight (wgrad target for SN layers), same offsets as `grad`
+            self.grad_sn = torch.zeros(off, dtype=torch.float32, device=self.device)
+            self.sn_dot = torch.zeros(len(self.sn_names), 4, device=self.device)
+        # packed weights
+        tdt = hip.torch_dtype(dtype)
+        ck = ck_of(dtype)
+        self.packed_fwd: Dict[str, torch.Tensor] = {}
+        self.packed_dgrad: Dict[str, torch.Tensor] = {}
+        self.pad: Dict[str, Tuple[int, int, int, int]] = {}
+        items = []
+        for i, s in enumerate(specs):
+            kk = s.k * s.k
+            cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck)
+            cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck)
+            self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)
+            pf = torch.zeros(kk * cout_pad * cin_pad, dtype=tdt, device=self.device)
+            ntap_d = kk if s.stride == 1 else 16
+            pd = torch.zeros(ntap_d * cin_pad_o * cout_pad_i, dtype=tdt, device=self.device)
+            self.packed_fwd[s.name], self.packed_dgrad[s.name] = pf, pd
+            woff, _ = self.offsets[s.name + (".weight_orig" if s.sn else ".weight")]
+            inv = (self.sigma.data_ptr() + 4 * self.sn_names.index(s.name)) if s.sn else None
+            items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, pf.data_ptr(), pd.data_ptr(),
+                                  s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i))
+        self._pack_items = items
+        self.pack_table = hip.device_table(items)
+        if self.sn_names:
+            sn_items, bwd_items = [], []
+            for j, n in enumerate(self.sn_names):
+                s = self.specs[n]
+                woff, _ = self.offsets[n + ".weight_orig"]
+                rows, cols = s.cout, s.cin * s.k * s.k
+                sn_items.append(SNItem(self.data.data_ptr() + 4 * woff, self.u[n].data_ptr(), self.v[n].data_ptr(),
+                                       self.sigma.data_ptr() + 4 * j, self.sn_tmp[j].data_ptr(), rows, cols))
+                bwd_items.append(SNBwdItem(self.grad_sn.data_ptr() + 4 * woff, self.data.data_ptr() + 4 * woff,
+                                           self.u[n].data_ptr(), self.v[n].data_ptr(), self.sigma.data_ptr() + 4 * j,
+                                           self.grad.data_ptr() + 4 * woff, self.sn_dot[j].data_ptr(), rows, cols))
+            self.sn_table = hip.device_table(sn_items)
+            self.sn_bwd_table = hip.device_table(bwd_items)
+            self.sn_max_rows = max(self.specs[n].cout for n in self.sn_names)
+            self.sn_max_cols = max(self.specs[n].cin * self.specs[n].k ** 2 for n in self.sn_names)
+            self.sn_max_elems = max(self.specs[n].cout * self.specs[n].cin * self.specs[n].k ** 2
+                                    for n in self.sn_names)
+
+    # ---- tensor views in the reference layout ----
+    def tensor(self, key: str, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shape = self.offsets[key]
+        n = math.prod(shape)
+        return (self.data if arena is None else arena)[off:off + n].view(shape)
+
+    def ptr(self, key: str, arena: Optional[torch.Tensor] = None) -> int:
+        off, _ = self.offsets[key]
+        return (self.data if arena is None else arena).data_ptr() + 4 * off
+
+    def wkey(self, name: str) -> str:
+        return name + (".weight_orig" if self.specs[name].sn else ".weight")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        with torch.no_grad():
+            for key in self.offsets:
+                if key in sd:
+                    self.tensor(key).copy_(sd[key].to(self.device, torch.float32))
+                elif strict:
+                    raise KeyError(key)
+            for n in self.sn_names:
+                if n + ".weight_u" in sd:
+                    self.u[n].copy_(sd[n + ".weight_u"].to(self.device, torch.float32))
+                    self.v[n].copy_(sd[n + ".weight_v"].to(self.device, torch.float32))
+                elif strict:
+                    raise KeyError(n + ".weight_u")
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        for s in self.specs.values():
+            if s.sn:
+                out[s.name + ".weight_orig"] = self.tensor(s.name + ".weight_orig").clone()
+                out[s.name + ".weight_u"] = self.u[s.name].clone()
+                out[s.name + ".weight_v"] = self.v[s.name].clone()
+            else:
+                out[s.name + ".weight"] = self.tensor(s.name + ".weight").clone()
+            if s.bias:
+                out[s.name + ".bias"] = self.tensor(s.name + ".bias").clone()
+        return out
+
+    # ---- device ops ----
+    def pack(self):
+        hip.check(hip.lib().ssr_pack_weights(self.pack_table.data_ptr(), len(self._pack_items), self.dtype,
+                                             hip.stream_ptr()), "ssr_pack_weights")
+
+    def spectral_norm(self, power_iter: bool):
+        if self.sn_names:
+            hip.check(hip.lib().ssr_spectral_norm(self.sn_table.data_ptr(), len(self.sn_names), self.sn_max_rows,
+                                                  self.sn_max_cols, 1 if power_iter else 0, hip.stream_ptr()),
+                      "ssr_spectral_norm")
+
+    def spectral_norm_backward(self):
+        """grad += d(W/sigma)^T grad_sn ; consumes (and re-zeroes) grad_sn."""
+        if self.sn_names:
+            self.sn_dot.zero_()
+            hip.check(hip.lib().ssr_spectral_norm_bwd(self.sn_bwd_table.data_ptr(), len(self.sn_names),
+                                                      self.sn_max_elems, hip.stream_ptr()), "ssr_spectral_norm_bwd")
+            self.grad_sn.zero_()
+
+
+class Launcher:
+    """An ordered list of prepared C-ABI calls."""
+
+    def __init__(self):
+        self.calls = []
+
+    def add(self, fn, *args, what=""):
+        self.calls.append((fn, args, what))
+
+    def run(self):
+        st = hip.stream_ptr()
+        for fn, args, what in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                hip.check(rc, what or getattr(fn, "__name__", "call"))
+
+    def __len__(self):
+        return len(self.calls)
+
+
+class _ConvBuilder:
+    """Fills ssr_conv_desc records; keeps them alive."""
+
+    def __init__(self, store: ParamStore, N: int):
+        self.store, self.N, self.dt = store, N, store.dtype
+        self.keep = []
+
+    def conv(self, L: Launcher, name: str, x: View, hi: int, wi: int, y: View, *, up=1, act=hip.ACT_NONE, alpha=1.0,
+             y0: View = hip.NULL_VIEW, r1: View = hip.NULL_VIEW, r1_nc=0, beta1=0.0, r2: View = hip.NULL_VIEW,
+             r2_nc=0, beta2=0.0, cin: Optional[int] = None):
+        s = self.store.specs[name]
+        cout_pad, _, _, _ = self.store.pad[name]
+        d = ConvDesc()
+        d.dtype = self.dt
+        d.x, d.N, d.Hi, d.Wi, d.up = x, self.N, hi, wi, up
+        d.Cin = rup(s.cin, 8) if cin is None else cin
+        d.w = self.store.packed_fwd[name].data_ptr()
+        d.CoutPad = cout_pad
+        d.bias = self.store.ptr(name + ".bias") if s.bias else None
+        d.KH = d.KW = s.k
+        d.stride = s.stride
+        d.pad_y = d.pad_x = 1
+        lh, lw = hi * up, wi * up
+        d.Gh, d.Gw = (lh // s.stride, lw // s.stride)
+        d.Ho, d.Wo, d.oys, d.oyo, d.oxs, d.oxo = d.Gh, d.Gw, 1, 0, 1, 0
+        d.Cout = s.cout
+        d.y, d.y0, d.y1 = y, y0, hip.NULL_VIEW
+        d.alpha, d.act = alpha, act
+        d.r1, d.r1_nc, d.beta1 = r1, r1_nc, beta1
+        d.r2, d.r2_nc, d.beta2 = r2, r2_nc, beta2
+        d.accumulate = 0
+        d.m, d.m_c0, d.m_c1 = hip.NULL_VIEW, 0, 0
+        self.keep.append(d)
+        L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv fwd {name}")
+        return d
+
+    def dgrad(self, L: Launcher, name: str, dy: View, gh: int, gw: int, y: View, *, cout: Optional[int] = None,
+              alpha=1.0, y1: View = hip.NULL_VIEW, r1: View = hip.NULL_VIEW, r1_nc=0, beta1=0.0,
+              r2: View = hip.NULL_VIEW, r2_nc=0, beta2=0.0, accumulate=0, m: View = hip.NULL_VIEW, m_c0=0, m_c1=0,
+              cin_dy: Optional[int] = None):
+        """Gradient w.r.t. the conv input.  `dy` lives on the forward output grid (gh x gw).
+        stride 1: one 3x3 conv with rotated weights; stride 2 (4x4): four 2x2 parity-class launches."""
+        s = self.store.specs[name]
+        _, _, cin_pad_o, cout_pad_i = self.store.pad[name]
+        wbase = self.store.packed_dgrad[name].data_ptr()
+        esz = 4 if self.dt == hip.F32 else 2
+        classes = [(0, 0)] if s.stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
+        for (py, px) in classes:
+            d = ConvDesc()
+            d.dtype = self.dt
+            d.x, d.N, d.Hi, d.Wi, d.up = dy, self.N, gh, gw, 1
+            d.Cin = rup(s.cout, 8) if cin_dy is None else cin_dy
+            d.CoutPad = cin_pad_o
+            d.bias = None
+            d.Cout = s.cin if cout is None else cout
+            if s.stride == 1:
+                d.w = wbase
+                d.KH = d.KW = s.k
+                d.stride, d.pad_y, d.pad_x = 1, 1, 1
+                d.Gh, d.Gw = gh, gw
+                d.Ho, d.Wo, d.oys, d.oyo, d.oxs, d.oxo = gh, gw, 1, 0, 1, 0
+            else:
+                cls = py * 2 + px
+                d.w = wbase + cls * 4 * cin_pad_o * cout_pad_i * esz
+                d.KH = d.KW = 2
+                d.stride, d.pad_y, d.pad_x = 1, 1 - py, 1 - px
+                d.Gh, d.Gw = gh, gw
+                d.Ho, d.Wo, d.oys, d.oyo, d.oxs, d.oxo = 2 * gh, 2 * gw, 2, py, 2, px
+            d.y, d.y0, d.y1 = y, hip.NULL_VIEW, y1
+            d.alpha, d.act = alpha, hip.ACT_NONE
+            d.r1, d.r1_nc, d.beta1 = r1, r1_nc, beta1
+            d.r2, d.r2_nc, d.beta2 = r2, r2_nc, beta2
+            d.accumulate = accumulate
+            d.m, d.m_c0, d.m_c1 = m, m_c0, m_c1
+            self.keep.append(d)
+            L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad {name}")
+
+
+class WgradBatch:
+    """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride)."""
+
+    MAX_TILES_PER_ITEM = 128
+
+    def __init__(self, dtype: int, k: int, stride: int):
+        self.dtype, self.k, self.stride = dtype, k, stride
+        self.layers: List[WgradLayer] = []
+        self.items: List[WgradItem] = []
+        self.layer_tab = self.item_tab = None
+
+    def add(self, x: View, dy: View, N, hi, wi, up, cin, cout, gh, gw, alpha, dw_ptr, cin_w, db_ptr):
+        li = len(self.layers)
+        self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, dw_ptr, cin_w, db_ptr))
+        tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw)
+        splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM))
+        per = -(-tiles // splits)
+        for co0 in range(0, cout, 32):
+            for ci0 in range(0, cin_w, 32):
+                for sp in range(splits):
+                    b, e = sp * per, min(tiles, (sp + 1) * per)
+                    if b < e:
+                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if splits > 1 else 0))
+
+    def finalize(self):
+        if self.layers:
+            # heavy items first: better tail behaviour on 256 CUs
+            self.items.sort(key=lambda it: -(it.tile_end - it.tile_begin))
+            self.layer_tab = hip.device_table(self.layers)
+            self.item_tab = hip.device_table(self.items)
+
+    def launch(self, L: Launcher):
+        if self.layers:
+            L.add(hip.lib().ssr_conv2d_wgrad, self.layer_tab.data_ptr(), self.item_tab.data_ptr(), len(self.items),
+                  self.dtype, self.k, self.k, self.stride, what="wgrad batch")
+
+
+# =====================================================================================================
+# Generator
+# =====================================================================================================
+def generator_specs(num_in_ch, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32) -> List[ConvSpec]:
+    """Layer list in the reference's state_dict order (rrdbnet_arch.py:92-114)."""
+    if scale == 2:
+        num_in_ch *= 4
+    elif scale == 1:
+        num_in_ch *= 16
+    nf, gc = num_feat, num_grow_ch
+    specs = [ConvSpec("conv_first", nf, num_in_ch)]
+    for i in range(num_block):
+        for j in (1, 2, 3):
+            for k in range(1, 5):
+                specs.append(ConvSpec(f"body.{i}.rdb{j}.conv{k}", gc, nf + (k - 1) * gc))
+            specs.append(ConvSpec(f"body.{i}.rdb{j}.conv5", nf, nf + 4 * gc))
+    specs.append(ConvSpec("conv_body", nf, nf))
+    specs.append(ConvSpec("conv_up1", nf, nf))
+    specs.append(ConvSpec("conv_up2", nf, nf))
+    if scale in (8, 16):
+        specs.append(ConvSpec("conv_up3", nf, nf))
+        if scale == 16:
+            specs.append(ConvSpec("conv_up4", nf, nf))
+    specs.append(ConvSpec("conv_hr", nf, nf))
+    specs.append(ConvSpec("conv_last", num_out_ch, nf))
+    return specs
+
+
+class GeneratorPlan:
+    """SSR_RRDBNet on NHWC buffers for a fixed (B, H, W)."""
+
+    def __init__(self, store: ParamStore, B: int, H: int, W: int, *, num_in_ch, num_out_ch=3, scale=4, num_feat=64,
+                 num_block=23, num_grow_ch=32, training=True, out_buf: Optional[torch.Tensor] = None,
+                 need_input_grad=False):
+        self.store, self.B, self.dt = store, B, store.dtype
+        self.scale, self.nf, self.nb, self.gc = scale, num_feat, num_block, num_grow_ch
+        self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
+        self.unshuffle = 2 if scale == 2 else 4 if scale == 1 else 1
+        assert H % self.unshuffle == 0 and W % self.unshuffle == 0
+        self.Hin, self.Win = H, W
+        H, W = H // self.unshuffle, W // self.unshuffle
+        self.H, self.W = H, W
+        self.cin_eff = num_in_ch * self.unshuffle ** 2
+        assert num_feat % 8 == 0 and num_grow_ch % 8 == 0, "num_feat/num_grow_ch must be multiples of 8"
+        self.training = training
+        tdt, dev = hip.torch_dtype(self.dt), store.device
+        nf, gc, nb = self.nf, self.gc, self.nb
+        cd = nf + 4 * gc
+        z = lambda *s: torch.zeros(*s, dtype=tdt, device=dev)
+        self.n_up = {1: 2, 2: 2, 4: 2, 8: 3, 16: 4}[scale] if scale in (1, 2, 4, 8, 16) else 2
+        self.up_names = [f"conv_up{i + 1}" for i in range(self.n_up)]
+        self.Ho, self.Wo = H * (1 << self.n_up), W * (1 << self.n_up)
+        self.xin = z(B, H, W, rup(self.cin_eff, 8))
+        n_rdb = 3 * nb
+        n_bufs = n_rdb if training else min(n_rdb, 4)
+        self.bufs = [z(B, H, W, cd) for _ in range(n_bufs)]
+        self.body_out = z(B, H, W, nf)
+        self.trunk = z(B, H, W, nf)
+        self.ups = [z(B, H << (i + 1), W << (i + 1), nf) for i in range(self.n_up)]
+        self.hr = z(B, self.Ho, self.Wo, nf)
+        self.out = out_buf if out_buf is not None else z(B, self.Ho, self.Wo, rup(num_out_ch, 8))
+        assert self.out.shape[:3] == (B, self.Ho, self.Wo)
+        cb = _ConvBuilder(store, B)
+        self._cb = cb
+        # ------------------------------------------------------------------ forward
+        F = Launcher()
+        buf = lambda r: self.bufs[r % n_bufs]
+        # feat must survive until conv_body's trunk add; with rotating buffers (inference) keep a copy
+        self.feat = self.bufs[0] if n_bufs == n_rdb else z(B, H, W, nf)
+        cb.conv(F, "conv_first", view(self.xin), H, W, view(buf(0), 0),
+                y0=hip.NULL_VIEW if n_bufs == n_rdb else view(self.feat))
+        for r in range(n_rdb):
+            i, j = divmod(r, 3)
+            p = f"body.{i}.rdb{j + 1}"
+            cur = buf(r)
+            for k in range(1, 5):
+                cb.conv(F, f"{p}.conv{k}", view(cur, 0), H, W, view(cur, nf + (k - 1) * gc), act=hip.ACT_LRELU,
+                        cin=nf + (k - 1) * gc)
+            dst = view(self.body_out) if r == n_rdb - 1 else view(buf(r + 1), 0)
+            if j < 2:   # x5*0.2 + x                                            (rrdbnet_arch.py:44)
+                cb.conv(F, f"{p}.conv5", view(cur, 0), H, W, dst, alpha=0.2, r1=view(cur, 0), r1_nc=nf, beta1=1.0,
+                        cin=cd)
+            else:       # (x5*0.2 + x)*0.2 + x_rrdb                              (rrdbnet_arch.py:44,68)
+                cb.conv(F, f"{p}.conv5", view(cur, 0), H, W, dst, alpha=0.04, r1=view(cur, 0), r1_nc=nf, beta1=0.2,
+                        r2=view(buf(r - 2), 0), r2_nc=nf, beta2=1.0, cin=cd)
+        # feat + conv_body(body)                                                 (rrdbnet_arch.py:124-125)
+        cb.conv(F, "conv_body", view(self.body_out), H, W, view(self.trunk), r1=view(self.feat, 0), r1_nc=nf, beta1=1.0)
+        src, sh, sw = self.trunk, H, W
+        for i, nm in enumerate(self.up_names):  # lrelu(conv(nearest x2))       (rrdbnet_arch.py:127-128)
+            cb.conv(F, nm, view(src), sh, sw, view(self.ups[i]), up=2, act=hip.ACT_LRELU)
+            src, sh, sw = self.ups[i], sh * 2, sw * 2
+        cb.conv(F, "conv_hr", view(src), sh, sw, view(self.hr), act=hip.ACT_LRELU)
+        cb.conv(F, "conv_last", view(self.hr), sh, sw, view(self.out))
+        self.fwd = F
+        if not training:
+            return
+        assert n_bufs == n_rdb
+        # ------------------------------------------------------------------ backward
+        self.d_out = z(B, self.Ho, self.Wo, self.out.shape[-1])     # dL/d out (valid: num_out_ch channels)
+        self.g_hr = z(B, self.Ho, self.Wo, nf)
+        self.g_ups = [z(B, H << (i + 1), W << (i + 1), nf) for i in range(self.n_up)]
+        self.g_tmp = [z(B, H << (i + 1), W << (i + 1), nf) for i in range(self.n_up)]
+        self.g_trunk = z(B, H, W, nf)
+        self.g_body_out = z(B, H, W, nf)
+        self.dbufs = [z(B, H, W, cd) for _ in range(n_rdb)]
+        self.g_xin = z(B, H, W, self.xin.shape[-1]) if need_input_grad else None
+        Bk = Launcher()
+        wg = WgradBatch(self.dt, 3, 1)
+        st = store
+
+        def add_wg(name, x: View, dy: View, hi, wi, up, gh, gw, alpha=1.0, cin=None):
+            s = st.specs[name]
+            wg.add(x, dy, B, hi, wi, up, rup(s.cin, 8) if cin is None else cin, s.cout, gh, gw, alpha,
+                   st.ptr(name + ".weight", st.grad), s.cin, st.ptr(name + ".bias", st.grad) if s.bias else None)
+
+        Ho, Wo = self.Ho, self.Wo
+        last_up = self.ups[-1]
+        # conv_last / conv_hr
+        add_wg("conv_last", view(self.hr), view(self.d_out), Ho, Wo, 1, Ho, Wo)
+        cb.dgrad(Bk, "conv_last", view(self.d_out), Ho, Wo, view(self.g_hr), m=view(self.hr), m_c0=0, m_c1=nf)
+        add_wg("conv_hr", view(last_up), view(self.g_hr), Ho, Wo, 1, Ho, Wo)
+        cb.dgrad(Bk, "conv_hr", view(self.g_hr), Ho, Wo, view(self.g_ups[-1]), m=view(last_up), m_c0=0, m_c1=nf)
+        # upsampling convs, last to first
+        for i in reversed(range(self.n_up)):
+            nm = self.up_names[i]
+            hh, ww = H << (i + 1), W << (i + 1)          # output dims of this conv
+            src = self.ups[i - 1] if i > 0 else self.trunk
+            add_wg(nm, view(src), view(self.g_ups[i]), hh // 2, ww // 2, 2, hh, ww)
+            cb.dgrad(Bk, nm, view(self.g_ups[i]), hh, ww, view(self.g_tmp[i]))
+            if i > 0:   # 2x2 sum back to the pre-upsample grid, masked by lrelu'(ups[i-1])
+                Bk.add(hip.lib().ssr_nearest2x_bwd, view(self.g_tmp[i]), hip.NULL_VIEW, hip.NULL_VIEW,
+                       view(self.g_ups[i - 1]), view(self.ups[i - 1]), self.dt, B, hh // 2, ww // 2, nf,
+                       what="nearest2x_bwd")
+            else:       # trunk = feat + conv_body(...) is linear: no mask
+                Bk.add(hip.lib().ssr_nearest2x_bwd, view(self.g_tmp[i]), hip.NULL_VIEW, hip.NULL_VIEW,
+                       view(self.g_trunk), hip.NULL_VIEW, self.dt, B, H, W, nf, what="nearest2x_bwd")
+        add_wg("conv_body", view(self.body_out), view(self.g_trunk), H, W, 1, H, W)
+        cb.dgrad(Bk, "conv_body", view(self.g_trunk), H, W, view(self.g_body_out))
+        # body, last RDB to first
+        for r in reversed(range(n_rdb)):
+            i, j = divmod(r, 3)
+            p = f"body.{i}.rdb{j + 1}"
+            cur, dcur = self.bufs[r], self.dbufs[r]
+            d_out_r = view(self.g_body_out) if r == n_rdb - 1 else view(self.dbufs[r + 1], 0)
+            if j == 2:
+                d_rrdb = d_out_r            # gradient w.r.t. this RRDB's output
+                a5, b5 = 0.04, 0.2
+            else:
+                rr = 3 * i + 2
+                d_rrdb = view(self.g_body_out) if rr == n_rdb - 1 else view(self.dbufs[rr + 1], 0)
+                a5, b5 = 0.2, 1.0
+            add_wg(f"{p}.conv5", view(cur, 0), d_out_r, H, W, 1, H, W, alpha=a5, cin=cd)
+            cb.dgrad(Bk, f"{p}.conv5", d_out_r, H, W, view(dcur, 0), cout=cd, alpha=a5, r1=d_out_r, r1_nc=nf,
+                     beta1=b5, m=view(cur, 0), m_c0=nf + 3 * gc, m_c1=cd, cin_dy=nf)
+            for k in (4, 3, 2, 1):
+                cin_k = nf + (k - 1) * gc
+                add_wg(f"{p}.conv{k}", view(cur, 0), view(dcur, cin_k), H, W, 1, H, W, cin=cin_k)
+                kw = dict(cout=cin_k, accumulate=1, cin_dy=gc)
+                if k >= 2:
+                    kw.update(m=view(cur, 0), m_c0=nf + (k - 2) * gc, m_c1=cin_k)
+                else:
+                    if j == 0:      # d x_rrdb += d out_rrdb                     (rrdbnet_arch.py:68)
+                        kw.update(r2=d_rrdb, r2_nc=nf, beta2=1.0)
+                    if r == 0:      # d feat += d trunk                          (rrdbnet_arch.py:125)
+                        kw.update(r1=view(self.g_trunk), r1_nc=nf, beta1=1.0)
+                cb.dgrad(Bk, f"{p}.conv{k}", view(dcur, cin_k), H, W, view(dcur, 0), **kw)
+        add_wg("conv_first", view(self.xin), view(self.dbufs[0], 0), H, W, 1, H, W, cin=self.xin.shape[-1])
+        if need_input_grad:
+            cb.dgrad(Bk, "conv_first", view(self.dbufs[0], 0), H, W, view(self.g_xin), cout=self.xin.shape[-1],
+                     cin_dy=nf)
+        wg.finalize()
+        wg.launch(Bk)
+        self._wg = wg
+        self.bwd = Bk
+
+    # ---- boundary: NCHW fp32 tensors of the reference API ----
+    def load_input(self, x_nchw: torch.Tensor, scale: float = 1.0):
+        assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and x_nchw.is_cuda
+        assert tuple(x_nchw.shape) == (self.B, self.num_in_ch, self.Hin, self.Win), x_nchw.shape
+        hip.check(hip.lib().ssr_nchw_to_nhwc(x_nchw.data_ptr(), self.B, self.num_in_ch, self.Hin, self.Win,
+                                             view(self.xin), self.dt, self.unshuffle, 1, scale, hip.stream_ptr()),
+                  "ssr_nchw_to_nhwc")
+
+    def read_output(self, out_nchw: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out_nchw is None:
+            out_nchw = torch.empty(self.B, self.num_out_ch, self.Ho, self.Wo, device=self.store.device)
+        hip.check(hip.lib().ssr_nhwc_to_nchw(view(self.out), self.dt, out_nchw.data_ptr(), self.B, self.num_out_ch,
+                                             self.Ho, self.Wo, hip.stream_ptr()), "ssr_nhwc_to_nchw")
+        return out_nchw
+
+    def load_output_grad(self, g_nchw: torch.Tensor):
+        hip.check(hip.lib().ssr_nchw_to_nhwc(g_nchw.data_ptr(), self.B, self.num_out_ch, self.Ho, self.Wo,
+                                             view(self.d_out), self.dt, 1, 1, 1.0, hip.stream_ptr()),
+                  "ssr_nchw_to_nhwc")
+
+    def read_input_grad(self) -> torch.Tensor:
+        """dL/dx in NCHW of the *unshuffled* input (scale 4) — inverse unshuffle is done by the caller."""
+        g = torch.empty(self.B, self.cin_eff, self.H, self.W, device=self.store.device)
+        hip.check(hip.lib().ssr_nhwc_to_nchw(view(self.g_xin), self.dt, g.data_ptr(), self.B, self.cin_eff, self.H,
+                                             self.W, hip.stream_ptr()), "ssr_nhwc_to_nchw")
+        return g
+
+
+# =====================================================================================================
+# Discriminator
+# =====================================================================================================
+def discriminator_specs(num_in_ch, num_feat=64) -> List[ConvSpec]:
+    """discriminator_arch.py:28-40."""
+    nf = num_feat
+    return [
+        ConvSpec("conv0", nf, num_in_ch, 3, 1, True, False),
+        ConvSpec("conv1", nf * 2, nf, 4, 2, False, True),
+        ConvSpec("conv2", nf * 4, nf * 2, 4, 2, False, True),
+        ConvSpec("conv3", nf * 8, nf * 4, 4, 2, False, True),
+        ConvSpec("conv4", nf * 4, nf * 8, 3, 1, False, True),
+        ConvSpec("conv5", nf * 2, nf * 4, 3, 1, False, True),
+        ConvSpec("conv6", nf, nf * 2, 3, 1, False, True),
+        ConvSpec("conv7", nf, nf, 3, 1, False, True),
+        ConvSpec("conv8", nf, nf, 3, 1, False, True),
+        ConvSpec("conv9", 1, nf, 3, 1, True, False),
+    ]
+
+
+class DiscriminatorPlan:
+    """SSR_UNetDiscriminatorSN on NHWC buffers for a fixed (B, H, W).
+
+    `forward(x_buf)` plans are built per input buffer (fake / real share all activations, because every
+    forward is followed by its own backward before the next forward: ssr_esrgan_model.py:181-227)."""
+
+    def __init__(self, store: ParamStore, B: int, H: int, W: int, *, num_in_ch, num_feat=64, skip_connection=True,
+                 training=True):
+        assert H % 8 == 0 and W % 8 == 0, "U-Net discriminator needs H, W divisible by 8"
+        assert num_feat % 8 == 0
+        self.store, self.B, self.H, self.W, self.dt = store, B, H, W, store.dtype
+        self.nf, self.skip, self.cd = num_feat, skip_connection, num_in_ch
+        self.cdp = rup(num_in_ch, 8)
+        tdt, dev = hip.torch_dtype(self.dt), store.device
+        nf = num_feat
+        z = lambda *s: torch.zeros(*s, dtype=tdt, device=dev)
+        H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        self.x0, self.x1, self.x2, self.x3 = z(B, H, W, nf), z(B, H2, W2, 2 * nf), z(B, H4, W4, 4 * nf), z(B, H8, W8, 8 * nf)
+        self.u3, self.a4 = z(B, H4, W4, 8 * nf), z(B, H4, W4, 4 * nf)
+        self.u4, self.a5 = z(B, H2, W2, 4 * nf), z(B, H2, W2, 2 * nf)
+        self.u5, self.a6 = z(B, H, W, 2 * nf), z(B, H, W, nf)
+        self.x6 = z(B, H, W, nf) if skip_connection else self.a6
+        self.o7, self.o8 = z(B, H, W, nf), z(B, H, W, nf)
+        self.logits = z(B, H, W, 8)
+        self._cb = _ConvBuilder(store, B)
+        self._fwd_cache: Dict[int, Launcher] = {}
+        self._bwd_cache: Dict[Tuple[int, bool, int], Launcher] = {}
+        self.training = training
+        if training:
+            self.d_logits = z(B, H, W, 8)
+            self.g_o8, self.g_o7 = z(B, H, W, nf), z(B, H, W, nf)
+            self.g_a6, self.g_x6 = z(B, H, W, nf), (z(B, H, W, nf) if skip_connection else None)
+            self.g_u5 = z(B, H, W, 2 * nf)
+            self.g_a5, self.g_x5 = z(B, H2, W2, 2 * nf), (z(B, H2, W2, 2 * nf) if skip_connection else None)
+            self.g_u4 = z(B, H2, W2, 4 * nf)
+            self.g_a4, self.g_x4 = z(B, H4, W4, 4 * nf), (z(B, H4, W4, 4 * nf) if skip_connection else None)
+            self.g_u3 = z(B, H4, W4, 8 * nf)
+            self.g3, self.g2, self.g1, self.g0 = z(B, H8, W8, 8 * nf), z(B, H4, W4, 4 * nf), z(B, H2, W2, 2 * nf), z(B, H, W, nf)
+            self.g_in = z(B, H, W, self.cdp)
+
+    def forward_plan(self, x_buf: torch.Tensor) -> Launcher:
+        key = x_buf.data_ptr()
+        if key in self._fwd_cache:
+            return self._fwd_cache[key]
+        assert tuple(x_buf.shape) == (self.B, self.H, self.W, self.cdp), (x_buf.shape, self.cdp)
+        cb, nf, B, H, W, dt = self._cb, self.nf, self.B, self.H, self.W, self.dt
+        H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        L = Launcher()
+        lib = hip.lib()
+        LR = hip.ACT_LRELU
+        cb.conv(L, "conv0", view(x_buf), H, W, view(self.x0), act=LR, cin=self.cdp)
+        cb.conv(L, "conv1", view(self.x0), H, W, view(self.x1), act=LR)
+        cb.conv(L, "conv2", view(self.x1), H2, W2, view(self.x2), act=LR)
+        cb.conv(L, "conv3", view(self.x2), H4, W4, view(self.x3), act=LR)
+        L.add(lib.ssr_bilinear2x_fwd, view(self.x3), hip.NULL_VIEW, view(self.u3), dt, B, H8, W8, 8 * nf,
+              what="bilinear u3")
+        cb.conv(L, "conv4", view(self.u3), H4, W4, view(self.a4), act=LR)
+        # x4 = a4 + x2 is never materialised: the skip add is folded into the bilinear read
+        L.add(lib.ssr_bilinear2x_fwd, view(self.a4), view(self.x2) if self.skip else hip.NULL_VIEW, view(self.u4), dt,
+              B, H4, W4, 4 * nf, what="bilinear u4")
+        cb.conv(L, "conv5", view(self.u4), H2, W2, view(self.a5), act=LR)
+        L.add(lib.ssr_bilinear2x_fwd, view(self.a5), view(self.x1) if self.skip else hip.NULL_VIEW, view(self.u5), dt,
+              B, H2, W2, 2 * nf, what="bilinear u5")
+        if self.skip:   # a6 = lrelu(conv6) kept for the backward mask; x6 = a6 + x0 feeds conv7
+            cb.conv(L, "conv6", view(self.u5), H, W, view(self.x6), act=LR, y0=view(self.a6), r1=view(self.x0),
+                    r1_nc=nf, beta1=1.0)
+        else:
+            cb.conv(L, "conv6", view(self.u5), H, W, view(self.a6), act=LR)
+        cb.conv(L, "conv7", view(self.x6), H, W, view(self.o7), act=LR)
+        cb.conv(L, "conv8", view(self.o7), H, W, view(self.o8), act=LR)
+        cb.conv(L, "conv9", view(self.o8), H, W, view(self.logits))
+        self._fwd_cache[key] = L
+        return L
+
+    def backward_plan(self, x_buf: torch.Tensor, param_grads: bool, input_grad: bool,
+                      in_residual: Optional[torch.Tensor] = None) -> Launcher:
+        """Backward from self.d_logits.  param_grads=False reproduces the generator phase where D's
+        parameters are frozen (ssr_esrgan_model.py:136-137): dgrad only."""
+        key = (x_buf.data_ptr(), param_grads, 1 if input_grad else 0, 0 if in_residual is None else in_residual.data_ptr())
+        if key in self._bwd_cache:
+            return self._bwd_cache[key]
+        cb, st, nf, B, H, W, dt = self._cb, self.store, self.nf, self.B, self.H, self.W, self.dt
+        H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        lib = hip.lib()
+        L = Launcher()
+        wg3, wg4 = WgradBatch(dt, 3, 1), WgradBatch(dt, 4, 2)
+
+        def add_wg(name, x, dy, hi, wi, gh, gw, cin=None):
+            if not param_grads:
+                return
+            s = st.specs[name]
+            arena = st.grad_sn if s.sn else st.grad
+            (wg3 if s.k == 3 else wg4).add(x, dy, B, hi, wi, 1, rup(s.cin, 8) if cin is None else cin, s.cout, gh, gw,
+                                           1.0, st.ptr(st.wkey(name), arena), s.cin,
+                                           st.ptr(name + ".bias", st.grad) if s.bias else None)
+
+        NV = hip.NULL_VIEW
+        add_wg("conv9", view(self.o8), view(self.d_logits), H, W, H, W)
+        cb.dgrad(L, "conv9", view(self.d_logits), H, W, view(self.g_o8), m=view(self.o8), m_c0=0, m_c1=nf)
+        add_wg("conv8", view(self.o7), view(self.g_o8), H, W, H, W)
+        cb.dgrad(L, "conv8", view(self.g_o8), H, W, view(self.g_o7), m=view(self.o7), m_c0=0, m_c1=nf)
+        add_wg("conv7", view(self.x6), view(self.g_o7), H, W, H, W)
+        cb.dgrad(L, "conv7", view(self.g_o7), H, W, view(self.g_a6), y1=view(self.g_x6) if self.skip else NV,
+                 m=view(self.a6), m_c0=0, m_c1=nf)
+        add_wg("conv6", view(self.u5), view(self.g_a6), H, W, H, W)
+        cb.dgrad(L, "conv6", view(self.g_a6), H, W, view(self.g_u5))
+        L.add(lib.ssr_bilinear2x_bwd, view(self.g_u5), NV, view(self.g_x5) if self.skip else NV, view(self.g_a5),
+              view(self.a5), dt, B, H2, W2, 2 * nf, what="bilinear bwd 5")
+        add_wg("conv5", view(self.u4), view(self.g_a5), H2, W2, H2, W2)
+        cb.dgrad(L, "conv5", view(self.g_a5), H2, W2, view(self.g_u4))
+        L.add(lib.ssr_bilinear2x_bwd, view(self.g_u4), NV, view(self.g_x4) if self.skip else NV, view(self.g_a4),
+              view(self.a4), dt, B, H4, W4, 4 * nf, what="bilinear bwd 4")
+        add_wg("conv4", view(self.u3), view(self.g_a4), H4, W4, H4, W4)
+        cb.dgrad(L, "conv4", view(self.g_a4), H4, W4, view(self.g_u3))
+        L.add(lib.ssr_bilinear2x_bwd, view(self.g_u3), NV, NV, view(self.g3), view(self.x3), dt, B, H8, W8, 8 * nf,
+              what="bilinear bwd 3")
+        sk = lambda t: (view(t) if self.skip else NV)
+        add_wg("conv3", view(self.x2), view(self.g3), H4, W4, H8, W8)
+        cb.dgrad(L, "conv3", view(self.g3), H8, W8, view(self.g2), r1=sk(self.g_x4), r1_nc=4 * nf, beta1=1.0,
+                 m=view(self.x2), m_c0=0, m_c1=4 * nf)
+        add_wg("conv2", view(self.x1), view(self.g2), H2, W2, H4, W4)
+        cb.dgrad(L, "conv2", view(self.g2), H4, W4, view(self.g1), r1=sk(self.g_x5), r1_nc=2 * nf, beta1=1.0,
+                 m=view(self.x1), m_c0=0, m_c1=2 * nf)
+        add_wg("conv1", view(self.x0), view(self.g1), H, W, H2, W2)
+        cb.dgrad(L, "conv1", view(self.g1), H2, W2, view(self.g0), r1=sk(self.g_x6), r1_nc=nf, beta1=1.0,
+                 m=view(self.x0), m_c0=0, m_c1=nf)
+        add_wg("conv0", view(x_buf), view(self.g0), H, W, H, W, cin=self.cdp)
+        if input_grad:
+            kw = {}
+            if in_residual is not None:
+                kw.update(r1=view(in_residual), r1_nc=self.cdp, beta1=1.0)
+            cb.dgrad(L, "conv0", view(self.g0), H, W, view(self.g_in), cout=self.cdp, cin_dy=nf, **kw)
+        wg3.finalize(); wg4.finalize()
+        wg3.launch(L); wg4.launch(L)
+        self._keep = getattr(self, "_keep", []) + [wg3, wg4]
+        self._bwd_cache[key] = L
+        return L

@@ -1,0 +1,182 @@
+"""ctypes binding of libssr_hip.so (the C ABI declared in include/ssr_hip.h).
+
+PyTorch supplies device memory and streams only: every call passes raw ``data_ptr()`` addresses and
+the current HIP stream handle.  There is NO CPU / eager fallback: if the library is missing or a
+launch fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssr_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU = 0, 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("cs", C.c_int32), ("coff", C.c_int32)]
+
+
+NULL_VIEW = View(None, 0, 0)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("x", View), ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("up", C.c_int32), ("Cin", C.c_int32),
+        ("w", C.c_void_p), ("CoutPad", C.c_int32), ("bias", C.c_void_p),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
+        ("Gh", C.c_int32), ("Gw", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("oys", C.c_int32), ("oyo", C.c_int32), ("oxs", C.c_int32),
+        ("oxo", C.c_int32), ("Cout", C.c_int32),
+        ("y", View), ("y0", View), ("y1", View),
+        ("alpha", C.c_float), ("act", C.c_int32),
+        ("r1", View), ("r1_nc", C.c_int32), ("beta1", C.c_float),
+        ("r2", View), ("r2_nc", C.c_int32), ("beta2", C.c_float),
+        ("accumulate", C.c_int32),
+        ("m", View), ("m_c0", C.c_int32), ("m_c1", C.c_int32),
+    ]
+
+
+class WgradLayer(C.Structure):
+    _fields_ = [
+        ("x", View), ("dy", View),
+        ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("up", C.c_int32), ("Cin", C.c_int32),
+        ("Cout", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32), ("Gh", C.c_int32), ("Gw", C.c_int32),
+        ("alpha", C.c_float), ("dw", C.c_void_p), ("Cin_w", C.c_int32), ("db", C.c_void_p),
+    ]
+
+
+class WgradItem(C.Structure):
+    _fields_ = [("layer", C.c_int32), ("co0", C.c_int32), ("ci0", C.c_int32), ("tile_begin", C.c_int32),
+                ("tile_end", C.c_int32), ("atomic", C.c_int32)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("inv_scale", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
+        ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+        ("CoutPad", C.c_int32), ("CinPad", C.c_int32), ("CinPadO", C.c_int32), ("CoutPadI", C.c_int32),
+    ]
+
+
+class SNItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p), ("tmp", C.c_void_p),
+                ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class SNBwdItem(C.Structure):
+    _fields_ = [("dw_sn", C.c_void_p), ("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
+                ("dw", C.c_void_p), ("tmp", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("ema", C.c_void_p), ("n", C.c_int64), ("lr", C.c_void_p), ("step", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("ema_decay", C.c_float),
+                ("grad_scale", C.c_float)]
+
+
+# every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ssr_conv2d", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
+    "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
+    "ssr_device_info", "ssr_abi_version",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libssr_hip.so (built by __graft_entry__.build()).  Raises if it is missing: the product
+    path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    l.ssr_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
+    l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    l.ssr_wgrad_tiles.argtypes = [i32, i32, i32]
+    l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]
+    l.ssr_nchw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, View, i32, i32, i32, f32, vp]
+    l.ssr_nhwc_to_nchw.argtypes = [View, i32, vp, i32, i32, i32, i32, vp]
+    l.ssr_fill.argtypes = [vp, i64, i32, f32, vp]
+    l.ssr_bilinear2x_fwd.argtypes = [View, View, View, i32, i32, i32, i32, i32, vp]
+    l.ssr_bilinear2x_bwd.argtypes = [View, View, View, View, View, i32, i32, i32, i32, i32, vp]
+    l.ssr_nearest2x_bwd.argtypes = [View, View, View, View, View, i32, i32, i32, i32, i32, vp]
+    l.ssr_spectral_norm.argtypes = [vp, i32, i32, i32, i32, vp]
+    l.ssr_spectral_norm_bwd.argtypes = [vp, i32, i32, vp]
+    l.ssr_l1_loss.argtypes = [View, View, View, i32, i64, i32, f32, vp, vp]
+    l.ssr_bce_logits_loss.argtypes = [View, View, i32, i64, f32, f32, vp, vp, vp]
+    l.ssr_adam_step.argtypes = [C.POINTER(AdamArgs), vp]
+    l.ssr_axpby_f32.argtypes = [f32, vp, f32, vp, i64, vp]
+    l.ssr_device_info.argtypes = [C.c_char_p, i32]
+    l.ssr_abi_version.argtypes = []
+    for s in ABI_SYMBOLS:
+        getattr(l, s).restype = i32
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed with code {rc}"
+                              + (" (bad descriptor)" if rc == -1 else " (unsupported)" if rc == -2 else " (hipError)"))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def torch_dtype(dt: int):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def dtype_code(dt) -> int:
+    if dt in (F32, "fp32", "float32", torch.float32):
+        return F32
+    if dt in (BF16, "bf16", "bfloat16", torch.bfloat16):
+        return BF16
+    raise ValueError(f"unsupported compute dtype {dt!r}")
+
+
+def view(t: Optional[torch.Tensor], coff: int = 0) -> View:
+    """NHWC tensor [..., C] -> channel-sliced view starting at channel `coff`."""
+    if t is None:
+        return View(None, 0, 0)
+    assert t.is_contiguous()
+    return View(t.data_ptr(), t.shape[-1], coff)
+
+
+def device_table(items) -> torch.Tensor:
+    """Copy a list of ctypes structs to a device byte tensor (descriptor tables)."""
+    arr_t = type(items[0]) * len(items)
+    arr = arr_t(*items)
+    raw = bytes(memoryview(arr).cast("B"))
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    return host.cuda()
+
+
+def device_info() -> str:
+    buf = C.create_string_buffer(256)
+    lib().ssr_device_info(buf, 256)
+    return buf.value.decode()

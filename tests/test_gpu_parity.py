@@ -1,0 +1,246 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).
+
+Every test drives the HIP path through the C ABI (libssr_hip.so via satlas_super_resolution_amd.hip)
+and compares with (a) the golden vectors produced by the unmodified reference classes
+(tests/golden/*.pt) and (b) the CPU oracle (oracle/esrgan_oracle.py) at larger sizes.
+
+Tolerance (north_star / SURVEY.md D5): |a - ref| <= 1e-3*max|ref| + 1e-3*|ref| in fp32 mode.
+"""
+from collections import OrderedDict
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, parity_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from satlas_super_resolution_amd import engine, hip
+    return engine, hip
+
+
+def _nchw_to_buf(hip, x, buf, dt):
+    x = x.contiguous().float().cuda()
+    N, C, H, W = x.shape
+    hip.check(hip.lib().ssr_nchw_to_nhwc(x.data_ptr(), N, C, H, W, hip.view(buf), dt, 1, 1, 1.0, hip.stream_ptr()),
+              "nchw_to_nhwc")
+
+
+def _buf_to_nchw(hip, buf, C, dt):
+    N, H, W, _ = buf.shape
+    out = torch.empty(N, C, H, W, device="cuda")
+    hip.check(hip.lib().ssr_nhwc_to_nchw(hip.view(buf), dt, out.data_ptr(), N, C, H, W, hip.stream_ptr()),
+              "nhwc_to_nchw")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# single conv layers vs torch (CPU fp32) — every geometry the path uses
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,B", [
+    (64, 32, 3, 1, 32, 32, 2), (192, 64, 3, 1, 32, 32, 1), (3, 64, 3, 1, 20, 12, 2), (64, 3, 3, 1, 16, 48, 1),
+    (64, 1, 3, 1, 8, 8, 1), (24, 64, 3, 1, 9, 7, 1), (64, 128, 4, 2, 32, 32, 2), (16, 24, 4, 2, 8, 40, 1),
+    (512, 256, 3, 1, 16, 16, 1), (40, 8, 3, 1, 5, 33, 3),
+])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_conv_layer_fwd_dgrad_wgrad(cin, cout, k, stride, H, W, B, mode):
+    engine, hip = _mods()
+    dt = hip.dtype_code(mode)
+    tdt = hip.torch_dtype(dt)
+    torch.manual_seed(cin * 131 + cout)
+    spec = engine.ConvSpec("c", cout, cin, k, stride, True, False)
+    st = engine.ParamStore([spec], dt)
+    w = torch.randn(cout, cin, k, k) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout) * 0.1
+    st.load_state_dict({"c.weight": w, "c.bias": b})
+    st.pack()
+    x = torch.randn(B, cin, H, W)
+    cinp, coutp = engine.rup(cin, 8), engine.rup(cout, 8)
+    Ho, Wo = H // stride, W // stride
+    xb = torch.zeros(B, H, W, cinp, dtype=tdt, device="cuda")
+    yb = torch.zeros(B, Ho, Wo, coutp, dtype=tdt, device="cuda")
+    _nchw_to_buf(hip, x, xb, dt)
+    cb = engine._ConvBuilder(st, B)
+    L = engine.Launcher()
+    cb.conv(L, "c", hip.view(xb), H, W, hip.view(yb), cin=cinp)
+    L.run()
+    y = _buf_to_nchw(hip, yb, cout, dt).cpu()
+    if mode == "bf16":   # reference on bf16-rounded operands, fp32 accumulate
+        xr, wr = x.bfloat16().float(), w.bfloat16().float()
+        tol = 1.5e-2
+    else:
+        xr, wr, tol = x, w, 1e-3
+    xr = xr.clone().requires_grad_(True)
+    wr = wr.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=1)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < tol, ("fwd", rel_err(y, yr))
+    # dgrad + wgrad
+    r = torch.randn_like(yr)
+    rr = r.bfloat16().float() if mode == "bf16" else r
+    (yr * rr).sum().backward()
+    dyb = torch.zeros(B, Ho, Wo, coutp, dtype=tdt, device="cuda")
+    dxb = torch.zeros(B, H, W, cinp, dtype=tdt, device="cuda")
+    _nchw_to_buf(hip, r, dyb, dt)
+    L2 = engine.Launcher()
+    cb.dgrad(L2, "c", hip.view(dyb), Ho, Wo, hip.view(dxb), cout=cinp, cin_dy=coutp)
+    wg = engine.WgradBatch(dt, k, stride)
+    wg.add(hip.view(xb), hip.view(dyb), B, H, W, 1, cinp, cout, Ho, Wo, 1.0, st.ptr("c.weight", st.grad), cin,
+           st.ptr("c.bias", st.grad))
+    wg.finalize()
+    wg.launch(L2)
+    st.grad.zero_()
+    L2.run()
+    dx = _buf_to_nchw(hip, dxb, cin, dt).cpu()
+    assert rel_err(dx, xr.grad) < tol, ("dgrad", rel_err(dx, xr.grad))
+    dw = st.tensor("c.weight", st.grad).cpu()
+    db = st.tensor("c.bias", st.grad).cpu()
+    assert rel_err(dw, wr.grad) < tol, ("wgrad", rel_err(dw, wr.grad))
+    assert rel_err(db, br.grad) < tol, ("bgrad", rel_err(db, br.grad))
+
+
+def test_bilinear_and_nearest_against_torch():
+    engine, hip = _mods()
+    dt = hip.F32
+    torch.manual_seed(5)
+    for (B, H, W, Cc) in [(2, 5, 7, 8), (1, 16, 16, 24)]:
+        a = torch.randn(B, Cc, H, W, requires_grad=True)
+        b2 = torch.randn(B, Cc, H, W)
+        ab, bb = torch.zeros(B, H, W, Cc, device="cuda"), torch.zeros(B, H, W, Cc, device="cuda")
+        yb = torch.zeros(B, 2 * H, 2 * W, Cc, device="cuda")
+        _nchw_to_buf(hip, a.detach(), ab, dt)
+        _nchw_to_buf(hip, b2, bb, dt)
+        hip.check(hip.lib().ssr_bilinear2x_fwd(hip.view(ab), hip.view(bb), hip.view(yb), dt, B, H, W, Cc,
+                                               hip.stream_ptr()), "bil")
+        yr = F.interpolate(a + b2, scale_factor=2, mode="bilinear", align_corners=False)
+        assert rel_err(_buf_to_nchw(hip, yb, Cc, dt), yr) < 1e-5
+        r = torch.randn_like(yr)
+        (yr * r).sum().backward()
+        rb = torch.zeros(B, 2 * H, 2 * W, Cc, device="cuda")
+        gb = torch.zeros(B, H, W, Cc, device="cuda")
+        _nchw_to_buf(hip, r, rb, dt)
+        hip.check(hip.lib().ssr_bilinear2x_bwd(hip.view(rb), hip.NULL_VIEW, hip.NULL_VIEW, hip.view(gb),
+                                               hip.NULL_VIEW, dt, B, H, W, Cc, hip.stream_ptr()), "bilb")
+        assert rel_err(_buf_to_nchw(hip, gb, Cc, dt), a.grad) < 1e-5
+        # nearest x2 backward = 2x2 sum
+        a2 = torch.randn(B, Cc, H, W, requires_grad=True)
+        yn = F.interpolate(a2, scale_factor=2, mode="nearest")
+        (yn * r).sum().backward()
+        hip.check(hip.lib().ssr_nearest2x_bwd(hip.view(rb), hip.NULL_VIEW, hip.NULL_VIEW, hip.view(gb),
+                                              hip.NULL_VIEW, dt, B, H, W, Cc, hip.stream_ptr()), "nb")
+        assert rel_err(_buf_to_nchw(hip, gb, Cc, dt), a2.grad) < 1e-6
+
+
+def test_index_maps_bit_exact():
+    """pixel_unshuffle and nearest-upsample index arithmetic must be bit exact (north_star)."""
+    engine, hip = _mods()
+    fx = load_golden("index_maps")
+    dt = hip.F32
+    for key, ref in fx.items():
+        if key.startswith("unshuffle"):
+            c, hh, hw, s = map(int, key.split("_")[1:])
+            x = torch.arange(c * hh * hw, dtype=torch.float32).view(1, c, hh, hw).cuda()
+            c2 = c * s * s
+            buf = torch.zeros(1, hh // s, hw // s, engine.rup(c2, 8), device="cuda")
+            hip.check(hip.lib().ssr_nchw_to_nhwc(x.data_ptr(), 1, c, hh, hw, hip.view(buf), dt, s, 1, 1.0,
+                                                 hip.stream_ptr()), "unshuffle")
+            got = buf[..., :c2].permute(0, 3, 1, 2).to(torch.int64).cpu()
+            assert torch.equal(got, ref), key
+        elif key.startswith("nearest"):
+            f = int(key[len("nearest")])
+            x = torch.arange(2 * 3 * 5, dtype=torch.float32).view(1, 2, 3, 5).cuda()
+            buf = torch.zeros(1, 3 * f, 5 * f, 8, device="cuda")
+            hip.check(hip.lib().ssr_nchw_to_nhwc(x.data_ptr(), 1, 2, 3, 5, hip.view(buf), dt, 1, f, 1.0,
+                                                 hip.stream_ptr()), "nearest")
+            got = buf[..., :2].permute(0, 3, 1, 2).to(torch.int64).cpu()
+            assert torch.equal(got, ref), key
+
+
+# ---------------------------------------------------------------------------------------------
+# whole networks vs golden vectors from the reference classes
+# ---------------------------------------------------------------------------------------------
+def _run_generator(fx, mode="fp32", training=True):
+    engine, hip = _mods()
+    dt = hip.dtype_code(mode)
+    kw = fx["kwargs"]
+    st = engine.ParamStore(engine.generator_specs(**kw), dt)
+    st.load_state_dict(fx["state_dict"])
+    B, _, H, W = fx["x"].shape
+    plan = engine.GeneratorPlan(st, B, H, W, training=training, need_input_grad=training, **kw)
+    st.pack()
+    plan.load_input(fx["x"].cuda().contiguous())
+    plan.fwd.run()
+    return engine, hip, st, plan, plan.read_output()
+
+
+@pytest.mark.parametrize("name", ["g_tiny_ragged", "g_mid_24ch", "g_scale2", "g_scale1"])
+def test_generator_golden_forward_backward(name):
+    fx = load_golden(name)
+    engine, hip, st, plan, y = _run_generator(fx)
+    assert parity_close(y, fx["y"]), rel_err(y, fx["y"])
+    plan.load_output_grad(fx["r"].cuda().contiguous())
+    st.grad.zero_()
+    plan.bwd.run()
+    worst = 0.0
+    for k, g in fx["grads"].items():
+        got = st.tensor(k, st.grad)
+        assert parity_close(got, g), (k, rel_err(got, g))
+        worst = max(worst, rel_err(got, g))
+    if fx["kwargs"]["scale"] == 4:
+        dx = plan.read_input_grad()
+        assert parity_close(dx, fx["dx"]), rel_err(dx, fx["dx"])
+
+
+def test_generator_golden_inference_plan_matches():
+    """training=False uses 4 rotating dense-block buffers; result must equal the training plan."""
+    fx = load_golden("g_tiny_ragged")
+    _, _, _, _, y = _run_generator(fx, training=False)
+    assert parity_close(y, fx["y"]), rel_err(y, fx["y"])
+
+
+def test_generator_bf16_mode_close():
+    fx = load_golden("g_mid_24ch")
+    _, _, _, _, y = _run_generator(fx, mode="bf16", training=False)
+    assert rel_err(y, fx["y"]) < 3e-2, rel_err(y, fx["y"])
+
+
+@pytest.mark.parametrize("name", ["d_tiny", "d_in6_noskip"])
+def test_discriminator_golden_forward_backward(name):
+    engine, hip = _mods()
+    fx = load_golden(name)
+    dt = hip.F32
+    kw = fx["kwargs"]
+    st = engine.ParamStore(engine.discriminator_specs(kw["num_in_ch"], kw["num_feat"]), dt)
+    st.load_state_dict(fx["state_dict_before"])
+    B, C, H, W = fx["x"].shape
+    plan = engine.DiscriminatorPlan(st, B, H, W, **kw)
+    xb = torch.zeros(B, H, W, plan.cdp, device="cuda")
+    _nchw_to_buf(hip, fx["x"], xb, dt)
+    st.spectral_norm(power_iter=True)
+    st.pack()
+    plan.forward_plan(xb).run()
+    y = _buf_to_nchw(hip, plan.logits, 1, dt)
+    assert parity_close(y, fx["y"]), rel_err(y, fx["y"])
+    for n in st.sn_names:
+        assert rel_err(st.u[n], fx["state_dict_after"][n + ".weight_u"]) < 1e-4, n
+        assert rel_err(st.v[n], fx["state_dict_after"][n + ".weight_v"]) < 1e-4, n
+    _nchw_to_buf(hip, fx["r"], plan.d_logits, dt)
+    st.grad.zero_()
+    st.grad_sn.zero_()
+    plan.backward_plan(xb, param_grads=True, input_grad=True).run()
+    st.spectral_norm_backward()
+    for k, g in fx["grads"].items():
+        got = st.tensor(k, st.grad)
+        assert parity_close(got, g), (k, rel_err(got, g))
+    dx = _buf_to_nchw(hip, plan.g_in, C, dt)
+    assert parity_close(dx, fx["dx"]), rel_err(dx, fx["dx"])
+    # eval mode: sigma from stored u, v without power iteration
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    plan.forward_plan(xb).run()
+    y_eval = _buf_to_nchw(hip, plan.logits, 1, dt)
+    assert parity_close(y_eval, fx["y_eval"]), rel_err(y_eval, fx["y_eval"])

@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py — G+D ESRGAN train-step throughput on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json): N=1 -> configs[1] "1xS2 RGB ESRGAN (RRDBNet G + UNetDiscriminatorSN D) train
+step, batch=16 bf16 on 1 MI355X"; N>1 keeps the same per-GPU batch (weak scaling, pure data parallel:
+independent samples per rank, gradient all-reduce over RCCL; satlas_super_resolution_amd/dp.py).
+A "step" = one full optimize_parameters(): G fwd+bwd+Adam+EMA, 3 D forwards (+3 spectral-norm power
+iterations), D dgrad-only bwd + 2 full D bwd, Adam — nothing skipped.  Inputs are synthetic random
+S2/NAIP tensors already resident in HBM; weights are random-init of the named architecture.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel symbol (by GPU time inside one
+instrumented step): algorithmic conv FLOPs of its launches / their summed duration, measured with
+events on the launch stream; `cpu_baseline` is the oracle (CPU restatement of the reference step,
+oracle/esrgan_oracle.py) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
+    ap.add_argument("--frames", type=int, default=1, help="Sentinel-2 frames (x3 RGB channels); configs[1]: 1")
+    ap.add_argument("--feed-disc-lr", action="store_true")
+    ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def conv_flops(d) -> float:
+    """Algorithmic FLOPs of one ssr_conv2d launch: 2 * grid * Cout * taps * Cin_valid."""
+    return 2.0 * d.N * d.Gh * d.Gw * d.Cout * d.KH * d.KW * d.Cin
+
+
+def instrumented_step(ts, args):
+    """Run one step's launch list eagerly with an event pair around every C-ABI call on the launch
+    stream; returns per-symbol totals."""
+    import ctypes as C
+    from satlas_super_resolution_amd import hip
+    lib = hip.lib()
+    records = []  # (symbol, flops, ev0, ev1)
+
+    def wrap(L):
+        for fn, a, what in L.calls:
+            name = getattr(fn, "__name__", str(fn))
+            sym, fl = name, 0.0
+            if name == "ssr_conv2d":
+                d = a[0]._obj
+                v = lib.ssr_conv2d_variant(C.byref(d))
+                sym = f"conv_kernel<{args.dtype},K{v // 1000},S{(v // 100) % 10},NT{(v // 10) % 10},W{v % 10}>"
+                fl = conv_flops(d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a, hip.stream_ptr())
+            e1.record()
+            assert rc == 0, (name, rc)
+            records.append((sym, fl, e0, e1))
+
+    class Rec:
+        def __init__(self, L):
+            self.L = L
+
+        def run(self):
+            wrap(self.L)
+
+    # temporarily route Launcher.run through the recorder
+    from satlas_super_resolution_amd import engine
+    orig = engine.Launcher.run
+    engine.Launcher.run = lambda self: wrap(self)
+    use_graph, ts.use_graph = ts.use_graph, False
+    try:
+        ts.step()
+    finally:
+        engine.Launcher.run = orig
+        ts.use_graph = use_graph
+    torch.cuda.synchronize()
+    agg = {}
+    for sym, fl, e0, e1 in records:
+        a = agg.setdefault(sym, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += fl
+    return agg
+
+
+def wgrad_flops(ts):
+    tot = 0.0
+    for batch in [ts.g_plan._wg]:
+        for L in batch.layers:
+            tot += 2.0 * L.N * L.Gh * L.Gw * L.Cout * 9 * L.Cin_w
+    return tot
+
+
+def cpu_baseline(args, c_in, c_d):
+    from oracle import esrgan_oracle as O
+    torch.manual_seed(0)
+    B = args.cpu_batch
+    g0 = O.generator_init(num_in_ch=c_in, num_block=args.blocks, seed=0)
+    d0 = O.discriminator_init(c_d, 64, seed=1)
+    orc = O.ESRGANOracle(g0, d0, O.StepConfig(feed_disc_lr=args.feed_disc_lr))
+    lr, gt = torch.rand(B, c_in, 32, 32), torch.rand(B, 3, 128, 128)
+    orc.step(lr, gt, 1)  # warm-up
+    ts = []
+    for it in range(args.cpu_steps):
+        t0 = time.perf_counter()
+        orc.step(lr, gt, it + 2)
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.cpu_steps} timed G+D steps (median) at batch {B}, fp32, same architecture/shapes, "
+                      f"after 1 warm-up; host CPU: {cpu}; oracle/esrgan_oracle.py (PyTorch CPU restatement)"}
+
+
+def main():
+    args = parse()
+    from satlas_super_resolution_amd import dp as dpmod, hip
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    from oracle import esrgan_oracle as O   # flop model + cpu baseline only (never on the measured path)
+
+    ctx = dpmod.init_distributed()
+    assert ctx.world == args.gpus or ctx.world == 1 and args.gpus == 1, \
+        f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.manual_seed(0 + ctx.rank)                      # per-rank seed = manual_seed + rank (options.py:81)
+    c_in = 3 * args.frames
+    c_d = 3 + (c_in if args.feed_disc_lr else 0)
+    B = args.batch
+    g_kw = dict(num_in_ch=c_in, num_out_ch=3, scale=4, num_feat=64, num_block=args.blocks, num_grow_ch=32)
+    d_kw = dict(num_in_ch=c_d, num_feat=64, skip_connection=True)
+    ts = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, args.dtype, StepConfig(feed_disc_lr=args.feed_disc_lr), dp=ctx,
+                         use_graph=not args.no_graph)
+    # random-init weights of the named architecture (reference init distributions), identical on all ranks
+    ts.load_state(O.generator_init(seed=0, **g_kw), O.discriminator_init(c_d, 64, seed=1))
+    ts.sync_params_from_rank0()
+    lr = torch.rand(B, c_in, 32, 32, device="cuda")
+    gt = torch.rand(B, 3, 128, 128, device="cuda")
+    ts.feed_data(lr, gt)
+
+    for _ in range(max(args.warmup, 2)):   # >= 2: first touch + graph capture happen outside the timed region
+        ts.step()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if ctx.active:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log = ts.log()
+    finite = all(v == v and abs(v) < 1e30 for v in log.values())
+
+    value = ctx.world * B * args.steps / dt
+    gflop_img = O.step_gflop_per_image(c_in, c_d)
+    out = {
+        "metric": "G+D train-step images/sec", "value": value, "unit": "images/s", "n_gpus": ctx.world,
+        "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.frames}xS2 RGB ({c_in}-ch) 32x32->128x128 ESRGAN train step: "
+                               f"SSR_RRDBNet(nf=64,nb={args.blocks},gc=32) + SSR_UNetDiscriminatorSN(in={c_d},nf=64), "
+                               f"L1(1.0)+vanilla-GAN(0.1), Adam x2, EMA; BASELINE.json configs[1] shape",
+                   "per_gpu_batch": B, "global_batch": B * ctx.world, "parallelism": f"dp{ctx.world}",
+                   "hip_graph": not args.no_graph, "feed_disc_lr": args.feed_disc_lr},
+        "step_gflop_per_image": gflop_img,
+        "step_tflops": value * gflop_img / 1e3,
+        "frac_of_mfma_peak_whole_step": value * gflop_img / 1e3 / (PEAK_TFLOPS[args.dtype] * ctx.world),
+        "losses_finite": finite,
+    }
+    if ctx.rank == 0 and not args.no_roofline:
+        agg = instrumented_step(ts, args)
+        conv = {k: v for k, v in agg.items() if k.startswith("conv_kernel")}
+        dom = max(conv, key=lambda k: conv[k][1])
+        n, secs, fl = conv[dom]
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n,
+                           "avg_launch_us": 1e6 * secs / n, "flops_per_launch": fl / n,
+                           "achieved": fl / secs / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                           "frac": fl / secs / 1e12 / PEAK_TFLOPS[args.dtype], "traffic": traffic}
+        out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in
+                                           sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, c_in, c_d)
+    if ctx.rank == 0:
+        print(json.dumps(out))
+    if ctx.active:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,10 @@ typedef struct ssr_conv_desc {
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
+/* Which kernel instantiation ssr_conv2d dispatches this descriptor to, encoded as
+ * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
+ * used by bench.py to attribute launch durations to kernel symbols.  Negative on error. */
+int ssr_conv2d_variant(const ssr_conv_desc* d);
 
 /*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at

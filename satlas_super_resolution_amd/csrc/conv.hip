@@ -150,13 +150,18 @@ int launch_conv(const ssr_conv_desc& d, hipStream_t st) {
     return SSR_OK;
 }
 
+// BN = 64 when the padded output width allows it; small problems use 2-wave (4x16) tiles so that
+// more workgroups exist than CUs.
+inline void pick_tile(const ssr_conv_desc& d, bool& nt2, bool& small) {
+    nt2 = (d.CoutPad % 64) == 0;
+    const long tiles4 = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32));
+    small = tiles4 < 384;
+}
+
 template <typename T, int KH, int KW, int S>
 int dispatch_tile(const ssr_conv_desc& d, hipStream_t st) {
-    // BN = 64 when the padded output width allows it; small problems use 2-wave (4x16) tiles so that
-    // more workgroups exist than CUs.
-    const bool nt2 = (d.CoutPad % 64) == 0;
-    const long tiles4 = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32));
-    const bool small = tiles4 < 384;
+    bool nt2, small;
+    pick_tile(d, nt2, small);
     if (nt2) return small ? launch_conv<T, KH, KW, S, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 2, 4>(d, st);
     return small ? launch_conv<T, KH, KW, S, 1, 2>(d, st) : launch_conv<T, KH, KW, S, 1, 4>(d, st);
 }
@@ -175,6 +180,13 @@ bool view_ok(const ssr_view& v, bool required) {
 }
 
 }  // namespace
+
+extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
+    if (!dp) return SSR_EINVAL;
+    bool nt2, small;
+    pick_tile(*dp, nt2, small);
+    return dp->KH * 1000 + dp->stride * 100 + (nt2 ? 2 : 1) * 10 + (small ? 2 : 4);
+}
 
 extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) {
     if (!dp) return SSR_EINVAL;

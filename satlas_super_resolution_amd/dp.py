@@ -1,0 +1,104 @@
+"""Data-parallel gradient exchange over flat fp32 arenas (RCCL over xGMI on MI355X; gloo on CPU for tests).
+
+The reference gets data parallelism from torch DDP inside BasicSR: bucketed
+NCCL all-reduce of G grads during G backward, TWO all-reduces of D grads (one per backward()), a
+broadcast of the spectral-norm u/v buffers before each D forward and a reduce of 7 loss scalars.
+MI355X-first re-design:
+  * gradients live in ONE flat arena per network, so the exchange is a handful of large all-reduces
+    (chunked so RCCL can pipeline them over the 7 xGMI links) issued on a SIDE stream;
+  * the generator exchange is launched as soon as G's backward retires and overlaps the whole
+    discriminator phase (D real+fake forward/backward do not depend on the updated G weights);
+    both Adam updates run after the exchanges complete;
+  * D grads are reduced ONCE after both backward passes (avg_real+avg_fake == avg(real+fake));
+  * u/v stay bit-identical across ranks without any broadcast: every rank applies the same
+    deterministic power iteration to the same (all-reduced) weights;
+  * averaging (1/world) is folded into the fused Adam kernel's grad_scale.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> "DPContext":
+    """One process per GPU, env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), mirroring
+    basicsr.utils.dist_util.init_dist('pytorch') as called from /root/reference/ssr/utils/options.py:65-74."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return DPContext(None, 0, 1)
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return DPContext(dist.group.WORLD, rank, world)
+
+
+class DPContext:
+    def __init__(self, group, rank: int, world: int, chunk_bytes: int = 32 << 20):
+        self.group, self.rank, self.world = group, rank, world
+        self.chunk_elems = max(1, chunk_bytes // 4)
+        self._comm_stream = None
+        self._pending: List = []
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1
+
+    @property
+    def grad_scale(self) -> float:
+        """DDP averages gradients: fold 1/world into the optimizer kernel."""
+        return 1.0 / self.world
+
+    def _stream(self):
+        if self._comm_stream is None and torch.cuda.is_available():
+            self._comm_stream = torch.cuda.Stream()
+        return self._comm_stream
+
+    def all_reduce_async(self, flat: torch.Tensor):
+        """Sum-all-reduce a flat arena in chunks.  On GPU the collectives are enqueued on a side stream
+        that first waits for the producer (current) stream; call wait() before consuming."""
+        if not self.active:
+            return
+        if flat.is_cuda:
+            cs = self._stream()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                for off in range(0, flat.numel(), self.chunk_elems):
+                    dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for off in range(0, flat.numel(), self.chunk_elems):
+                self._pending.append(dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM,
+                                                     group=self.group, async_op=True))
+
+    def wait(self):
+        if not self.active:
+            return
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def reduce_scalars(self, t: torch.Tensor) -> torch.Tensor:
+        """reduce_loss_dict (BasicSR): mean over ranks of the logged scalars (rank 0 reads them)."""
+        if not self.active:
+            return t
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t / self.world
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0):
+        """DDP constructor semantics: parameters/buffers start identical to rank 0's."""
+        if self.active:
+            dist.broadcast(t, src=src, group=self.group)
+
+    def barrier(self):
+        if self.active:
+            dist.barrier(group=self.group)

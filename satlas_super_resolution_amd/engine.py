@@ -350,7 +350,7 @@ class GeneratorPlan:
 
     def __init__(self, store: ParamStore, B: int, H: int, W: int, *, num_in_ch, num_out_ch=3, scale=4, num_feat=64,
                  num_block=23, num_grow_ch=32, training=True, out_buf: Optional[torch.Tensor] = None,
-                 need_input_grad=False):
+                 d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False):
         self.store, self.B, self.dt = store, B, store.dtype
         self.scale, self.nf, self.nb, self.gc = scale, num_feat, num_block, num_grow_ch
         self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
@@ -415,7 +415,9 @@ class GeneratorPlan:
             return
         assert n_bufs == n_rdb
         # ------------------------------------------------------------------ backward
-        self.d_out = z(B, self.Ho, self.Wo, self.out.shape[-1])     # dL/d out (valid: num_out_ch channels)
+        # dL/d out (valid: num_out_ch channels); may alias the discriminator's input-gradient buffer
+        self.d_out = d_out_buf if d_out_buf is not None else z(B, self.Ho, self.Wo, self.out.shape[-1])
+        assert self.d_out.shape == self.out.shape
         self.g_hr = z(B, self.Ho, self.Wo, nf)
         self.g_ups = [z(B, H << (i + 1), W << (i + 1), nf) for i in range(self.n_up)]
         self.g_tmp = [z(B, H << (i + 1), W << (i + 1), nf) for i in range(self.n_up)]

@@ -1,0 +1,252 @@
+"""The fused G+D ESRGAN train step on one MI355X (one process per GPU; see dp.py for the exchange).
+
+Follows /root/reference/ssr/models/ssr_esrgan_model.py:119-233 (optimize_parameters) operation by
+operation — generator phase with D frozen (:136-193), discriminator real/fake phases (:196-228), EMA
+(:230-231) — with the L1 + vanilla-GAN losses of the measured configuration.
+Everything runs through libssr_hip.so; the whole step is static and is replayed from hipGraphs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import engine, hip
+from .dp import DPContext
+from .hip import AdamArgs, view
+
+
+@dataclass
+class StepConfig:
+    l1_weight: float = 1.0         # pixel_opt.loss_weight           (esrgan_s2naip_urban.yml:118-121)
+    gan_weight: float = 0.1        # gan_opt.loss_weight             (:139-144)
+    lr_g: float = 1e-4             # optim_g                         (:98-102)
+    lr_d: float = 1e-4             # optim_d                         (:103-107)
+    betas: Tuple[float, float] = (0.9, 0.99)
+    eps: float = 1e-8
+    ema_decay: float = 0.999       # train.ema_decay                 (:97)
+    net_d_iters: int = 1           # (:146)
+    net_d_init_iters: int = 0      # (:147)
+    feed_disc_lr: bool = False     # top-level feed_disc_lr          (:14)
+    real_label: float = 1.0
+    fake_label: float = 0.0
+
+
+LOSS_KEYS = ("l_g_pix", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake")
+
+
+class AdamState:
+    """torch.optim.Adam state over a ParamStore's flat arena (+ optional EMA arena)."""
+
+    def __init__(self, store: engine.ParamStore, lr: float, betas, eps: float, ema_decay: float = 0.0):
+        dev = store.device
+        self.store = store
+        self.exp_avg = torch.zeros_like(store.data)
+        self.exp_avg_sq = torch.zeros_like(store.data)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr = torch.full((1,), lr, dtype=torch.float32, device=dev)
+        self.ema = store.data.clone() if ema_decay > 0 else None      # model_ema(0): copy of net_g
+        self.args = AdamArgs(store.data.data_ptr(), store.grad.data_ptr(), self.exp_avg.data_ptr(),
+                             self.exp_avg_sq.data_ptr(), self.ema.data_ptr() if self.ema is not None else None,
+                             store.numel, self.lr.data_ptr(), self.step.data_ptr(), betas[0], betas[1], eps,
+                             ema_decay, 1.0)
+
+    def set_lr(self, lr: float):
+        self.lr.fill_(lr)
+
+    def update(self, grad_scale: float = 1.0):
+        self.args.grad_scale = grad_scale
+        hip.check(hip.lib().ssr_adam_step(C.byref(self.args), hip.stream_ptr()), "ssr_adam_step")
+
+
+class ESRGANTrainStep:
+    """State + launch plans of one rank's G+D train step for fixed (B, h, w)."""
+
+    def __init__(self, g_kwargs: Dict, d_kwargs: Dict, B: int, h: int, w: int, dtype="fp32",
+                 cfg: StepConfig = StepConfig(), dp: Optional[DPContext] = None, use_graph: bool = True,
+                 g_store: Optional[engine.ParamStore] = None, d_store: Optional[engine.ParamStore] = None):
+        assert g_kwargs.get("scale", 4) == 4, "the train step is defined for scale 4 (all shipped configs)"
+        self.cfg, self.B, self.h, self.w = cfg, B, h, w
+        self.dt = hip.dtype_code(dtype)
+        self.dp = dp if dp is not None else DPContext(None, 0, 1)
+        self.use_graph = use_graph
+        self.g_kwargs, self.d_kwargs = dict(g_kwargs), dict(d_kwargs)
+        cin, cout = g_kwargs["num_in_ch"], g_kwargs.get("num_out_ch", 3)
+        cd = d_kwargs["num_in_ch"]
+        assert cd == cout + (cin if cfg.feed_disc_lr else 0), \
+            f"network_d.num_in_ch={cd} must be {cout} (+{cin} with feed_disc_lr): ssr_esrgan_model.py:171-178"
+        self.cin, self.cout, self.cd = cin, cout, cd
+        self.g_store = g_store or engine.ParamStore(engine.generator_specs(**g_kwargs), self.dt)
+        self.d_store = d_store or engine.ParamStore(
+            engine.discriminator_specs(cd, d_kwargs.get("num_feat", 64)), self.dt)
+        tdt, dev = hip.torch_dtype(self.dt), self.g_store.device
+        H, W = 4 * h, 4 * w
+        self.H, self.W = H, W
+        cdp = engine.rup(cd, 8)
+        z = lambda *s: torch.zeros(*s, dtype=tdt, device=dev)
+        self.fake_in = z(B, H, W, cdp)      # [G output | lr_resized]   (ssr_esrgan_model.py:171-178)
+        self.real_in = z(B, H, W, cdp)      # [gt       | lr_resized]   (:202-213)
+        self.grad_l1 = z(B, H, W, cdp)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
+                                               num_feat=d_kwargs.get("num_feat", 64),
+                                               skip_connection=d_kwargs.get("skip_connection", True))
+        self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in,
+                                           d_out_buf=self.d_plan.g_in, **g_kwargs)
+        self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
+        self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
+        self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._warm = False
+        self.iter = 0
+
+    # ------------------------------------------------------------------ state
+    def load_state(self, g_sd, d_sd, reset_ema: bool = True):
+        self.g_store.load_state_dict(g_sd)
+        self.d_store.load_state_dict(d_sd)
+        if reset_ema and self.opt_g.ema is not None:
+            self.opt_g.ema.copy_(self.g_store.data)
+
+    def ema_state_dict(self):
+        out = OrderedDict()
+        for key in self.g_store.offsets:
+            out[key] = self.g_store.tensor(key, self.opt_g.ema).clone()
+        return out
+
+    def sync_params_from_rank0(self):
+        """DDP constructor semantics."""
+        for t in (self.g_store.data, self.d_store.data, *self.d_store.u.values(), *self.d_store.v.values()):
+            self.dp.broadcast_(t)
+        if self.opt_g.ema is not None:
+            self.opt_g.ema.copy_(self.g_store.data)
+
+    # ------------------------------------------------------------------ data
+    def feed_data(self, lr: torch.Tensor, gt: torch.Tensor, scale: float = 1.0):
+        """lr: [B,Cin,h,w], gt: [B,3,4h,4w] float32 NCHW on the GPU (`scale` = 1/255 for uint8-valued
+        inputs: ssr_esrgan_model.py:106-108)."""
+        L = hip.lib()
+        st = hip.stream_ptr()
+        lr = lr.contiguous()
+        gt = gt.contiguous()
+        self.g_plan.load_input(lr, scale)
+        hip.check(L.ssr_nchw_to_nhwc(gt.data_ptr(), self.B, self.cout, self.H, self.W, view(self.real_in), self.dt, 1,
+                                     1, scale, st), "gt->nhwc")
+        if self.cfg.feed_disc_lr:   # lr_resized = F.interpolate(lr, scale_factor=4) (nearest), :133
+            for buf in (self.real_in, self.fake_in):
+                hip.check(L.ssr_nchw_to_nhwc(lr.data_ptr(), self.B, self.cin, self.h, self.w,
+                                             hip.View(buf.data_ptr(), buf.shape[-1], self.cout), self.dt, 1, 4, scale,
+                                             st), "lr_resized")
+
+    # ------------------------------------------------------------------ phases
+    def _bce(self, target, weight, loss_idx, mean_idx, with_grad=True):
+        d = self.d_plan
+        lp = self.losses.data_ptr()
+        hip.check(hip.lib().ssr_bce_logits_loss(view(d.logits), view(d.d_logits) if with_grad else hip.NULL_VIEW,
+                                                self.dt, self.B * self.H * self.W, target, weight, lp + 4 * loss_idx,
+                                                (lp + 4 * mean_idx) if mean_idx is not None else None,
+                                                hip.stream_ptr()), "ssr_bce_logits_loss")
+
+    def _d_forward(self, x_buf):
+        self.d_store.spectral_norm(power_iter=True)   # train-mode hook: one power iteration per forward
+        self.d_store.pack()
+        self.d_plan.forward_plan(x_buf).run()
+
+    def _phase_g(self):
+        cfg = self.cfg
+        self.g_store.grad.zero_()
+        self.losses.zero_()
+        self.g_store.pack()
+        self.g_plan.fwd.run()                                              # :140
+        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.real_in), view(self.grad_l1), self.dt,
+                                        self.B * self.H * self.W, self.cout, cfg.l1_weight, self.losses.data_ptr(),
+                                        hip.stream_ptr()), "ssr_l1_loss")   # :147-150
+        self._d_forward(self.fake_in)                                      # :181
+        self._bce(cfg.real_label, cfg.gan_weight, 1, None)                 # :182 (is_disc=False)
+        self.d_plan.backward_plan(self.fake_in, param_grads=False, input_grad=True,
+                                  in_residual=self.grad_l1).run()          # :192, D frozen (:136-137)
+        self.g_plan.bwd.run()
+
+    def _phase_g_skipped(self):
+        """current_iter fails the gate at :144: only the forward runs (self.output is still needed)."""
+        self.losses.zero_()
+        self.g_store.pack()
+        self.g_plan.fwd.run()
+
+    def _phase_d(self):
+        cfg = self.cfg
+        self.d_store.grad.zero_()                                          # optimizer_d.zero_grad() :215
+        self.d_store.grad_sn.zero_()
+        self._d_forward(self.real_in)                                      # :217
+        self._bce(cfg.real_label, 1.0, 2, 3)                               # :218-220
+        self.d_plan.backward_plan(self.real_in, param_grads=True, input_grad=False).run()   # :221
+        self.d_store.spectral_norm_backward()
+        self._d_forward(self.fake_in)                                      # :224 (output.detach())
+        self._bce(cfg.fake_label, 1.0, 4, 5)                               # :225-226
+        self.d_plan.backward_plan(self.fake_in, param_grads=True, input_grad=False).run()   # :227
+        self.d_store.spectral_norm_backward()
+
+    def _phase_opt_g(self):
+        self.opt_g.update(self.dp.grad_scale)                              # :193 (+ EMA :230-231)
+
+    def _phase_opt_d(self):
+        self.opt_d.update(self.dp.grad_scale)                              # :228
+
+    # ------------------------------------------------------------------ driver
+    def _run(self, name, fn):
+        if not self.use_graph:
+            fn()
+            return
+        g = self._graphs.get(name)
+        if g is None:
+            if not self._warm:     # first touch of every kernel (hipFuncSetAttribute etc.) outside capture
+                return fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[name] = g
+        g.replay()
+
+    def step(self, current_iter: Optional[int] = None):
+        """One optimize_parameters().  Order of device work (single rank): identical to the reference.
+        With DP the G-grad all-reduce overlaps the D phases and both Adam updates come last (the D
+        phases do not read G's parameters, so the result is unchanged)."""
+        self.iter = self.iter + 1 if current_iter is None else current_iter
+        cfg = self.cfg
+        g_on = (self.iter % cfg.net_d_iters == 0) and (self.iter > cfg.net_d_init_iters)
+        if self.dp.active:
+            if g_on:
+                self._run("g", self._phase_g)
+                self.dp.all_reduce_async(self.g_store.grad)
+            else:
+                self._run("g_skip", self._phase_g_skipped)
+            self._run("d", self._phase_d)
+            self.dp.all_reduce_async(self.d_store.grad)
+            self.dp.wait()
+            if g_on:
+                self._run("opt_g", self._phase_opt_g)
+            self._run("opt_d", self._phase_opt_d)
+        else:
+            def whole():
+                self._phase_g()
+                self._phase_opt_g()
+                self._phase_d()
+                self._phase_opt_d()
+
+            def whole_skip():
+                self._phase_g_skipped()
+                self._phase_d()
+                self._phase_opt_d()
+            self._run("step" if g_on else "step_skip", whole if g_on else whole_skip)
+        self._warm = True
+
+    # ------------------------------------------------------------------ results
+    def log(self) -> "OrderedDict[str, float]":
+        """get_current_log(): one host sync, only when the caller logs (train.py:116-121)."""
+        vals = self.dp.reduce_scalars(self.losses).tolist()
+        return OrderedDict((k, vals[i]) for i, k in enumerate(LOSS_KEYS))
+
+    def output(self) -> torch.Tensor:
+        """self.output (NCHW fp32) of the last generator forward."""
+        return self.g_plan.read_output()

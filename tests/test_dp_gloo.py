@@ -1,0 +1,90 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange (satlas_super_resolution_amd/dp.py).
+
+Checks (a) chunked async all-reduce of a flat arena, (b) the DP identity the design relies on:
+per-rank half-batch gradients summed and scaled by 1/world equal the full-batch gradients of the
+mean-reduced losses — for G, and for D with ONE exchange after both backward passes (instead of the
+reference DDP's two), and (c) that spectral-norm u/v stay identical across ranks without a broadcast.
+The compute is the CPU oracle (test infrastructure)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from satlas_super_resolution_amd.dp import init_distributed
+    from oracle import esrgan_oracle as O
+    torch.set_num_threads(2)
+    ctx = init_distributed(backend="gloo")
+    assert ctx.world == world and ctx.rank == rank and ctx.active
+    # (a) chunked all-reduce over a flat arena
+    ctx.chunk_elems = 1000
+    flat = torch.arange(4321, dtype=torch.float32) * (rank + 1)
+    ctx.all_reduce_async(flat)
+    ctx.wait()
+    assert torch.equal(flat, torch.arange(4321, dtype=torch.float32) * 3)
+    assert abs(ctx.grad_scale - 0.5) < 1e-12
+    # (b) DP identity on a small ESRGAN step
+    g_kw = dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
+    g0 = O.generator_init(seed=5, **g_kw)
+    d0 = O.discriminator_init(3, 8, seed=6)
+    torch.manual_seed(7)
+    lr, gt = torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32)
+    full = O.ESRGANOracle(g0, d0, O.StepConfig())
+    full.step(lr, gt, 1)
+    part = O.ESRGANOracle(g0, d0, O.StepConfig())
+    part.step(lr[rank:rank + 1], gt[rank:rank + 1], 1)
+    keys_g, keys_d = list(part.g_grads), list(part.d_grads)
+    flat_g = torch.cat([part.g_grads[k].reshape(-1) for k in keys_g])
+    flat_d = torch.cat([part.d_grads[k].reshape(-1) for k in keys_d])     # real+fake already summed: ONE exchange
+    ctx.all_reduce_async(flat_g)
+    ctx.all_reduce_async(flat_d)
+    ctx.wait()
+    flat_g *= ctx.grad_scale
+    flat_d *= ctx.grad_scale
+    ref_g = torch.cat([full.g_grads[k].reshape(-1) for k in keys_g])
+    ref_d = torch.cat([full.d_grads[k].reshape(-1) for k in keys_d])
+    eg = float((flat_g - ref_g).abs().max() / ref_g.abs().max())
+    ed = float((flat_d - ref_d).abs().max() / ref_d.abs().max())
+    # (c) u/v identical across ranks without broadcast (same weights -> same power iteration)
+    u = part.d["conv3.weight_u"].clone()
+    gathered = [torch.zeros_like(u) for _ in range(world)]
+    dist.all_gather(gathered, u)
+    same_uv = all(torch.equal(gathered[0], t) for t in gathered)
+    losses = ctx.reduce_scalars(torch.tensor([float(rank + 1), 2.0]))
+    q.put((rank, eg, ed, same_uv, losses.tolist()))
+    ctx.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, eg, ed, same_uv, losses in res:
+        assert eg < 1e-4, ("G grads", rank, eg)
+        assert ed < 1e-4, ("D grads", rank, ed)
+        assert same_uv
+        assert losses == [1.5, 2.0]

@@ -244,3 +244,172 @@ def test_discriminator_golden_forward_backward(name):
     plan.forward_plan(xb).run()
     y_eval = _buf_to_nchw(hip, plan.logits, 1, dt)
     assert parity_close(y_eval, fx["y_eval"]), rel_err(y_eval, fx["y_eval"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused G+D train step vs the reference-driven golden step and vs the CPU oracle
+# ---------------------------------------------------------------------------------------------
+def _check_step_against(fx_logs, fx_g0, fx_d0, g_final, d_final, g_ema_final, ts, upd_tol=2e-2):
+    for k, v in g_final.items():
+        upd_ref = v - fx_g0[k]
+        upd = ts.g_store.tensor(k).cpu() - fx_g0[k]
+        assert (upd - upd_ref).abs().max() <= upd_tol * upd_ref.abs().max() + 1e-9, ("G", k)
+    sd_d = ts.d_store.state_dict()
+    for k, v in d_final.items():
+        got = sd_d[k].cpu()
+        if k.endswith("_u") or k.endswith("_v"):
+            assert rel_err(got, v) < 1e-3, ("D buffer", k, rel_err(got, v))
+        else:
+            upd_ref = v - fx_d0[k]
+            assert (got - v).abs().max() <= upd_tol * upd_ref.abs().max() + 1e-9, ("D", k)
+    ema = ts.ema_state_dict()
+    for k, v in g_ema_final.items():
+        # ema - g0 = (1-decay) * sum of parameter updates: same update-relative tolerance as the params
+        upd_ref = v - fx_g0[k]
+        assert (ema[k].cpu() - v).abs().max() <= upd_tol * upd_ref.abs().max() + 3e-7 * v.abs().max() + 1e-9, ("EMA", k)
+
+
+@pytest.mark.parametrize("name", ["step_tiny", "step_tiny_feedlr"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_golden(name, use_graph):
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    fx = load_golden(name)
+    cfg = StepConfig(l1_weight=fx["l1_weight"], gan_weight=fx["gan_weight"], lr_g=fx["lr"], lr_d=fx["lr"],
+                     betas=tuple(fx["betas"]), ema_decay=fx["ema_decay"], feed_disc_lr=fx["feed_disc_lr"])
+    B = fx["data"][0][0].shape[0]
+    ts = ESRGANTrainStep(fx["g_kwargs"], fx["d_kwargs"], B, 8, 8, "fp32", cfg, use_graph=use_graph)
+    ts.load_state(fx["g0"], fx["d0"])
+    for it, (lr, gt) in enumerate(fx["data"], start=1):
+        ts.feed_data(lr.cuda(), gt.cuda())
+        ts.step(it)
+        log = ts.log()
+        for k, v in fx["logs"][it - 1].items():
+            assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, log[k], v)
+        if it == 1:
+            # gradients of iteration 1 are still in the arenas only for D (G's were consumed by Adam but
+            # not cleared): compare both
+            for k, g in fx["g_grads_iter1"].items():
+                got = ts.g_store.tensor(k, ts.g_store.grad)
+                assert parity_close(got, g), ("g grad", k, rel_err(got, g))
+            for k, g in fx["d_grads_iter1"].items():
+                got = ts.d_store.tensor(k, ts.d_store.grad)
+                assert parity_close(got, g), ("d grad", k, rel_err(got, g))
+    out = ts.output()
+    assert parity_close(out, fx["output_last"]), rel_err(out, fx["output_last"])
+    _check_step_against(fx["logs"], fx["g0"], fx["d0"], fx["g_final"], fx["d_final"], fx["g_ema_final"], ts)
+
+
+def test_train_step_vs_oracle_baseline_shape():
+    """BASELINE.json configs[1] shape at reduced depth/batch (1xS2 RGB, 32x32 -> 128x128; nf=64, gc=32, nb=2,
+    B=2) against the CPU oracle, two iterations."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    g_kw = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32)
+    d_kw = dict(num_in_ch=3, num_feat=64, skip_connection=True)
+    g0 = O.generator_init(seed=1, **g_kw)
+    d0 = O.discriminator_init(3, 64, seed=2)
+    torch.manual_seed(3)
+    data = [(torch.rand(2, 3, 32, 32), torch.rand(2, 3, 128, 128)) for _ in range(2)]
+    orc = O.ESRGANOracle(g0, d0, O.StepConfig())
+    ts = ESRGANTrainStep(g_kw, d_kw, 2, 32, 32, "fp32", StepConfig(), use_graph=True)
+    ts.load_state(g0, d0)
+    for it, (lr, gt) in enumerate(data, start=1):
+        ref_log = orc.step(lr, gt, it)
+        ts.feed_data(lr.cuda(), gt.cuda())
+        ts.step(it)
+        log = ts.log()
+        for k, v in ref_log.items():
+            assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, log[k], v)
+        if it == 1:
+            for k, g in orc.g_grads.items():
+                got = ts.g_store.tensor(k, ts.g_store.grad)
+                assert parity_close(got, g), ("g grad", k, rel_err(got, g))
+            for k, g in orc.d_grads.items():
+                got = ts.d_store.tensor(k, ts.d_store.grad)
+                assert parity_close(got, g), ("d grad", k, rel_err(got, g))
+    assert parity_close(ts.output(), orc.output)
+    _check_step_against(None, g0, d0, orc.g, {k: orc.d[k] for k in orc.d}, orc.g_ema, ts)
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in boundary: nn.Module plugins under torch.autograd, and the model plugin
+# ---------------------------------------------------------------------------------------------
+def test_arch_plugins_autograd_matches_golden():
+    from satlas_super_resolution_amd.archs.rrdbnet_arch import SSR_RRDBNet
+    from satlas_super_resolution_amd.archs.discriminator_arch import SSR_UNetDiscriminatorSN
+    fx = load_golden("g_tiny_ragged")
+    net = SSR_RRDBNet(**fx["kwargs"])
+    net.load_state_dict(fx["state_dict"], strict=True)
+    net = net.cuda().train()
+    x = fx["x"].cuda().requires_grad_(True)
+    y = net(x)
+    assert parity_close(y, fx["y"])
+    (y * fx["r"].cuda()).sum().backward()
+    assert parity_close(x.grad, fx["dx"])
+    for k, p in net.named_parameters():
+        assert parity_close(p.grad, fx["grads"][k]), k
+    with torch.no_grad():
+        assert parity_close(net(fx["x"].cuda()), fx["y"])       # inference plan
+    # discriminator: train-mode forward updates u/v in place; frozen params -> dgrad only
+    fd = load_golden("d_tiny")
+    d = SSR_UNetDiscriminatorSN(**fd["kwargs"])
+    d.load_state_dict(fd["state_dict_before"], strict=True)
+    d = d.cuda().train()
+    xd = fd["x"].cuda().requires_grad_(True)
+    yd = d(xd)
+    assert parity_close(yd, fd["y"])
+    (yd * fd["r"].cuda()).sum().backward()
+    assert parity_close(xd.grad, fd["dx"])
+    for k, p in d.named_parameters():
+        assert parity_close(p.grad, fd["grads"][k]), k
+    sd = d.state_dict()
+    for n in ("conv1", "conv8"):
+        assert rel_err(sd[n + ".weight_u"], fd["state_dict_after"][n + ".weight_u"]) < 1e-4
+    d.eval()
+    with torch.no_grad():
+        assert parity_close(d(fd["x"].cuda()), fd["y_eval"])
+
+
+def test_model_plugin_runs_reference_style_loop(tmp_path):
+    """SSRESRGANModel driven the way /root/reference/ssr/train.py:106-126 drives it, YAML-shaped opt."""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden("step_tiny")
+    opt = {
+        "model_type": "SSRESRGANModel", "scale": 4, "manual_seed": 0, "is_train": True, "dist": False,
+        "l1_gt_usm": False, "percep_gt_usm": False, "gan_gt_usm": False, "feed_disc_lr": False,
+        "network_g": dict(type="SSR_RRDBNet", **fx["g_kwargs"]),
+        "network_d": dict(type="SSR_UNetDiscriminatorSN", **fx["d_kwargs"]),
+        "path": {"models": str(tmp_path / "models"), "training_states": str(tmp_path / "states")},
+        "train": {"ema_decay": 0.999, "optim_g": {"type": "Adam", "lr": 1e-4, "weight_decay": 0, "betas": [0.9, 0.99]},
+                  "optim_d": {"type": "Adam", "lr": 1e-4, "weight_decay": 0, "betas": [0.9, 0.99]},
+                  "scheduler": {"type": "MultiStepLR", "milestones": [400000], "gamma": 0.5},
+                  "pixel_opt": {"type": "L1Loss", "loss_weight": 1.0, "reduction": "mean"},
+                  "gan_opt": {"type": "GANLoss", "gan_type": "vanilla", "real_label_val": 1.0,
+                              "fake_label_val": 0.0, "loss_weight": 0.1},
+                  "net_d_iters": 1, "net_d_init_iters": 0},
+    }
+    model = build_model(opt)
+    for it, (lr, gt) in enumerate(fx["data"], start=1):
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.feed_data({"lr": (lr * 255).round().to(torch.uint8), "hr": (gt * 255).round().to(torch.uint8)})
+        if it == 1:
+            model.ts.load_state(fx["g0"], fx["d0"])
+        model.optimize_parameters(it)
+        log = model.get_current_log()
+        assert set(log) == {"l_g_pix", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake"}
+        for k, v in fx["logs"][it - 1].items():      # inputs were quantised to uint8: loose
+            assert abs(log[k] - v) < 2e-2, (k, log[k], v)
+    assert model.get_current_learning_rate() == [1e-4]
+    model.test()
+    vis = model.get_current_visuals()
+    assert vis["result"].shape == (2, 3, 32, 32) and vis["lr"].shape == (2, 6, 8, 8)
+    model.save(0, 2)
+    ck = torch.load(tmp_path / "models" / "net_g_2.pth")
+    assert set(ck) == {"params", "params_ema"} and "conv_first.weight" in ck["params_ema"]
+    assert set(torch.load(tmp_path / "models" / "net_d_2.pth")) == {"params"}
+    with pytest.raises(KeyError):            # the reference indexes opt['l1_gt_usm'] directly
+        bad = dict(opt); bad.pop("l1_gt_usm")
+        m2 = build_model(bad)
+        m2.feed_data({"lr": torch.zeros(2, 6, 8, 8, dtype=torch.uint8), "hr": torch.zeros(2, 3, 32, 32, dtype=torch.uint8)})
+        m2.optimize_parameters(1)

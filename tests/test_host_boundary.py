@@ -1,0 +1,81 @@
+"""CPU: the host-side mirror of the reference's plugin interface: registry names, ctor
+signatures, state_dict layout (checked against the reference modules' own state_dicts stored in the
+golden fixtures), YAML-style option handling."""
+import inspect
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_registry_names_and_signatures():
+    from satlas_super_resolution_amd import archs, models  # noqa: F401  (filename-suffix discovery)
+    from satlas_super_resolution_amd.registry import ARCH_REGISTRY, MODEL_REGISTRY, build_network
+    G = ARCH_REGISTRY.get("SSR_RRDBNet")
+    D = ARCH_REGISTRY.get("SSR_UNetDiscriminatorSN")
+    M = MODEL_REGISTRY.get("SSRESRGANModel")
+    pg = list(inspect.signature(G.__init__).parameters)[1:7]
+    assert pg == ["num_in_ch", "num_out_ch", "scale", "num_feat", "num_block", "num_grow_ch"]   # rrdbnet_arch.py:92
+    pd = list(inspect.signature(D.__init__).parameters)[1:4]
+    assert pd == ["num_in_ch", "num_feat", "skip_connection"]                                    # discriminator_arch.py:23
+    assert list(inspect.signature(M.__init__).parameters)[1:] == ["opt"]
+    for name in ("feed_data", "optimize_parameters", "test", "get_current_visuals", "get_current_log",
+                 "update_learning_rate", "get_current_learning_rate", "save", "resume_training", "validation"):
+        assert callable(getattr(M, name)), name
+    # network_g of esrgan_s2naip_urban.yml:70-76 (num_in_ch 36 is legal and must be honoured)
+    net = build_network({"type": "SSR_RRDBNet", "num_in_ch": 36, "num_out_ch": 3, "num_feat": 64, "num_block": 1,
+                         "num_grow_ch": 32})
+    assert net.conv_first.weight.shape == (64, 36, 3, 3)
+
+
+@pytest.mark.parametrize("name", ["g_tiny_ragged", "g_mid_24ch", "g_scale2", "g_scale1"])
+def test_generator_state_dict_layout_matches_reference(name):
+    from satlas_super_resolution_amd.archs.rrdbnet_arch import SSR_RRDBNet
+    fx = load_golden(name)
+    net = SSR_RRDBNet(**fx["kwargs"])
+    ref = fx["state_dict"]
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype, k
+    net.load_state_dict(ref, strict=True)   # published checkpoints load with strict_load_g: true
+    # init distributions (rrdbnet_arch.py:35): RDB convs ~ kaiming*0.1 with zero bias
+    fresh = SSR_RRDBNet(**fx["kwargs"])
+    w = fresh.body[0].rdb1.conv1.weight if hasattr(fresh.body, "__getitem__") else getattr(fresh.body, "0").rdb1.conv1.weight
+    fan_in = w.shape[1] * 9
+    assert abs(float(w.std()) - 0.1 * (2.0 / fan_in) ** 0.5) < 0.3 * 0.1 * (2.0 / fan_in) ** 0.5
+    assert float(getattr(fresh.body, "0").rdb1.conv1.bias.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["d_tiny", "d_in6_noskip"])
+def test_discriminator_state_dict_layout_matches_reference(name):
+    from satlas_super_resolution_amd.archs.discriminator_arch import SSR_UNetDiscriminatorSN
+    fx = load_golden(name)
+    net = SSR_UNetDiscriminatorSN(**fx["kwargs"])
+    ref = fx["state_dict_before"]
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())     # 28 entries: weight/bias, weight_orig/weight_u/weight_v
+    for k in ref:
+        assert sd[k].shape == ref[k].shape, k
+    net.load_state_dict(ref, strict=True)
+    assert torch.allclose(net.conv1.weight_u.norm(), torch.tensor(1.0), atol=1e-5)
+
+
+def test_generator_full_size_parameter_counts():
+    """16,697,987 / 16,710,083 / 16,751,555 params for C_in = 3 / 24 / 96; D 4,376,897 (C_d=3)."""
+    from satlas_super_resolution_amd import engine
+    for cin, n in ((3, 16697987), (24, 16710083), (96, 16751555)):
+        specs = engine.generator_specs(num_in_ch=cin)
+        assert sum(s.cout * s.cin * 9 + s.cout for s in specs) == n
+        assert len(specs) == 351
+    d = engine.discriminator_specs(3)
+    assert sum(s.cout * s.cin * s.k * s.k + (s.cout if s.bias else 0) for s in d) == 4376897
+
+
+def test_model_option_handling_without_gpu():
+    """Unsupported options must raise, never be silently ignored; KeyError semantics of the reference."""
+    from satlas_super_resolution_amd.models.ssr_esrgan_model import _arch_kwargs
+    with pytest.raises(NotImplementedError):
+        _arch_kwargs({"type": "SRCNN"}, "SSR_RRDBNet")
+    assert _arch_kwargs({"type": "SSR_RRDBNet", "num_in_ch": 24}, "SSR_RRDBNet") == {"num_in_ch": 24}

@@ -76,7 +76,7 @@ def instrumented_step(ts, args):
             rc = fn(*a, hip.stream_ptr())
             e1.record()
             assert rc == 0, (name, rc)
-            records.append((sym, fl, e0, e1))
+            records.append((sym, fl, e0, e1, what))
 
     class Rec:
         def __init__(self, L):
@@ -96,12 +96,25 @@ def instrumented_step(ts, args):
         engine.Launcher.run = orig
         ts.use_graph = use_graph
     torch.cuda.synchronize()
-    agg = {}
-    for sym, fl, e0, e1 in records:
+    agg, per_layer = {}, {}
+    for sym, fl, e0, e1, what in records:
+        secs = e0.elapsed_time(e1) * 1e-3
         a = agg.setdefault(sym, [0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += secs
         a[2] += fl
+        b = per_layer.setdefault((what, sym), [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += secs
+        b[2] += fl
+    if os.environ.get("SSR_BENCH_LAYER_DUMP"):
+        rows = sorted(((k[0], k[1], v[0], 1e6 * v[1] / v[0], v[2] / v[0] / 1e9,
+                        (v[2] / v[1] / 1e12) if v[1] > 0 else 0.0) for k, v in per_layer.items()),
+                      key=lambda r: -r[2] * r[3])
+        with open(os.environ["SSR_BENCH_LAYER_DUMP"], "w") as f:
+            f.write("what | symbol | launches | avg_us | gflop_per_launch | tflops\n")
+            for r in rows:
+                f.write(f"{r[0]} | {r[1]} | {r[2]} | {r[3]:.2f} | {r[4]:.3f} | {r[5]:.1f}\n")
     return agg
 
 

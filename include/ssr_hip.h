@@ -64,8 +64,11 @@ typedef struct ssr_conv_desc {
     ssr_view x;
     int32_t N, Hi, Wi;        /* stored input dims */
     int32_t up;               /* 1, or 2 = nearest x2 upsample on read (logical dims Hi*up x Wi*up) */
-    int32_t Cin;              /* channels contracted (multiple of 8) */
-    /* packed weights [KH*KW][CoutPad][CinPad], CinPad = roundup(Cin, 16 (f32) | 32 (bf16)) */
+    int32_t Cin;              /* channels contracted from x (multiple of 8) */
+    ssr_view x2;              /* optional second input (p == NULL: none): the contraction runs over the channel */
+    int32_t Cin2;             /*   concatenation [x(Cin) | x2(Cin2)] — "gather" form of the dense-block backward */
+    /* packed weights, chunk-major [Cin chunk][KH*KW][CoutPad][CK]; CK = ssr_conv2d_ck(dtype, KH) input
+     * channels per chunk (32 bf16 / 16 fp32; half of that for 4x4 kernels), Cin zero-padded to a multiple */
     const void* w;
     int32_t CoutPad;          /* multiple of 32 */
     const float* bias;        /* Cout floats or NULL */
@@ -89,6 +92,8 @@ int ssr_conv2d(const ssr_conv_desc* d, void* stream);
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
  * used by bench.py to attribute launch durations to kernel symbols.  Negative on error. */
 int ssr_conv2d_variant(const ssr_conv_desc* d);
+/* input channels per packed weight chunk for a KHxKH kernel in `dtype` */
+int ssr_conv2d_ck(int32_t dtype, int32_t KH);
 
 /*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at
@@ -126,12 +131,14 @@ int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw);
 typedef struct ssr_pack_item {
     const float* src;         /* [Cout][Cin][KH][KW] */
     const float* inv_scale;   /* device scalar sigma (weights are divided by it) or NULL */
-    void* dst_fwd;            /* [KH*KW][CoutPad][CinPad] or NULL */
-    void* dst_dgrad;          /* stride 1: [KH*KW][CinPadO][CoutPadI] (taps flipped); stride 2 (4x4):
-                                 [4 parity classes][4 taps][CinPadO][CoutPadI]; or NULL */
+    void* dst_fwd;            /* [CinPad/ck_fwd][KH*KW][CoutPad][ck_fwd] or NULL */
+    void* dst_dgrad;          /* stride 1: [CoutPadI/ck_dgrad][KH*KW (taps flipped)][CinPadO][ck_dgrad];
+                                 stride 2 (4x4): [4 parity classes][CoutPadI/ck_dgrad][4 taps][CinPadO][ck_dgrad];
+                                 or NULL */
     int32_t Cout, Cin, KH, KW, stride;
     int32_t CoutPad, CinPad;      /* fwd padding */
-    int32_t CinPadO, CoutPadI;    /* dgrad: "output" channels (=Cin) padded to 32, "input" (=Cout) padded to CK */
+    int32_t CinPadO, CoutPadI;    /* dgrad: "output" channels (=Cin) padded to 32, "input" (=Cout) padded to ck_dgrad */
+    int32_t ck_fwd, ck_dgrad;     /* channels per chunk of the consuming kernels (ssr_conv2d_ck) */
 } ssr_pack_item;
 
 int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream);

@@ -16,8 +16,7 @@ from .hipnet import HipNet
 
 class _GeneratorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, x, *params):
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    def forward(ctx, net, need, x, *params):
         st = net.store()
         B, _, H, W = x.shape
         plan = net.plan(B, H, W, training=need)
@@ -39,11 +38,11 @@ class _GeneratorFn(torch.autograd.Function):
         st.grad.zero_()
         plan.bwd.run()
         gx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             gx = plan.read_input_grad()
             if plan.unshuffle > 1:
                 gx = F.pixel_shuffle(gx, plan.unshuffle)   # inverse of the pixel_unshuffle index map
-        return (None, gx, *net.grads_from_arena(list(ctx.needs_input_grad[2:])))
+        return (None, None, gx, *net.grads_from_arena(list(ctx.needs_input_grad[3:])))
 
 
 @ARCH_REGISTRY.register()
@@ -63,4 +62,7 @@ class SSR_RRDBNet(HipNet):
         return self._plans[key]
 
     def forward(self, x):
-        return _GeneratorFn.apply(self, x, *self.parameters())
+        params = list(self.parameters())
+        # grad mode is off inside Function.forward: decide here whether activations must be retained
+        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _GeneratorFn.apply(self, need, x, *params)

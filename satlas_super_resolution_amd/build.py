@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv.hip", "wgrad.hip", "misc.hip"]
+SOURCES = ["conv.hip", "conv_res.hip", "wgrad.hip", "wgrad_bf16.hip", "misc.hip"]
 OUT = os.path.join(HERE, "libssr_hip.so")
 
 
@@ -21,7 +21,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wgrad_common.h"), os.path.join(CSRC, "conv_epilogue.h"),
                                                        os.path.join(ROOT, "include", "ssr_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

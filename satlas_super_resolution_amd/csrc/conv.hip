@@ -1,33 +1,44 @@
-// Direct (im2col-free) NHWC convolution on the gfx950 matrix cores.
+// Direct (im2col-free) NHWC convolution on the gfx950 matrix cores — software-pipelined version.
 //
-// One workgroup = WAVES wavefronts computes an output tile of TH x 16 grid positions (TH = 2*WAVES)
-// times BN = 32*NT output channels.  Per input-channel chunk (CK = 16 fp32 / 32 bf16 channels) the
-// workgroup stages the input halo patch and the [tap][co][ci] weight slab in LDS once, then every
-// tap reads its shifted window straight out of the patch: no im2col buffer ever exists.
-// Each wave owns 32 grid positions (2 rows x 16) and NT 32x32 MFMA accumulators; a single 16-byte
-// LDS read per operand feeds 4 v_mfma_f32_32x32x2_f32 (fp32, exact) or 1 v_mfma_f32_32x32x16_bf16.
-// LDS rows are 80 bytes (64 data + 16 pad): conflict-free for the 16-lane ds_read_b128 groups.
+// A workgroup of MW*KS wavefronts computes an output tile of (2*MW) x 16 grid positions times
+// BN = 32*NT output channels.  Input channels are consumed in chunks of CK (32 bf16 / 16 fp32; half
+// of that for the 4x4 stride-2 layers): per chunk the workgroup stages the input halo patch and the
+// [tap][co][CK] weight slab in LDS ONCE and every tap reads its shifted window straight out of the patch.
+//   * pipelining: LDS is double buffered and the global loads of chunk c+1 are issued into registers
+//     before chunk c is contracted, so HBM/L2 latency overlaps the MFMAs; one barrier per chunk.
+//   * waves: MW waves tile the pixels (32 grid positions = 2 rows x 16 each, NT 32x32 accumulators);
+//     KS = 2 splits the reduction inside a chunk across two waves per pixel group (k-substep for 3x3/2x2,
+//     tap-column parity for 4x4), which doubles the waves per CU for the small 32x32-pixel generator
+//     layers; partial sums are combined through LDS once at the end.
+//   * matrix core: one 16-byte LDS read per operand feeds 4 v_mfma_f32_32x32x2_f32 (fp32, exact) or
+//     1 v_mfma_f32_32x32x16_bf16; rows are padded by 16 B (80 B / 48 B): conflict-free ds_read_b128.
+//   * packed weights are chunk-major [chunk][tap][CoutPad][CK]: a stage's slab is contiguous in HBM.
 //
 // Replaces: every nn.Conv2d forward on the ESRGAN path and (with flipped weights) its dgrad —
 // /root/reference/ssr/archs/rrdbnet_arch.py:26-30,99-112,123-136 and discriminator_arch.py:28-40,44-69 —
 // with torch.cat (rrdbnet_arch.py:39-42), LeakyReLU, the 0.2-residuals (:44,:68), the trunk add (:125),
 // nearest x2 upsampling (:127-128), the U-Net skip adds (discriminator_arch.py:53-64) and the
 // corresponding backward masks / gradient fan-in sums folded into the load and the epilogue.
-#include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
-template <typename T, int KH, int KW, int S, int NT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void conv_kernel(const ssr_conv_desc d) {
-    constexpr int VEC = DT<T>::VEC, CK = 4 * VEC, CKP = CK + VEC, BN = 32 * NT;
-    constexpr int TH = 2 * WAVES, TW = 16;
+template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
+__global__ __launch_bounds__(64 * MW * KS) void conv_kernel(const ssr_conv_desc d) {
+    constexpr int VEC = DT<T>::VEC;
+    constexpr int KSTEPS = (KH == 4) ? 1 : 2;          // 16-byte k-reads per tap per chunk
+    constexpr int CK = KSTEPS * 2 * VEC, VPR = 2 * KSTEPS, CKP = CK + VEC, BN = 32 * NT;
+    constexpr int TH = 2 * MW, TW = 16;
     constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
-    constexpr int NTHR = 64 * WAVES;
+    constexpr int NTHR = 64 * MW * KS;
+    constexpr int PVEC = PH * PW * VPR, WVEC = KH * KW * BN * VPR;
+    constexpr int NPV = (PVEC + NTHR - 1) / NTHR, NWV = (WVEC + NTHR - 1) / NTHR;
+    constexpr int STAGE = (PH * PW + KH * KW * BN) * CKP;   // elements per LDS stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* lp = reinterpret_cast<T*>(smem);  // patch   [PH*PW][CKP]
-    T* lw = lp + PH * PW * CKP;          // weights [KH*KW*BN][CKP]
+    T* lds = reinterpret_cast<T*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MW, kh = wave / MW;               // pixel group, k-split half
     const int tiles_x = (d.Gw + TW - 1) / TW, tiles_y = (d.Gh + TH - 1) / TH;
     int b = blockIdx.x;
     const int tx_i = b % tiles_x; b /= tiles_x;
@@ -40,7 +51,65 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(const ssr_conv_desc d)
     const T* __restrict__ wg = reinterpret_cast<const T*>(d.w);
     const int upshift = d.up == 2 ? 1 : 0;
     const int LH = d.Hi << upshift, LW = d.Wi << upshift;
-    const int CinPad = (d.Cin + CK - 1) / CK * CK;
+    const T* __restrict__ x2g = reinterpret_cast<const T*>(d.x2.p);
+    const int Ktot = d.Cin + d.Cin2;
+    const int nchunks = (Ktot + CK - 1) / CK;
+    const size_t wchunk = (size_t)KH * KW * d.CoutPad * CK;   // packed elements per chunk
+
+    // ---- per-thread staging descriptors (independent of the chunk) ----
+    int pgo[NPV], pgo2[NPV], plo[NPV], pch[NPV];   // global element offsets into x / x2 (-1: outside image),
+                                                   // LDS offset, channel part
+    int wgo[NWV], wlo[NWV];
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) {
+        const int v = tid + q * NTHR;
+        const int pix = v / VPR, part = v - pix * VPR;
+        const int py = pix / PW, px = pix - py * PW;
+        const int ly = gy0 * S + py - d.pad_y, lx = gx0 * S + px - d.pad_x;
+        const bool ok = v < PVEC && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+        pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff +
+                            part * VEC)
+                    : -1;
+        pgo2[q] = (ok && x2g) ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x2.cs +
+                                      d.x2.coff + part * VEC)
+                              : -1;
+        plo[q] = v < PVEC ? pix * CKP + part * VEC : -1;
+        pch[q] = part * VEC;
+    }
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) {
+        const int v = tid + q * NTHR;
+        const int row = v / VPR, part = v - row * VPR;
+        const int tap = row / BN, co = row - tap * BN;
+        wgo[q] = v < WVEC ? (tap * d.CoutPad + co0 + co) * CK + part * VEC : -1;
+        wlo[q] = PH * PW * CKP + row * CKP + part * VEC;
+    }
+    u32x4 rp[NPV], rw[NWV];
+    auto load_chunk = [&](int c) {
+        const int c0 = c * CK;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            u32x4 val = {0u, 0u, 0u, 0u};
+            const int k0 = c0 + pch[q];
+            if (pgo[q] >= 0) {
+                if (k0 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[q] + c0);
+                else if (k0 < Ktot) val = *reinterpret_cast<const u32x4*>(x2g + (size_t)pgo2[q] + (c0 - d.Cin));
+            }
+            rp[q] = val;
+        }
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            if (wgo[q] >= 0) rw[q] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[q]);
+    };
+    auto store_chunk = [&](int stage) {
+        T* base = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q)
+            if (plo[q] >= 0) *reinterpret_cast<u32x4*>(base + plo[q]) = rp[q];
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            if (wgo[q] >= 0) *reinterpret_cast<u32x4*>(base + wlo[q]) = rw[q];
+    };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -49,93 +118,118 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(const ssr_conv_desc d)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int i = lane & 31, g = lane >> 5;
-    const int ty = 2 * wave + (i >> 4), tx = i & 15;
-    const T* abase = lp + ((ty * S) * PW + tx * S) * CKP + g * VEC;
-    const T* bbase = lw + i * CKP + g * VEC;
+    const int ty = 2 * wm + (i >> 4), tx = i & 15;
+    // K-split offsets: k-substep (KSTEPS == 2) or tap-column parity (4x4)
+    const int a_ks = (KS == 2) ? (KSTEPS == 2 ? kh * 2 * VEC : kh * CKP) : 0;
+    const int b_ks = (KS == 2) ? (KSTEPS == 2 ? kh * 2 * VEC : kh * BN * CKP) : 0;
+    const int a_off = ((ty * S) * PW + tx * S) * CKP + g * VEC + a_ks;
+    const int b_off = PH * PW * CKP + i * CKP + g * VEC + b_ks;
 
-    for (int c0 = 0; c0 < CinPad; c0 += CK) {
-        // ---- stage the halo patch (zero outside the image / beyond Cin) ----
-        for (int v = tid; v < PH * PW * 4; v += NTHR) {
-            const int pix = v >> 2, part = v & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const int ly = gy0 * S + py - d.pad_y, lx = gx0 * S + px - d.pad_x;
-            const int c = c0 + part * VEC;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (ly >= 0 && ly < LH && lx >= 0 && lx < LW && c < d.Cin) {
-                const int sy = ly >> upshift, sx = lx >> upshift;  // nearest: floor(o/2)
-                const size_t off = ((size_t)(n * d.Hi + sy) * d.Wi + sx) * d.x.cs + d.x.coff + c;
-                val = *reinterpret_cast<const u32x4*>(xg + off);
-            }
-            *reinterpret_cast<u32x4*>(lp + pix * CKP + part * VEC) = val;
-        }
-        // ---- stage the weight slab [tap][co0..co0+BN)[c0..c0+CK) ----
-        for (int v = tid; v < KH * KW * BN * 4; v += NTHR) {
-            const int row = v >> 2, part = v & 3;
-            const int tap = row / BN, co = row - tap * BN;
-            const size_t off = ((size_t)tap * d.CoutPad + co0 + co) * CinPad + c0 + part * VEC;
-            *reinterpret_cast<u32x4*>(lw + row * CKP + part * VEC) = *reinterpret_cast<const u32x4*>(wg + off);
-        }
-        __syncthreads();
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next = c + 1 < nchunks;
+        if (has_next) load_chunk(c + 1);
+        const T* ab = lds + (c & 1) * STAGE + a_off;
+        const T* bb = lds + (c & 1) * STAGE + b_off;
+        if (KSTEPS == 2) {
+            constexpr int NKK = (KS == 2) ? 1 : 2;
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
+            for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
+                for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const u32x4 a = *reinterpret_cast<const u32x4*>(abase + (ky * PW + kx) * CKP + kk * 2 * VEC);
+                    for (int kk = 0; kk < NKK; ++kk) {
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(ab + (ky * PW + kx) * CKP + kk * 2 * VEC);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const u32x4 bv = *reinterpret_cast<const u32x4*>(
+                                bb + ((ky * KW + kx) * BN + t * 32) * CKP + kk * 2 * VEC);
+                            mma16<T>(acc[t], a, bv);
+                        }
+                    }
+        } else {
+            constexpr int NKX = (KS == 2) ? KW / 2 : KW, KXS = (KS == 2) ? 2 : 1;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                for (int kxi = 0; kxi < NKX; ++kxi) {
+                    const int kx = kxi * KXS;
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(ab + (ky * PW + kx) * CKP);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const u32x4 bb = *reinterpret_cast<const u32x4*>(
-                            bbase + ((ky * KW + kx) * BN + t * 32) * CKP + kk * 2 * VEC);
-                        mma16<T>(acc[t], a, bb);
+                        const u32x4 bv =
+                            *reinterpret_cast<const u32x4*>(bb + ((ky * KW + kx) * BN + t * 32) * CKP);
+                        mma16<T>(acc[t], a, bv);
                     }
                 }
-            }
         }
+        if (has_next) store_chunk((c + 1) & 1);
         __syncthreads();
     }
 
-    // ---- fused epilogue ----
-    T* __restrict__ yp = reinterpret_cast<T*>(d.y.p);
-    T* __restrict__ y0p = reinterpret_cast<T*>(d.y0.p);
-    T* __restrict__ y1p = reinterpret_cast<T*>(d.y1.p);
-    const T* __restrict__ r1p = reinterpret_cast<const T*>(d.r1.p);
-    const T* __restrict__ r2p = reinterpret_cast<const T*>(d.r2.p);
-    const T* __restrict__ mp = reinterpret_cast<const T*>(d.m.p);
+    // ---- fused epilogue for one 32-channel output tile ----
+    char* slab = smem + (size_t)MW * 16 * 64 * sizeof(float) + (size_t)wave * EPI_STAGE_BYTES;   // behind `red`
+    auto epilogue = [&](const f32x16& a, int t) {
+        conv_epilogue<T>(d, a, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+    };
+
+    if (KS == 1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = co0 + t * 32 + i;
-        if (co >= d.Cout) continue;
-        const float bv = d.bias ? d.bias[co] : 0.f;
-        const bool has_r1 = r1p && co < d.r1_nc, has_r2 = r2p && co < d.r2_nc;
-        const bool has_m = mp && co >= d.m_c0 && co < d.m_c1;
+        for (int t = 0; t < NT; ++t) epilogue(acc[t], t);
+    } else {
+        // combine the two k-halves through LDS (stage buffers are free after the last barrier);
+        // with NT == 2 each half finishes one of the two output tiles, otherwise half 0 finishes.
+        float* red = reinterpret_cast<float*>(smem);          // [MW][16][64]
+        float* mine = red + (wm * 16) * 64 + lane;
+        if (NT == 2) {
+            if (kh == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pi = mfma32_row(r, g);
-            const int gy = gy0 + 2 * wave + (pi >> 4), gx = gx0 + (pi & 15);
-            if (gy >= d.Gh || gx >= d.Gw) continue;
-            const size_t p = ((size_t)(n * d.Ho + gy * d.oys + d.oyo)) * d.Wo + gx * d.oxs + d.oxo;
-            float v = acc[t][r] + bv;
-            if (d.act == SSR_ACT_LRELU) v = lrelu(v);
-            v *= d.alpha;
-            if (y0p) y0p[p * d.y0.cs + d.y0.coff + co] = from_f32<T>(v);
-            if (has_r1) v += d.beta1 * to_f32(r1p[p * d.r1.cs + d.r1.coff + co]);
-            if (has_r2) v += d.beta2 * to_f32(r2p[p * d.r2.cs + d.r2.coff + co]);
-            if (d.accumulate) v += to_f32(yp[p * d.y.cs + d.y.coff + co]);
-            if (y1p) y1p[p * d.y1.cs + d.y1.coff + co] = from_f32<T>(v);
-            if (has_m) v *= lrelu_grad_from_out(to_f32(mp[p * d.m.cs + d.m.coff + co]));
-            yp[p * d.y.cs + d.y.coff + co] = from_f32<T>(v);
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[NT - 1][r];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[NT - 1][r] += mine[r * 64];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            } else {
+                epilogue(acc[NT - 1], NT - 1);
+            }
+        } else {
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            }
         }
     }
 }
 
-template <typename T, int KH, int KW, int S, int NT, int WAVES>
+template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
 int launch_conv(const ssr_conv_desc& d, hipStream_t st) {
-    constexpr int VEC = DT<T>::VEC, CK = 4 * VEC, CKP = CK + VEC, BN = 32 * NT;
-    constexpr int TH = 2 * WAVES, TW = 16, PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
-    constexpr size_t lds = (size_t)(PH * PW + KH * KW * BN) * CKP * sizeof(T);
+    constexpr int VEC = DT<T>::VEC, KSTEPS = (KH == 4) ? 1 : 2, CK = KSTEPS * 2 * VEC, CKP = CK + VEC, BN = 32 * NT;
+    constexpr int TH = 2 * MW, TW = 16, PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+    constexpr size_t stage = (size_t)(PH * PW + KH * KW * BN) * CKP * sizeof(T);
+    constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
+    constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_kernel<T, KH, KW, S, NT, WAVES>;
+    auto kern = conv_kernel<T, KH, KW, S, NT, MW, KS>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -145,13 +239,13 @@ int launch_conv(const ssr_conv_desc& d, hipStream_t st) {
     }
     const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
     dim3 grid(tiles, d.CoutPad / BN, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, st, d);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * MW * KS), lds, st, d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }
 
-// BN = 64 when the padded output width allows it; small problems use 2-wave (4x16) tiles so that
-// more workgroups exist than CUs.
+// BN = 64 when the padded output width allows it; small problems use 4x16-pixel tiles (MW = 2) so
+// that there are at least as many workgroups as CUs.
 inline void pick_tile(const ssr_conv_desc& d, bool& nt2, bool& small) {
     nt2 = (d.CoutPad % 64) == 0;
     const long tiles4 = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32));
@@ -162,8 +256,8 @@ template <typename T, int KH, int KW, int S>
 int dispatch_tile(const ssr_conv_desc& d, hipStream_t st) {
     bool nt2, small;
     pick_tile(d, nt2, small);
-    if (nt2) return small ? launch_conv<T, KH, KW, S, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 2, 4>(d, st);
-    return small ? launch_conv<T, KH, KW, S, 1, 2>(d, st) : launch_conv<T, KH, KW, S, 1, 4>(d, st);
+    if (nt2) return small ? launch_conv<T, KH, KW, S, 2, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 2, 4, 2>(d, st);
+    return small ? launch_conv<T, KH, KW, S, 1, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 1, 4, 2>(d, st);
 }
 
 template <typename T>
@@ -181,11 +275,21 @@ bool view_ok(const ssr_view& v, bool required) {
 
 }  // namespace
 
+// K-resident LDS-DMA kernel for the small generator-body layers (conv_res.hip)
+bool ssr_conv_res_try(const ssr_conv_desc& d, hipStream_t st, int* rc);
+bool ssr_conv_res_qualifies(const ssr_conv_desc& d);
+
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
+    if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
     bool nt2, small;
     pick_tile(*dp, nt2, small);
     return dp->KH * 1000 + dp->stride * 100 + (nt2 ? 2 : 1) * 10 + (small ? 2 : 4);
+}
+
+extern "C" int ssr_conv2d_ck(int32_t dtype, int32_t KH) {
+    const int vec = dtype == SSR_F32 ? 4 : 8;
+    return (KH == 4 ? 1 : 2) * 2 * vec;
 }
 
 extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) {
@@ -196,7 +300,11 @@ extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) {
     if (d.Cin <= 0 || (d.Cin % 8) != 0 || d.CoutPad <= 0 || (d.CoutPad % 32) != 0 || d.Cout > d.CoutPad)
         return SSR_EINVAL;
     if (!(d.up == 1 || d.up == 2) || d.N <= 0 || d.Gh <= 0 || d.Gw <= 0) return SSR_EINVAL;
+    if (d.x2.p && (d.Cin2 <= 0 || (d.Cin2 % 8) != 0 || !view_ok(d.x2, true))) return SSR_EINVAL;
+    if (!d.x2.p && d.Cin2 != 0) return SSR_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = 0;
+    if (ssr_conv_res_try(d, st, &rc)) return rc;
     if (d.dtype == SSR_F32) return dispatch_geom<float>(d, st);
     if (d.dtype == SSR_BF16) return dispatch_geom<__bf16>(d, st);
     return SSR_EUNSUP;

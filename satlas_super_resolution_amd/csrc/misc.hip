@@ -37,13 +37,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
     const float inv = it.inv_scale ? 1.0f / it.inv_scale[0] : 1.0f;
     const long stride = (long)gridDim.x * blockDim.x;
     const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (it.dst_fwd) {
+    if (it.dst_fwd) {   // [chunk][tap][CoutPad][ck]
         T* __restrict__ dst = reinterpret_cast<T*>(it.dst_fwd);
+        const int ck = it.ck_fwd;
         const long total = (long)KK * it.CoutPad * it.CinPad;
         for (long e = t0; e < total; e += stride) {
-            const int ci = (int)(e % it.CinPad);
-            const long q = e / it.CinPad;
-            const int co = (int)(q % it.CoutPad), tap = (int)(q / it.CoutPad);
+            const int cc = (int)(e % ck);
+            long q = e / ck;
+            const int co = (int)(q % it.CoutPad); q /= it.CoutPad;
+            const int tap = (int)(q % KK), ci = (int)(q / KK) * ck + cc;
             float v = 0.f;
             if (co < it.Cout && ci < it.Cin) v = it.src[((long)co * it.Cin + ci) * KK + tap] * inv;
             dst[e] = from_f32<T>(v);
@@ -51,26 +53,29 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
     }
     if (it.dst_dgrad) {
         T* __restrict__ dst = reinterpret_cast<T*>(it.dst_dgrad);
+        const int ck = it.ck_dgrad;
         if (it.stride == 1) {
-            // Wd[tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
+            // Wd[chunk][tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
             const long total = (long)KK * it.CinPadO * it.CoutPadI;
             for (long e = t0; e < total; e += stride) {
-                const int k = (int)(e % it.CoutPadI);
-                const long q = e / it.CoutPadI;
-                const int o = (int)(q % it.CinPadO), tap = (int)(q / it.CinPadO);
+                const int cc = (int)(e % ck);
+                long q = e / ck;
+                const int o = (int)(q % it.CinPadO); q /= it.CinPadO;
+                const int tap = (int)(q % KK), k = (int)(q / KK) * ck + cc;
                 float v = 0.f;
                 if (k < it.Cout && o < it.Cin) v = it.src[((long)k * it.Cin + o) * KK + (KK - 1 - tap)] * inv;
                 dst[e] = from_f32<T>(v);
             }
         } else {
             // 4x4 stride-2 transposed conv as four output-parity classes of 2x2 taps:
-            // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x)
-            const long total = (long)16 * it.CinPadO * it.CoutPadI;
-            for (long e = t0; e < total; e += stride) {
-                const int k = (int)(e % it.CoutPadI);
-                long q = e / it.CoutPadI;
+            // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x); [cls][chunk][t][o][ck]
+            const long per_cls = (long)4 * it.CinPadO * it.CoutPadI;
+            for (long e = t0; e < 4 * per_cls; e += stride) {
+                const int cls = (int)(e / per_cls);
+                long q = e - cls * per_cls;
+                const int cc = (int)(q % ck); q /= ck;
                 const int o = (int)(q % it.CinPadO); q /= it.CinPadO;
-                const int t = (int)(q & 3), cls = (int)(q >> 2);
+                const int t = (int)(q & 3), k = (int)(q >> 2) * ck + cc;
                 const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
                 const int ky = py ? 2 - 2 * ty : 3 - 2 * ty, kx = px ? 2 - 2 * tx : 3 - 2 * tx;
                 float v = 0.f;

@@ -11,23 +11,15 @@
 // cross-wave reduce through LDS at the end; 4x4: wave w owns tap row ky = w).  A launch processes a
 // device table of work items spanning many layers, so the 345 tiny body layers of the generator
 // become ONE launch with one writer per dW element (deterministic, no atomics).
-// bf16 activations are widened to fp32 while being staged (v1: fp32 MFMA for both dtypes).
+// This file is the exact-fp32 path; bf16 uses the transpose-read bf16-MFMA kernel in wgrad_bf16.hip.
 //
 // Replaces autograd's convolution_backward (weight, bias) for every Conv2d under
 // /root/reference/ssr/models/ssr_esrgan_model.py:192,221,227.
-#include "common.h"
-#include <type_traits>
+#include "wgrad_common.h"
 
 namespace {
 
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-constexpr int WG_TH = 8, WG_TW = 16, WG_ROW = 36;  // LDS row stride in floats (32 + 4 pad, 16B aligned)
+constexpr int WG_ROW = 36;  // LDS row stride in floats (32 + 4 pad, 16B aligned)
 
 template <typename T> __device__ __forceinline__ void store_widened(float* dst, const u32x4& v);
 template <> __device__ __forceinline__ void store_widened<float>(float* dst, const u32x4& v) {
@@ -123,62 +115,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ssr_wgrad_layer* __res
         __syncthreads();
     }
 
-    // ---- write-out: D[row = co][col = ci] ----
-    float* __restrict__ dw = L.dw;
-    const int KK = KH * KW;
-    if (SPLIT_TAPS) {
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            const int tap = wave * KW + t;
-            const int ci = it.ci0 + i;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = it.co0 + mfma32_row(r, g);
-                if (co < L.Cout && ci < L.Cin_w) {
-                    const size_t idx = ((size_t)co * L.Cin_w + ci) * KK + tap;
-                    const float v = L.alpha * acc[t][r];
-                    if (it.atomic) atomicAdd(dw + idx, v); else dw[idx] += v;
-                }
-            }
-        }
-        if (do_bias && i == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = it.co0 + mfma32_row(r, g);
-                if (co < L.Cout) {
-                    const float v = L.alpha * accb[r];
-                    if (it.atomic) atomicAdd(L.db + co, v); else L.db[co] += v;
-                }
-            }
-        }
-    } else {
-        float* red = lx;  // [4 waves][16][64]
-        const bool bias_round = L.db != nullptr && it.ci0 == 0;
-        auto round = [&](const f32x16& part, int t, bool is_bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = part[r];
-            __syncthreads();
-            for (int e = tid; e < 1024; e += 256) {
-                const int r = e >> 6, ln = e & 63;
-                const float s = red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln] +
-                                red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln];
-                const int co = it.co0 + mfma32_row(r, ln >> 5), col = ln & 31;
-                const float v = L.alpha * s;
-                if (!is_bias) {
-                    const int ci = it.ci0 + col;
-                    if (co < L.Cout && ci < L.Cin_w) {
-                        const size_t idx = ((size_t)co * L.Cin_w + ci) * KK + t;
-                        if (it.atomic) atomicAdd(dw + idx, v); else dw[idx] += v;
-                    }
-                } else if (col == 0 && co < L.Cout) {
-                    if (it.atomic) atomicAdd(L.db + co, v); else L.db[co] += v;
-                }
-            }
-            __syncthreads();
-        };
-        static_for<0, NTAP>([&](auto tc) { constexpr int t = decltype(tc)::value; round(acc[t], t, false); });
-        if (bias_round) round(accb, 0, true);
-    }
+    wgrad_writeout<KH, KW, SPLIT_TAPS, NTAP>(acc, accb, L, it, lx, do_bias);
 }
 
 template <typename T, int KH, int KW, int S, bool SPLIT>
@@ -210,6 +147,10 @@ int dispatch_wgrad(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, i
 
 }  // namespace
 
+// bf16: transpose-read MFMA kernel (wgrad_bf16.hip)
+int ssr_wgrad_bf16_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW,
+                            int S, hipStream_t st);
+
 extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw) {
     return N * ((Gh + WG_TH - 1) / WG_TH) * ((Gw + WG_TW - 1) / WG_TW);
 }
@@ -219,6 +160,6 @@ extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgr
     if (!layers_dev || !items_dev || n_items <= 0) return SSR_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SSR_F32) return dispatch_wgrad<float>(layers_dev, items_dev, n_items, KH, KW, stride, st);
-    if (dtype == SSR_BF16) return dispatch_wgrad<__bf16>(layers_dev, items_dev, n_items, KH, KW, stride, st);
+    if (dtype == SSR_BF16) return ssr_wgrad_bf16_dispatch(layers_dev, items_dev, n_items, KH, KW, stride, st);
     return SSR_EUNSUP;
 }

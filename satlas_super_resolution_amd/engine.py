@@ -84,15 +84,17 @@ class ParamStore:
             self.sn_dot = torch.zeros(len(self.sn_names), 4, device=self.device)
         # packed weights
         tdt = hip.torch_dtype(dtype)
-        ck = ck_of(dtype)
+        L = hip.lib()
         self.packed_fwd: Dict[str, torch.Tensor] = {}
         self.packed_dgrad: Dict[str, torch.Tensor] = {}
         self.pad: Dict[str, Tuple[int, int, int, int]] = {}
         items = []
         for i, s in enumerate(specs):
             kk = s.k * s.k
-            cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck)
-            cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck)
+            ck_f = L.ssr_conv2d_ck(dtype, s.k)                       # kernel consuming the forward weights
+            ck_d = L.ssr_conv2d_ck(dtype, s.k if s.stride == 1 else 2)   # dgrad kernel (2x2 parity classes for s2)
+            cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck_f)
+            cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck_d)
             self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)
             pf = torch.zeros(kk * cout_pad * cin_pad, dtype=tdt, device=self.device)
             ntap_d = kk if s.stride == 1 else 16
@@ -101,7 +103,7 @@ class ParamStore:
             woff, _ = self.offsets[s.name + (".weight_orig" if s.sn else ".weight")]
             inv = (self.sigma.data_ptr() + 4 * self.sn_names.index(s.name)) if s.sn else None
             items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, pf.data_ptr(), pd.data_ptr(),
-                                  s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i))
+                                  s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d))
         self._pack_items = items
         self.pack_table = hip.device_table(items)
         if self.sn_names:

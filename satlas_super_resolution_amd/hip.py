@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32),
         ("x", View), ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("up", C.c_int32), ("Cin", C.c_int32),
+        ("x2", View), ("Cin2", C.c_int32),
         ("w", C.c_void_p), ("CoutPad", C.c_int32), ("bias", C.c_void_p),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
         ("Gh", C.c_int32), ("Gw", C.c_int32),
@@ -67,6 +68,7 @@ class PackItem(C.Structure):
         ("src", C.c_void_p), ("inv_scale", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
         ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
         ("CoutPad", C.c_int32), ("CinPad", C.c_int32), ("CinPadO", C.c_int32), ("CoutPadI", C.c_int32),
+        ("ck_fwd", C.c_int32), ("ck_dgrad", C.c_int32),
     ]
 
 
@@ -89,7 +91,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
@@ -115,6 +117,7 @@ def lib() -> C.CDLL:
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     l.ssr_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
     l.ssr_conv2d_variant.argtypes = [C.POINTER(ConvDesc)]
+    l.ssr_conv2d_ck.argtypes = [i32, i32]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     l.ssr_wgrad_tiles.argtypes = [i32, i32, i32]
     l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]

@@ -51,7 +51,7 @@ def parse():
 
 def conv_flops(d) -> float:
     """Algorithmic FLOPs of one ssr_conv2d launch: 2 * grid * Cout * taps * Cin_valid."""
-    return 2.0 * d.N * d.Gh * d.Gw * d.Cout * d.KH * d.KW * d.Cin
+    return 2.0 * d.N * d.Gh * d.Gw * d.Cout * d.KH * d.KW * (d.Cin + d.Cin2)
 
 
 def instrumented_step(ts, args):

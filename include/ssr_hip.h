@@ -143,6 +143,28 @@ typedef struct ssr_pack_item {
 
 int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream);
 
+/*
+ * Packed weights for the "gather" form of the dense-block backward (rrdbnet_arch.py:37-44 under autograd):
+ *   d x_k = sum_{j > k} conv3x3( dpre_j , rot180(W_j[:, slice_k])^T )
+ * i.e. ONE convolution per channel slice over the channel concatenation of all later pre-activation
+ * gradients — the mirror image of the concat-free forward.  One table entry copies the slice of one later
+ * conv into its K range of the gathered weight: dst[chunk][tap'][o][cc] with k = chunk*ck + cc,
+ * value = scale * src[k - kbase][ci0 + o][8 - tap'] for kbase <= k < kbase + Cout (rows o >= nci are zero).
+ */
+typedef struct ssr_pack_seg {
+    const float* src;         /* later conv, fp32 OIHW [Cout][Cin][3][3] */
+    void* dst;                /* [Kpad/ck][9][rows_pad][ck] */
+    float scale;              /* residual scaling folded in (0.2 / 0.04 for conv5: rrdbnet_arch.py:44,68) */
+    int32_t Cout, Cin;        /* of src */
+    int32_t ci0, nci;         /* slice of src's input channels = output channels of the gathered conv */
+    int32_t kbase;            /* offset of src's Cout channels inside the concatenated K */
+    int32_t rows_pad, ck;
+} ssr_pack_seg;
+int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_items, int32_t dtype, void* stream);
+
+/* dst[p, c] += src[p, c] over npix pixels and C channels of two NHWC views */
+int ssr_add_views(ssr_view dst, ssr_view src, int32_t dtype, int64_t npix, int32_t C, void* stream);
+
 /* ---- layout conversion at the plugin boundary (NCHW fp32 tensors of the reference API) ---- */
 /* dst NHWC[n,h,w,coff+c] = src NCHW fp32 [n,c,h,w] * scale, optionally through pixel_unshuffle
  * (arch_util.py:769-785; `unshuffle` = 1 none | 2 | 4) and nearest upsampling by `up`

@@ -86,6 +86,35 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_seg_kernel(const ssr_pack_seg* __restrict__ items) {
+    const ssr_pack_seg it = items[blockIdx.y];
+    T* __restrict__ dst = reinterpret_cast<T*>(it.dst);
+    const long total = (long)it.Cout * 9 * it.rows_pad;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(e % it.Cout);          // fastest: consecutive k -> consecutive cc in dst
+        long q = e / it.Cout;
+        const int o = (int)(q % it.rows_pad), tap = (int)(q / it.rows_pad);
+        const int k = it.kbase + kk, chunk = k / it.ck, cc = k - chunk * it.ck;
+        float v = 0.f;
+        if (o < it.nci) v = it.scale * it.src[((long)kk * it.Cin + it.ci0 + o) * 9 + (8 - tap)];
+        dst[(((long)chunk * 9 + tap) * it.rows_pad + o) * it.ck + cc] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_views_kernel(ssr_view dst, ssr_view src, long npix, int C) {
+    T* __restrict__ d = reinterpret_cast<T*>(dst.p);
+    const T* __restrict__ s = reinterpret_cast<const T*>(src.p);
+    const long total = npix * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long p = e / C;
+        const int c = (int)(e - p * C);
+        const long di = p * dst.cs + dst.coff + c;
+        d[di] = from_f32<T>(to_f32(d[di]) + to_f32(s[p * src.cs + src.coff + c]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // boundary layout conversion
 // ------------------------------------------------------------------------------------------------
@@ -142,17 +171,49 @@ __device__ __forceinline__ void bil_src(int o, int n_in, int& i0, int& i1, float
     l0 = 1.f - l1;
 }
 
+// 16-byte channel vectors (8 bf16 / 4 fp32 per thread)
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&f)[4]) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = v[k];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[4]) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = f[k];
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+template <> struct VecIO<__bf16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const __bf16* p, float (&f)[8]) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
+    }
+    static __device__ __forceinline__ void store(__bf16* p, const float (&f)[8]) {
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)f[k];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(ssr_view a, ssr_view b, ssr_view y, int N, int H, int W,
                                                              int C) {
-    const int H2 = 2 * H, W2 = 2 * W;
-    const long total = (long)N * H2 * W2 * C;
+    constexpr int V = VecIO<T>::N;
+    const int H2 = 2 * H, W2 = 2 * W, CV = C / V;
+    const long total = (long)N * H2 * W2 * CV;
     const T* __restrict__ ap = reinterpret_cast<const T*>(a.p);
     const T* __restrict__ bp = reinterpret_cast<const T*>(b.p);
     T* __restrict__ yp = reinterpret_cast<T*>(y.p);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        long q = e / C;
+        const int c = (int)(e % CV) * V;
+        long q = e / CV;
         const int ox = (int)(q % W2); q /= W2;
         const int oy = (int)(q % H2);
         const int n = (int)(q / H2);
@@ -160,14 +221,21 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(ssr_view a, ssr_vie
         float ly0, ly1, lx0, lx1;
         bil_src(oy, H, y0, y1, ly0, ly1);
         bil_src(ox, W, x0, x1, lx0, lx1);
-        auto rd = [&](int yy, int xx) {
+        float t00[V], t01[V], t10[V], t11[V], o[V];
+        auto rd = [&](int yy, int xx, float (&f)[V]) {
             const long p = ((long)n * H + yy) * W + xx;
-            float v = to_f32(ap[p * a.cs + a.coff + c]);
-            if (bp) v += to_f32(bp[p * b.cs + b.coff + c]);
-            return v;
+            VecIO<T>::load(ap + p * a.cs + a.coff + c, f);
+            if (bp) {
+                float g[V];
+                VecIO<T>::load(bp + p * b.cs + b.coff + c, g);
+#pragma unroll
+                for (int k = 0; k < V; ++k) f[k] += g[k];
+            }
         };
-        const float v = ly0 * (lx0 * rd(y0, x0) + lx1 * rd(y0, x1)) + ly1 * (lx0 * rd(y1, x0) + lx1 * rd(y1, x1));
-        yp[(((long)n * H2 + oy) * W2 + ox) * y.cs + y.coff + c] = from_f32<T>(v);
+        rd(y0, x0, t00); rd(y0, x1, t01); rd(y1, x0, t10); rd(y1, x1, t11);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = ly0 * (lx0 * t00[k] + lx1 * t01[k]) + ly1 * (lx0 * t10[k] + lx1 * t11[k]);
+        VecIO<T>::store(yp + (((long)n * H2 + oy) * W2 + ox) * y.cs + y.coff + c, o);
     }
 }
 
@@ -182,20 +250,23 @@ __device__ __forceinline__ float bil_w(int o, int n_in, int i) {  // weight of i
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m,
                                                        int N, int H, int W, int C) {
-    const int H2 = 2 * H, W2 = 2 * W;
-    const long total = (long)N * H * W * C;
+    constexpr int V = VecIO<T>::N;
+    const int H2 = 2 * H, W2 = 2 * W, CV = C / V;
+    const long total = (long)N * H * W * CV;
     const T* __restrict__ dp = reinterpret_cast<const T*>(dy.p);
     const T* __restrict__ rp = reinterpret_cast<const T*>(r.p);
     const T* __restrict__ mp = reinterpret_cast<const T*>(m.p);
     T* __restrict__ y1p = reinterpret_cast<T*>(y1.p);
     T* __restrict__ yp = reinterpret_cast<T*>(y.p);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        long q = e / C;
+        const int c = (int)(e % CV) * V;
+        long q = e / CV;
         const int ix = (int)(q % W); q /= W;
         const int iy = (int)(q % H);
         const int n = (int)(q / H);
-        float s = 0.f;
+        float s[V], t[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
         if (MODE == 0) {
 #pragma unroll
             for (int dyy = -1; dyy <= 2; ++dyy) {
@@ -209,21 +280,34 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, 
                     if (ox < 0 || ox >= W2) continue;
                     const float wx = bil_w(ox, W, ix);
                     if (wx == 0.f) continue;
-                    s += wy * wx * to_f32(dp[(((long)n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c]);
+                    VecIO<T>::load(dp + (((long)n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c, t);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s[k] += wy * wx * t[k];
                 }
             }
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    s += to_f32(dp[(((long)n * H2 + 2 * iy + a) * W2 + 2 * ix + b) * dy.cs + dy.coff + c]);
+                for (int b = 0; b < 2; ++b) {
+                    VecIO<T>::load(dp + (((long)n * H2 + 2 * iy + a) * W2 + 2 * ix + b) * dy.cs + dy.coff + c, t);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s[k] += t[k];
+                }
         }
         const long p = ((long)n * H + iy) * W + ix;
-        if (rp) s += to_f32(rp[p * r.cs + r.coff + c]);
-        if (y1p) y1p[p * y1.cs + y1.coff + c] = from_f32<T>(s);
-        if (mp) s *= lrelu_grad_from_out(to_f32(mp[p * m.cs + m.coff + c]));
-        if (yp) yp[p * y.cs + y.coff + c] = from_f32<T>(s);
+        if (rp) {
+            VecIO<T>::load(rp + p * r.cs + r.coff + c, t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += t[k];
+        }
+        if (y1p) VecIO<T>::store(y1p + p * y1.cs + y1.coff + c, s);
+        if (mp) {
+            VecIO<T>::load(mp + p * m.cs + m.coff + c, t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] *= lrelu_grad_from_out(t[k]);
+        }
+        if (yp) VecIO<T>::store(yp + p * y.cs + y.coff + c, s);
     }
 }
 
@@ -232,12 +316,21 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, 
 //   tmp layout: [0..rows) = s = W v ; [rows..rows+cols) = t = W^T u ; [rows+cols] = scratch
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const ssr_sn_item* __restrict__ items) {
+    // t = W^T u: 64 columns per workgroup (coalesced 256-B row segments), the 4 waves stride the rows
+    __shared__ float part[4][64];
     const ssr_sn_item it = items[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= it.cols) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= it.cols) return;
     float s = 0.f;
-    for (int i = 0; i < it.rows; ++i) s += it.w[(long)i * it.cols + j] * it.u[i];
-    it.tmp[it.rows + j] = s;
+    if (j < it.cols) {
+        const float* __restrict__ wp = it.w + j;
+#pragma unroll 8
+        for (int i = w; i < it.rows; i += 4) s += wp[(long)i * it.cols] * it.u[i];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < it.cols) it.tmp[it.rows + j] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
 // one wave per row: s_i = sum_j W[i][j] * vhat[j], vhat = t / max(|t|, eps) (power_iter) or v (eval)
@@ -407,6 +500,28 @@ extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items,
     return SSR_OK;
 }
 
+extern "C" int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_items, int32_t dtype, void* stream) {
+    if (!items_dev || n_items <= 0) return SSR_EINVAL;
+    dim3 grid(8, n_items);
+    if (dtype == SSR_F32) hipLaunchKernelGGL(pack_seg_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_seg_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_add_views(ssr_view dst, ssr_view src, int32_t dtype, int64_t npix, int32_t C, void* stream) {
+    if (!dst.p || !src.p || npix <= 0 || C <= 0) return SSR_EINVAL;
+    const int g = grid_for(npix * C, 256 * 4, 2048);
+    if (dtype == SSR_F32)
+        hipLaunchKernelGGL(add_views_kernel<float>, dim3(g), dim3(256), 0, ST(stream), dst, src, (long)npix, C);
+    else if (dtype == SSR_BF16)
+        hipLaunchKernelGGL(add_views_kernel<__bf16>, dim3(g), dim3(256), 0, ST(stream), dst, src, (long)npix, C);
+    else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
 extern "C" int ssr_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, ssr_view dst,
                                 int32_t dtype, int32_t unshuffle, int32_t up, float scale, void* stream) {
     if (!src || !dst.p || unshuffle < 1 || up < 1 || H % unshuffle || W % unshuffle) return SSR_EINVAL;
@@ -451,8 +566,10 @@ extern "C" int ssr_fill(void* p, int64_t n, int32_t dtype, float value, void* st
 
 extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_t N, int32_t H, int32_t W,
                                   int32_t C, void* stream) {
-    if (!a.p || !y.p) return SSR_EINVAL;
-    const long total = (long)N * H * W * 4 * C;
+    if (!a.p || !y.p || (C % 8) != 0 || (a.cs % 8) || (a.coff % 8) || (y.cs % 8) || (y.coff % 8) ||
+        (b.p && ((b.cs % 8) || (b.coff % 8))))
+        return SSR_EINVAL;
+    const long total = (long)N * H * W * 4 * C / 4;
     if (dtype == SSR_F32)
         hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
                            b, y, N, H, W, C);
@@ -467,8 +584,8 @@ extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dt
 template <int MODE>
 static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N, int32_t H,
                     int32_t W, int32_t C, void* stream) {
-    if (!dy.p || (!y.p && !y1.p)) return SSR_EINVAL;
-    const long total = (long)N * H * W * C;
+    if (!dy.p || (!y.p && !y1.p) || (C % 8) != 0 || (dy.cs % 8) || (dy.coff % 8)) return SSR_EINVAL;
+    const long total = (long)N * H * W * C / 4;
     if (dtype == SSR_F32)
         hipLaunchKernelGGL((up2x_bwd_kernel<float, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
                            dy, r, y1, y, m, N, H, W, C);
@@ -492,7 +609,7 @@ extern "C" int ssr_spectral_norm(const ssr_sn_item* items_dev, int32_t n_items, 
                                  int32_t power_iter, void* stream) {
     if (!items_dev || n_items <= 0 || max_rows <= 0 || max_cols <= 0) return SSR_EINVAL;
     if (power_iter) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3((max_cols + 255) / 256, n_items), dim3(256), 0, ST(stream), items_dev);
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((max_cols + 63) / 64, n_items), dim3(256), 0, ST(stream), items_dev);
         SSR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3((max_rows + 3) / 4, n_items), dim3(256), 0, ST(stream), items_dev, power_iter);

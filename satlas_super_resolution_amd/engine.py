@@ -40,6 +40,7 @@ class ConvSpec:
     stride: int = 1
     bias: bool = True
     sn: bool = False  # spectral-normalised (weight stored as weight_orig)
+    dgrad_packed: bool = True  # keep a rotated/transposed copy for the per-conv (scatter) dgrad
 
 
 class ParamStore:
@@ -98,13 +99,19 @@ class ParamStore:
             self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)
             pf = torch.zeros(kk * cout_pad * cin_pad, dtype=tdt, device=self.device)
             ntap_d = kk if s.stride == 1 else 16
-            pd = torch.zeros(ntap_d * cin_pad_o * cout_pad_i, dtype=tdt, device=self.device)
+            pd = torch.zeros(ntap_d * cin_pad_o * cout_pad_i if s.dgrad_packed else 8, dtype=tdt, device=self.device)
             self.packed_fwd[s.name], self.packed_dgrad[s.name] = pf, pd
             woff, _ = self.offsets[s.name + (".weight_orig" if s.sn else ".weight")]
             inv = (self.sigma.data_ptr() + 4 * self.sn_names.index(s.name)) if s.sn else None
-            items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, pf.data_ptr(), pd.data_ptr(),
+            items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, pf.data_ptr(),
+                                  pd.data_ptr() if s.dgrad_packed else None,
                                   s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d))
         self._pack_items = items
+        # gathered dense-block dgrad weights (filled by add_rdb_gather)
+        self.gather: Dict[Tuple[str, int], torch.Tensor] = {}
+        self.gather_rows: Dict[Tuple[str, int], int] = {}
+        self._seg_items: List[hip.PackSeg] = []
+        self.seg_table = None
         self.pack_table = hip.device_table(items)
         if self.sn_names:
             sn_items, bwd_items = [], []
@@ -168,6 +175,34 @@ class ParamStore:
     def pack(self):
         hip.check(hip.lib().ssr_pack_weights(self.pack_table.data_ptr(), len(self._pack_items), self.dtype,
                                              hip.stream_ptr()), "ssr_pack_weights")
+        if self._seg_items:
+            if self.seg_table is None:
+                self.seg_table = hip.device_table(self._seg_items)
+            hip.check(hip.lib().ssr_pack_dgrad_gather(self.seg_table.data_ptr(), len(self._seg_items), self.dtype,
+                                                      hip.stream_ptr()), "ssr_pack_dgrad_gather")
+
+    def add_rdb_gather(self, prefix: str, nf: int, gc: int, a5: float):
+        """Packed weights of the gather-form backward of one ResidualDenseBlock (rrdbnet_arch.py:37-44):
+        slice k (0: the 64-ch block input, 1..4: x1..x4) <- conv3x3 over [dpre_{k+1}..dpre_4 | d_out],
+        conv5's part pre-scaled by a5 (0.2, or 0.04 inside the third RDB: :44,:68)."""
+        if (prefix, 0) in self.gather:
+            return
+        ck = hip.lib().ssr_conv2d_ck(self.dtype, 3)
+        tdt = hip.torch_dtype(self.dtype)
+        for k in range(5):
+            nout = nf if k == 0 else gc
+            ci0 = 0 if k == 0 else nf + (k - 1) * gc
+            K = (4 - k) * gc + nf
+            rows_pad, kpad = rup(nout, 32), rup(K, ck)
+            buf = torch.zeros(kpad * 9 * rows_pad, dtype=tdt, device=self.device)
+            self.gather[(prefix, k)], self.gather_rows[(prefix, k)] = buf, rows_pad
+            for jj in range(k + 1, 6):
+                cout_j = nf if jj == 5 else gc
+                cin_j = nf + (jj - 1) * gc
+                self._seg_items.append(hip.PackSeg(self.ptr(f"{prefix}.conv{jj}.weight"), buf.data_ptr(),
+                                                   a5 if jj == 5 else 1.0, cout_j, cin_j, ci0, nout,
+                                                   (jj - k - 1) * gc, rows_pad, ck))
+        self.seg_table = None
 
     def spectral_norm(self, power_iter: bool):
         if self.sn_names:
@@ -282,6 +317,35 @@ class _ConvBuilder:
             L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad {name}")
 
 
+def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View, c1: int, x2: View, c2: int, gh: int,
+                 gw: int, y: View, cout: int, **epi):
+    """One launch of the gather-form dense-block backward (ParamStore.add_rdb_gather)."""
+    st = cb.store
+    d = ConvDesc()
+    d.dtype = cb.dt
+    d.N, d.Hi, d.Wi, d.up = cb.N, gh, gw, 1
+    if c1 > 0:
+        d.x, d.Cin, d.x2, d.Cin2 = x1, c1, x2, c2
+    else:
+        d.x, d.Cin, d.x2, d.Cin2 = x2, c2, hip.NULL_VIEW, 0
+    d.w = st.gather[(prefix, k)].data_ptr()
+    d.CoutPad = st.gather_rows[(prefix, k)]
+    d.bias = None
+    d.KH = d.KW = 3
+    d.stride, d.pad_y, d.pad_x = 1, 1, 1
+    d.Gh, d.Gw = gh, gw
+    d.Ho, d.Wo, d.oys, d.oyo, d.oxs, d.oxo = gh, gw, 1, 0, 1, 0
+    d.Cout = cout
+    d.y, d.y0, d.y1 = y, hip.NULL_VIEW, hip.NULL_VIEW
+    d.alpha, d.act = 1.0, hip.ACT_NONE
+    d.r1, d.r1_nc, d.beta1 = epi.get("r1", hip.NULL_VIEW), epi.get("r1_nc", 0), epi.get("beta1", 0.0)
+    d.r2, d.r2_nc, d.beta2 = epi.get("r2", hip.NULL_VIEW), epi.get("r2_nc", 0), epi.get("beta2", 0.0)
+    d.accumulate = 0
+    d.m, d.m_c0, d.m_c1 = epi.get("m", hip.NULL_VIEW), epi.get("m_c0", 0), epi.get("m_c1", 0)
+    cb.keep.append(d)
+    L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad-gather {prefix}.slice{k}")
+
+
 class WgradBatch:
     """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride)."""
 
@@ -333,8 +397,8 @@ def generator_specs(num_in_ch, num_out_ch=3, scale=4, num_feat=64, num_block=23,
     for i in range(num_block):
         for j in (1, 2, 3):
             for k in range(1, 5):
-                specs.append(ConvSpec(f"body.{i}.rdb{j}.conv{k}", gc, nf + (k - 1) * gc))
-            specs.append(ConvSpec(f"body.{i}.rdb{j}.conv5", nf, nf + 4 * gc))
+                specs.append(ConvSpec(f"body.{i}.rdb{j}.conv{k}", gc, nf + (k - 1) * gc, dgrad_packed=False))
+            specs.append(ConvSpec(f"body.{i}.rdb{j}.conv5", nf, nf + 4 * gc, dgrad_packed=False))
     specs.append(ConvSpec("conv_body", nf, nf))
     specs.append(ConvSpec("conv_up1", nf, nf))
     specs.append(ConvSpec("conv_up2", nf, nf))
@@ -472,21 +536,23 @@ class GeneratorPlan:
                 rr = 3 * i + 2
                 d_rrdb = view(self.g_body_out) if rr == n_rdb - 1 else view(self.dbufs[rr + 1], 0)
                 a5, b5 = 0.2, 1.0
+            store.add_rdb_gather(p, nf, gc, a5)
             add_wg(f"{p}.conv5", view(cur, 0), d_out_r, H, W, 1, H, W, alpha=a5, cin=cd)
-            cb.dgrad(Bk, f"{p}.conv5", d_out_r, H, W, view(dcur, 0), cout=cd, alpha=a5, r1=d_out_r, r1_nc=nf,
-                     beta1=b5, m=view(cur, 0), m_c0=nf + 3 * gc, m_c1=cd, cin_dy=nf)
             for k in (4, 3, 2, 1):
-                cin_k = nf + (k - 1) * gc
-                add_wg(f"{p}.conv{k}", view(cur, 0), view(dcur, cin_k), H, W, 1, H, W, cin=cin_k)
-                kw = dict(cout=cin_k, accumulate=1, cin_dy=gc)
-                if k >= 2:
-                    kw.update(m=view(cur, 0), m_c0=nf + (k - 2) * gc, m_c1=cin_k)
-                else:
-                    if j == 0:      # d x_rrdb += d out_rrdb                     (rrdbnet_arch.py:68)
-                        kw.update(r2=d_rrdb, r2_nc=nf, beta2=1.0)
-                    if r == 0:      # d feat += d trunk                          (rrdbnet_arch.py:125)
-                        kw.update(r1=view(self.g_trunk), r1_nc=nf, beta1=1.0)
-                cb.dgrad(Bk, f"{p}.conv{k}", view(dcur, cin_k), H, W, view(dcur, 0), **kw)
+                add_wg(f"{p}.conv{k}", view(cur, 0), view(dcur, nf + (k - 1) * gc), H, W, 1, H, W,
+                       cin=nf + (k - 1) * gc)
+            # gather form: slice k <- one conv over [dpre_{k+1} .. dpre_4 | d_out]; every slice is written once,
+            # masked by lrelu'(x_k) in the epilogue, so dgrad needs no read-modify-write
+            for k in (4, 3, 2, 1):
+                gather_dgrad(cb, Bk, p, k, view(dcur, nf + k * gc), (4 - k) * gc, d_out_r, nf, H, W,
+                             view(dcur, nf + (k - 1) * gc), gc, m=view(cur, nf + (k - 1) * gc), m_c0=0, m_c1=gc)
+            kw = dict(r1=d_out_r, r1_nc=nf, beta1=b5)        # the `+ x` path of this RDB         (rrdbnet_arch.py:44)
+            if j == 0:                                          # d x_rrdb += d out_rrdb             (rrdbnet_arch.py:68)
+                kw.update(r2=d_rrdb, r2_nc=nf, beta2=1.0)
+            gather_dgrad(cb, Bk, p, 0, view(dcur, nf), 4 * gc, d_out_r, nf, H, W, view(dcur, 0), nf, **kw)
+        # d feat += d trunk                                                                      (rrdbnet_arch.py:125)
+        Bk.add(hip.lib().ssr_add_views, view(self.dbufs[0], 0), view(self.g_trunk), self.dt, B * H * W, nf,
+               what="add d_trunk")
         add_wg("conv_first", view(self.xin), view(self.dbufs[0], 0), H, W, 1, H, W, cin=self.xin.shape[-1])
         if need_input_grad:
             cb.dgrad(Bk, "conv_first", view(self.dbufs[0], 0), H, W, view(self.g_xin), cout=self.xin.shape[-1],

@@ -72,6 +72,11 @@ class PackItem(C.Structure):
     ]
 
 
+class PackSeg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_float), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("ci0", C.c_int32), ("nci", C.c_int32), ("kbase", C.c_int32), ("rows_pad", C.c_int32), ("ck", C.c_int32)]
+
+
 class SNItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p), ("tmp", C.c_void_p),
                 ("rows", C.c_int32), ("cols", C.c_int32)]
@@ -91,7 +96,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
@@ -121,6 +126,8 @@ def lib() -> C.CDLL:
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     l.ssr_wgrad_tiles.argtypes = [i32, i32, i32]
     l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]
+    l.ssr_pack_dgrad_gather.argtypes = [vp, i32, i32, vp]
+    l.ssr_add_views.argtypes = [View, View, i32, i64, i32, vp]
     l.ssr_nchw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, View, i32, i32, i32, f32, vp]
     l.ssr_nhwc_to_nchw.argtypes = [View, i32, vp, i32, i32, i32, i32, vp]
     l.ssr_fill.argtypes = [vp, i64, i32, f32, vp]

@@ -96,6 +96,24 @@ int ssr_conv2d_variant(const ssr_conv_desc* d);
 int ssr_conv2d_ck(int32_t dtype, int32_t KH);
 
 /*
+ * Fused ResidualDenseBlock forward (rrdbnet_arch.py:37-44, and :68 for the third block of an RRDB), bf16,
+ * num_feat 64 / num_grow_ch 32: x (channels [0,64) of `cur`) -> x1..x4 written to channels [64,192) of `cur`
+ * and   out[0,64) = alpha5*(conv5(cat(x..x4)) + b5) + beta1*x + beta2*r2.
+ * One launch keeps the whole dense block of an 8x8 tile (with its 5-pixel halo) resident in LDS.
+ * `w[k]` are the forward-packed weights of conv1..5 (ssr_pack_weights, chunk = 32 channels).
+ */
+typedef struct ssr_rdb_desc {
+    int32_t dtype, N, H, W;
+    ssr_view cur, out;
+    const void* w[5];
+    const float* bias[5];
+    float alpha5, beta1;
+    ssr_view r2;
+    float beta2;
+} ssr_rdb_desc;
+int ssr_rdb_forward(const ssr_rdb_desc* d, void* stream);
+
+/*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at
  * ssr_esrgan_model.py:192,221,227):
  *   dW[co][ci][ky][kx] += alpha * sum_{n,gy,gx} dY[n, gy, gx, co] * X[n, gy*stride+ky-pad_y, gx*stride+kx-pad_x, ci]

@@ -1,0 +1,425 @@
+// Fused ResidualDenseBlock forward (bf16, num_feat = 64, num_grow_ch = 32): ONE launch for
+// /root/reference/ssr/archs/rrdbnet_arch.py:37-44
+//     x1 = lrelu(conv1(x)); x2 = lrelu(conv2(cat(x,x1))); ... x5 = conv5(cat(x..x4)); return x5*0.2 + x
+// (and the RRDB tail `out*0.2 + x`, :68, when this is the third block).
+//
+// Why: at the measured batch (16 x 32x32 pixels) every per-conv launch is latency bound (8..12 us for
+// 0.6..1.5 GFLOP: launch + load latency + epilogue), and the five convs of a block are strictly
+// sequential.  Here a workgroup owns an 8x8 output tile of one image and keeps the WHOLE dense block
+// resident in LDS: the 18x18 input halo region (5-pixel halo) and the shrinking 16x16 / 14x14 / 12x12 /
+// 10x10 regions of x1..x4 never leave the CU between the convs; only the weights are streamed
+// (LDS-DMA, double buffered 18/36 KB slabs).  Cost: halo recompute (1.76x the MFMAs of the block);
+// gain: 5 launches -> 1, no re-load of activations, one latency chain per block instead of five.
+// x1..x4 are still written to the dense buffer (8x8 core only): training needs them for dgrad masks and wgrad.
+//
+// LDS map (bytes): X0 2 x 336 rows | X1 256 | X2 208 | X3 144 | X4 112 rows of 64 B (32 bf16, source-side
+// XOR swizzle: physical 16-B part = logical ^ ((row >> 2) & 3)) = 89,088; weight ring 4 x 18,432 = 73,728.
+// Waves: 4, each owns whole 32-pixel M-tiles (tiles w, w+4); conv5: wave = (M-tile, 32-channel N-tile).
+#include "common.h"
+
+#ifdef SSR_PROBE   // tools/rdb_probe.hip
+#define PROBE(k)                                                                           \
+    do {                                                                                   \
+        if (threadIdx.x == 0) g_probe[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PROBE(k)
+#endif
+
+namespace {
+
+constexpr int RB_AROW = 80;                        // bytes per activation row in LDS: 32 bf16 + 16 B pad
+constexpr int RB_WROW = 64;                        // bytes per weight row (dense: LDS-DMA writes lane-linearly)
+constexpr int RB_X0 = 0;                           // x: 2 planes x 324 rows
+constexpr int RB_X0P = 324 * RB_AROW;
+constexpr int RB_X1 = RB_X0 + 2 * RB_X0P;          // x1: 256 rows
+constexpr int RB_X2 = RB_X1 + 256 * RB_AROW;       // x2: 196 rows (+1 dummy row each: padding lanes write there)
+constexpr int RB_X3 = RB_X2 + 197 * RB_AROW;       // x3: 144 rows
+constexpr int RB_X4 = RB_X3 + 145 * RB_AROW;       // x4: 100 rows
+constexpr int RB_RING = RB_X4 + 101 * RB_AROW;
+constexpr int RB_SLAB = 288 * RB_WROW;             // 9 taps x 32 co rows of 32 ci
+constexpr int RB_NSTAGE = 3;
+constexpr int RB_BIAS = RB_RING + RB_NSTAGE * RB_SLAB;   // [5 convs][64] fp32 bias table
+constexpr int RB_LDS = RB_BIAS + (4 * 32 + 64) * 4;   // conv k < 5 at k*32, conv5 at 128
+static_assert(RB_LDS <= 160 * 1024, "LDS budget");
+static_assert(RB_NSTAGE * RB_SLAB >= 4 * 2048 + 2 * 2 * 4096, "ring doubles as reduce scratch + output slabs");
+
+__device__ __forceinline__ constexpr int rb_slice_base(int s) {   // slice 0 (plane 0), 1..4
+    return s == 0 ? RB_X0 : s == 1 ? RB_X1 : s == 2 ? RB_X2 : s == 3 ? RB_X3 : RB_X4;
+}
+
+// Weight slab q of the block's schedule -> ring stage: 18 LDS-DMA wave-instructions (16 rows x 64 B each),
+// all issued by the PRODUCER wave (wave 4) so that the four MFMA waves never spend issue slots on loads.
+// Schedule: conv1 c0,c1 | conv2 c0..2 | conv3 c0..3 | conv4 c0..4 | conv5 (c0,n0),(c0,n1) ... (c5,n1) = 26 slabs.
+constexpr int RB_NSLAB = 26;
+__device__ __forceinline__ void rb_issue_slab(const ssr_rdb_desc& d, int q, char* stage, int lane) {
+    int k, c, nt = 0;
+    if (q < 2) { k = 0; c = q; }
+    else if (q < 5) { k = 1; c = q - 2; }
+    else if (q < 9) { k = 2; c = q - 5; }
+    else if (q < 14) { k = 3; c = q - 9; }
+    else { k = 4; c = (q - 14) >> 1; nt = (q - 14) & 1; }
+    const int cp = k == 4 ? 64 : 32;
+    const __bf16* base = reinterpret_cast<const __bf16*>(d.w[k]) + (size_t)(c * 9 * cp + nt * 32) * 32;
+    const int lrow = lane >> 2, pp = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const int row = 16 * j + lrow;                      // = tap*32 + co
+        const int tap = row >> 5, co = row & 31, lp = pp ^ ((row >> 2) & 3);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + (tap * cp + co) * 32 + lp * 8),
+            (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
+    }
+}
+
+struct RbTile {   // per-lane coordinates of one 32-pixel M-tile of a conv's output region
+    int oy, ox;   // position inside the region (clamped to a valid pixel for padding lanes)
+};
+
+template <int K>   // conv index 1..5; region side R = 18 - 2K, P = R*R pixels
+__device__ __forceinline__ RbTile rb_tile(int mt, int i) {
+    constexpr int R = 18 - 2 * K, P = R * R;
+    const int p = 32 * mt + i;
+    const int pc = p < P ? p : P - 1;
+    RbTile t;
+    t.oy = pc / R;
+    t.ox = pc - t.oy * R;
+    return t;
+}
+
+// Contraction of one weight slab (32 input channels of slice S) into NMT accumulators.
+// KK0/NKK select the 16-channel k-substeps this wave handles (all: 0,2; k-split half: kh,1).
+// Every LDS address is one per-lane base plus a compile-time immediate; reads of tap n+1 are
+// scheduled in front of the MFMAs of tap n (one wave per SIMD: overlap must come from inside the wave).
+template <int K, int S, int NMT, int NKK>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const RbTile (&tl)[NMT], const char* smem,
+                                            const char* slab, int plane, int i, int g, int kk0) {
+    constexpr int RS = 18 - 2 * S;                 // side of slice S's region
+    constexpr int DELTA = K - S - 1;               // offset of conv K's output region inside slice S's region
+    const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + (kk0 * 2 + g) * 16;
+    const char* ab[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) ab[m] = sb + (tl[m].oy * RS + tl[m].ox) * RB_AROW;
+    const int bsw = (i >> 2) & 3;
+    const char* bb0 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw)) << 4);
+    const char* bb1 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw) ^ 2) << 4);   // second k-substep (NKK == 2)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const u32x4 bv = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + (ky * 3 + kx) * 32 * RB_WROW);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(
+                        ab[m] + ((DELTA + ky) * RS + DELTA + kx) * RB_AROW + kk * 32);
+                    mma16<__bf16>(acc[m], bv, a);   // A = weights (rows = co), B = pixels (cols): C[co][pixel]
+                }
+            }
+    // interleave: LDS latency (~130+ cycles) exceeds the 32..64 cycles of MFMA issue per step and there is one
+    // wave per SIMD, so operand reads run RB_PF steps ahead of the MFMAs that consume them
+    constexpr int RB_PF = 3, NSTEP = 9 * NKK;
+#pragma unroll
+    for (int n = 0; n < RB_PF; ++n) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMT, 0);
+#pragma unroll
+    for (int n = 0; n < NSTEP; ++n) {
+        if (n + RB_PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMT, 0);
+    }
+}
+
+// C fragment with the operands swapped (weights = A): lane l owns ONE pixel (column l & 31 of the M-tile) and
+// 16 output channels co = 8*(r>>2) + 4*(l>>5) + (r&3): four runs of 4 consecutive channels.
+// Epilogue of conv K < 5: x_K = lrelu(acc + bias), zero outside the image (one test per lane), packed to bf16 and
+// written to LDS slice K with four 8-byte stores.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+template <int K>
+__device__ __forceinline__ void rb_store_slice(const f32x16& acc, int mt, const float* bias_lds, char* smem, int ty0,
+                                               int tx0, int H, int W, int i, int g) {
+    constexpr int R = 18 - 2 * K, P = R * R, HK = 5 - K;
+    const int p = 32 * mt + i;
+    const int oy = p / R, ox = p - oy * R;
+    const int iy = ty0 - HK + oy, ix = tx0 - HK + ox;
+    const bool inside = p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;   // zero padding of the NEXT conv's input
+    char* row = smem + rb_slice_base(K) + (p < P ? p : P) * RB_AROW + g * 8;   // P = dummy row
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
+        bf16x4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(inside ? lrelu(acc[4 * q4 + e] + bq[e]) : 0.f);
+        *reinterpret_cast<bf16x4v*>(row + 16 * q4) = o;
+    }
+}
+
+// cooperative write of the 8x8 core of LDS slice K (32 channels) to the dense buffer: one 16-B vector per thread
+template <int K>
+__device__ __forceinline__ void rb_flush_core(const ssr_rdb_desc& d, const char* smem, int n, int ty0, int tx0,
+                                              int tid) {
+    constexpr int R = 18 - 2 * K, HK = 5 - K;
+    const int q = tid >> 2, part = tid & 3;
+    const int cy = q >> 3, cx = q & 7;
+    const int p = (cy + HK) * R + cx + HK;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + rb_slice_base(K) + p * RB_AROW + part * 16);
+    const int iy = ty0 + cy, ix = tx0 + cx;
+    if (iy < d.H && ix < d.W) {
+        __bf16* dst = reinterpret_cast<__bf16*>(d.cur.p) + ((size_t)(n * d.H + iy) * d.W + ix) * d.cur.cs + d.cur.coff +
+                      64 + 32 * (K - 1) + part * 8;
+        *reinterpret_cast<u32x4*>(dst) = v;
+    }
+}
+
+__global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int tiles_x = (d.W + 7) / 8, tiles_y = (d.H + 7) / 8;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int ty0 = ty_i * 8, tx0 = tx_i * 8;
+    const __bf16* __restrict__ w1 = reinterpret_cast<const __bf16*>(d.w[0]);
+    const __bf16* __restrict__ w2 = reinterpret_cast<const __bf16*>(d.w[1]);
+    const __bf16* __restrict__ w3 = reinterpret_cast<const __bf16*>(d.w[2]);
+    const __bf16* __restrict__ w4 = reinterpret_cast<const __bf16*>(d.w[3]);
+    const __bf16* __restrict__ w5 = reinterpret_cast<const __bf16*>(d.w[4]);
+    char* ring = smem + RB_RING;
+    PROBE(0);
+    const bool producer = wave == 4;
+    float* bias_lds = reinterpret_cast<float*>(smem + RB_BIAS);
+    {
+        const int k = tid < 128 ? tid >> 5 : 4, c = tid < 128 ? tid & 31 : tid - 128;   // 4 x 32 + 64 entries
+        if (tid < 192) bias_lds[tid] = d.bias[k] ? d.bias[k][c] : 0.f;
+    }
+    if (producer) rb_issue_slab(d, 0, ring, lane);
+    // ---- input halo region x: 18x18 pixels x 64 channels -> X0 (2 planes of 32 channels, padded rows),
+    //      staged through registers so that the rows can be padded (conflict-free, immediate offsets) ----
+    {
+        const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.cur.p);
+        u32x4 rx[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int v = tid + q * 320;                     // (plane, pixel, part): 2 x 324 x 4 = 2592 vectors
+            const int plane = v / 1296, r2 = v - plane * 1296;
+            const int pix = r2 >> 2, part = r2 & 3;
+            const int py = pix / 18, px = pix - py * 18;
+            const int iy = ty0 - 5 + py, ix = tx0 - 5 + px;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < 2592 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
+                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.H + iy) * d.W + ix) * d.cur.cs + d.cur.coff +
+                                                      plane * 32 + part * 8);
+            rx[q] = val;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int v = tid + q * 320;
+            const int plane = v / 1296, r2 = v - plane * 1296;
+            if (v < 2592) *reinterpret_cast<u32x4*>(smem + RB_X0 + plane * RB_X0P + (r2 >> 2) * RB_AROW + (r2 & 3) * 16) = rx[q];
+        }
+    }
+    int stage = 0;   // ring stage holding the slab that is consumed next
+    PROBE(1);
+
+    if (producer) {
+        // step q: the barrier publishes slab q (hipcc drains this wave's vmcnt(0) in front of it) and frees
+        // stage (q+1) % 3, which was consumed in step q-2; then slab q+1 is put in flight under the MFMAs of step q
+        for (int q = 0; q < RB_NSLAB; ++q) {
+            __syncthreads();
+            if (q + 1 < RB_NSLAB) rb_issue_slab(d, q + 1, ring + ((q + 1) % RB_NSTAGE) * RB_SLAB, lane);
+        }
+        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();   // conv5 tail barriers
+        return;
+    }
+#define RB_STEP(UNUSED)                                                                       \
+    __syncthreads(); /* slab in `stage` has landed (producer) and all x_k writes are visible */ \
+    const char* slab = ring + stage * RB_SLAB;                                                \
+    stage = stage + 1 == RB_NSTAGE ? 0 : stage + 1;
+#define RB_NEXT(W, WIDE, C, NT) 0
+
+    // ================= conv1: region 16x16 (8 M-tiles: wave w owns tiles w, w+4), K = x (2 chunks) ==========
+    {
+        f32x16 acc[2];
+        RbTile tl[2] = {rb_tile<1>(wave, i), rb_tile<1>(wave + 4, i)};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        { __syncthreads(); PROBE(8); RB_NEXT(w1, false, 1, 0); PROBE(9); const char* slab = ring + stage * RB_SLAB; stage = 1;
+          rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); PROBE(10); }
+        { __syncthreads(); PROBE(11); RB_NEXT(w2, false, 0, 0); PROBE(12); const char* slab = ring + stage * RB_SLAB; stage = 2;
+          rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); PROBE(13); }
+        const float* bias = bias_lds + 0 * 32;
+        rb_store_slice<1>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        rb_store_slice<1>(acc[1], wave + 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+    }
+    PROBE(2);
+    // ================= conv2: region 14x14 (7 M-tiles), K = x (2), x1 =======================================
+    {
+        f32x16 acc[2];
+        RbTile tl[2] = {rb_tile<2>(wave, i), rb_tile<2>(wave + 4 < 7 ? wave + 4 : 6, i)};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        { RB_STEP(RB_NEXT(w2, false, 1, 0)); rb_flush_core<1>(d, smem, n, ty0, tx0, tid);
+          rb_contract<2, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w2, false, 2, 0)); rb_contract<2, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
+        { RB_STEP(RB_NEXT(w3, false, 0, 0)); rb_contract<2, 1, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        const float* bias = bias_lds + 1 * 32;
+        rb_store_slice<2>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        if (wave + 4 < 7) rb_store_slice<2>(acc[1], wave + 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+    }
+    PROBE(3);
+    // ================= conv3: region 12x12 (5 M-tiles: wave 0 owns tiles 0 and 4) ===========================
+    {
+        f32x16 acc[2];
+        RbTile tl[2] = {rb_tile<3>(wave, i), rb_tile<3>(4, i)};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        { RB_STEP(RB_NEXT(w3, false, 1, 0)); rb_flush_core<2>(d, smem, n, ty0, tx0, tid);
+          rb_contract<3, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w3, false, 2, 0)); rb_contract<3, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
+        { RB_STEP(RB_NEXT(w3, false, 3, 0)); rb_contract<3, 1, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w4, false, 0, 0)); rb_contract<3, 2, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        const float* bias = bias_lds + 2 * 32;
+        rb_store_slice<3>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        if (wave == 0) rb_store_slice<3>(acc[1], 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+    }
+    PROBE(4);
+    // ================= conv4: region 10x10 (4 M-tiles, one per wave) ========================================
+    {
+        f32x16 acc[1];
+        RbTile tl[1] = {rb_tile<4>(wave, i)};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        { RB_STEP(RB_NEXT(w4, false, 1, 0)); rb_flush_core<3>(d, smem, n, ty0, tx0, tid);
+          rb_contract<4, 0, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w4, false, 2, 0)); rb_contract<4, 0, 1, 2>(acc, tl, smem, slab, 1, i, g, 0); }
+        { RB_STEP(RB_NEXT(w4, false, 3, 0)); rb_contract<4, 1, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w4, false, 4, 0)); rb_contract<4, 2, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        { RB_STEP(RB_NEXT(w5, true, 0, 0)); rb_contract<4, 3, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        const float* bias = bias_lds + 3 * 32;
+        rb_store_slice<4>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
+    }
+    PROBE(5);
+    // ================= conv5: 8x8 core (2 M-tiles) x 64 channels: wave = (M-tile mt, k-substep kh); the 12 slabs
+    //                   (6 chunks x 2 N-tiles) stream through the same ring; halves are combined through LDS ======
+    {
+        const int mt = wave & 1, kh = wave >> 1;
+        f32x16 acc0[1], acc1[1];                               // N-tile 0 / 1
+        RbTile tl[1] = {rb_tile<5>(mt, i)};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[0][r] = 0.f; acc1[0][r] = 0.f; }
+        // residual of the RRDB tail (third block only): this lane's pixel, 16 channels = four 8-byte loads,
+        // issued now and consumed in the epilogue
+        const int nt = kh;                                     // k-half kh finishes N-tile kh
+        const int q = 32 * mt + i, cy = q >> 3, cx = q & 7;    // this lane's core pixel
+        const int iy = ty0 + cy, ix = tx0 + cx;
+        const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+        bf16x4v r2v[4];
+        if (r2p) {
+            const __bf16* rp = r2p + ((size_t)(n * d.H + min(iy, d.H - 1)) * d.W + min(ix, d.W - 1)) * d.r2.cs + d.r2.coff +
+                               nt * 32 + 4 * g;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const bf16x4v*>(rp + 8 * q4);
+        }
+#define RB_C5(S, PLANE, C, NEXT)                                                                               \
+        { RB_STEP(NEXT); if (S == 0 && PLANE == 0) rb_flush_core<4>(d, smem, n, ty0, tx0, tid);                 \
+          rb_contract<5, S, 1, 1>(acc0, tl, smem, slab, PLANE, i, g, kh); }                                     \
+        { RB_STEP(if ((C) + 1 < 6) RB_NEXT(w5, true, (C) + 1, 0)); rb_contract<5, S, 1, 1>(acc1, tl, smem, slab, PLANE, i, g, kh); }
+        RB_C5(0, 0, 0, RB_NEXT(w5, true, 0, 1))
+        RB_C5(0, 1, 1, RB_NEXT(w5, true, 1, 1))
+        RB_C5(1, 0, 2, RB_NEXT(w5, true, 2, 1))
+        RB_C5(2, 0, 3, RB_NEXT(w5, true, 3, 1))
+        RB_C5(3, 0, 4, RB_NEXT(w5, true, 4, 1))
+        RB_C5(4, 0, 5, RB_NEXT(w5, true, 5, 1))
+#undef RB_C5
+        PROBE(6);
+        __syncthreads();   // ring is free: reduce scratch [2 mt][16][64] floats x 2 + output transpose slabs
+        // k-half kh = 0 finishes N-tile 0, kh = 1 finishes N-tile 1 (each needs the other's partial of its tile)
+        float* mine = reinterpret_cast<float*>(ring) + (mt * 16) * 64 + lane;
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = acc1[0][r];
+        }
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[0][r] += mine[r * 64];
+        }
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = acc0[0][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[0][r] += mine[r * 64];
+        }
+        // out = alpha5*(conv5 + b) + beta1*x (+ beta2*r2)                       (rrdbnet_arch.py:44, :68)
+        {
+            const int p0 = (cy + 5) * 18 + cx + 5;
+            const char* xrow = smem + RB_X0 + nt * RB_X0P + p0 * RB_AROW + g * 8;
+            const float* b5 = bias_lds + 128 + nt * 32;
+            __bf16* slabw = reinterpret_cast<__bf16*>(ring + 2 * 16 * 64 * 4 + wave * 2048);   // [32 px][32 co] bf16
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(b5 + 8 * q4 + 4 * g);
+                const bf16x4v xv = *reinterpret_cast<const bf16x4v*>(xrow + 16 * q4);
+                bf16x4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = kh == 0 ? acc0[0][4 * q4 + e] : acc1[0][4 * q4 + e];
+                    float v = d.alpha5 * (a + bq[e]) + d.beta1 * (float)xv[e];
+                    if (r2p) v += d.beta2 * (float)r2v[q4][e];
+                    o[e] = (__bf16)v;
+                }
+                *reinterpret_cast<bf16x4v*>(slabw + i * 32 + 8 * q4 + 4 * g) = o;
+            }
+            // the wave's 32 px x 64 B tile -> 128 16-byte vectors: 2 per lane
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int v = h * 64 + lane;
+                const int pix = v >> 2, part = v & 3;
+                const int qq = 32 * mt + pix, oy = ty0 + (qq >> 3), ox = tx0 + (qq & 7);
+                const u32x4 val = *reinterpret_cast<const u32x4*>(slabw + pix * 32 + part * 8);
+                if (oy < d.H && ox < d.W) {
+                    __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * d.H + oy) * d.W + ox) * d.out.cs +
+                                  d.out.coff + nt * 32 + part * 8;
+                    *reinterpret_cast<u32x4*>(dst) = val;
+                }
+            }
+        }
+    }
+    PROBE(7);
+#undef RB_STEP
+#undef RB_NEXT
+}
+
+}  // namespace
+
+extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) {
+    if (!dp) return SSR_EINVAL;
+    const ssr_rdb_desc& d = *dp;
+    if (d.dtype != SSR_BF16) return SSR_EUNSUP;
+    if (!d.cur.p || !d.out.p || d.N <= 0 || d.H <= 0 || d.W <= 0) return SSR_EINVAL;
+    if ((d.cur.cs % 8) || (d.cur.coff % 8) || (d.out.cs % 8) || (d.out.coff % 8)) return SSR_EINVAL;
+    for (int k = 0; k < 5; ++k)
+        if (!d.w[k]) return SSR_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rdb_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = d.N * ((d.H + 7) / 8) * ((d.W + 7) / 8);
+    hipLaunchKernelGGL(rdb_fwd_kernel, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -454,14 +455,31 @@ class GeneratorPlan:
         self.feat = self.bufs[0] if n_bufs == n_rdb else z(B, H, W, nf)
         cb.conv(F, "conv_first", view(self.xin), H, W, view(buf(0), 0),
                 y0=hip.NULL_VIEW if n_bufs == n_rdb else view(self.feat))
+        # bf16, nf = 64, gc = 32: one fused launch per dense block (csrc/rdb_fwd.hip); otherwise 5 convs
+        self.fused_rdb = (self.dt == hip.BF16 and nf == 64 and gc == 32 and os.environ.get("SSR_FUSED_RDB", "1") != "0")
+        self._rdb_descs = []
         for r in range(n_rdb):
             i, j = divmod(r, 3)
             p = f"body.{i}.rdb{j + 1}"
             cur = buf(r)
+            dst = view(self.body_out) if r == n_rdb - 1 else view(buf(r + 1), 0)
+            if self.fused_rdb:
+                rd = hip.RdbDesc()
+                rd.dtype, rd.N, rd.H, rd.W = self.dt, B, H, W
+                rd.cur, rd.out = view(cur, 0), dst
+                for k in range(5):
+                    rd.w[k] = store.packed_fwd[f"{p}.conv{k + 1}"].data_ptr()
+                    rd.bias[k] = store.ptr(f"{p}.conv{k + 1}.bias")
+                if j < 2:
+                    rd.alpha5, rd.beta1, rd.r2, rd.beta2 = 0.2, 1.0, hip.NULL_VIEW, 0.0
+                else:
+                    rd.alpha5, rd.beta1, rd.r2, rd.beta2 = 0.04, 0.2, view(buf(r - 2), 0), 1.0
+                self._rdb_descs.append(rd)
+                F.add(hip.lib().ssr_rdb_forward, C.byref(rd), what=f"rdb fwd {p}")
+                continue
             for k in range(1, 5):
                 cb.conv(F, f"{p}.conv{k}", view(cur, 0), H, W, view(cur, nf + (k - 1) * gc), act=hip.ACT_LRELU,
                         cin=nf + (k - 1) * gc)
-            dst = view(self.body_out) if r == n_rdb - 1 else view(buf(r + 1), 0)
             if j < 2:   # x5*0.2 + x                                            (rrdbnet_arch.py:44)
                 cb.conv(F, f"{p}.conv5", view(cur, 0), H, W, dst, alpha=0.2, r1=view(cur, 0), r1_nc=nf, beta1=1.0,
                         cin=cd)

@@ -449,3 +449,36 @@ def test_train_step_bf16_mode_tracks_fp32_oracle():
         worst = max(worst, rel_err(ts.d_store.tensor(k, ts.d_store.grad), g))
     assert worst < 8e-2, worst
     assert rel_err(ts.output(), orc.output) < 3e-2
+
+
+def test_fused_rdb_forward_matches_per_conv_path(monkeypatch):
+    """csrc/rdb_fwd.hip (one launch per dense block, bf16) against the per-conv bf16 path and the fp32 oracle,
+    on a ragged image size (tile edges) and on the BASELINE tile size."""
+    from oracle import esrgan_oracle as O
+    engine, hip = _mods()
+    kw = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32)
+    sd = O.generator_init(seed=4, **kw)
+    for name in list(sd):      # non-zero biases
+        if name.endswith(".bias"):
+            sd[name] = torch.randn_like(sd[name]) * 0.05
+    for (B, H, W) in [(2, 32, 32), (1, 19, 27)]:
+        torch.manual_seed(H)
+        x = torch.rand(B, 3, H, W)
+        outs, bufs = {}, {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SSR_FUSED_RDB", fused)
+            st = engine.ParamStore(engine.generator_specs(**kw), hip.BF16)
+            st.load_state_dict(sd)
+            plan = engine.GeneratorPlan(st, B, H, W, training=True, **kw)
+            assert plan.fused_rdb == (fused == "1")
+            st.pack()
+            plan.load_input(x.cuda())
+            plan.fwd.run()
+            outs[fused] = plan.read_output().cpu()
+            bufs[fused] = [b.float().cpu() for b in plan.bufs]
+        with torch.no_grad():
+            ref = O.generator_forward(sd, x)
+        for r, (a, b) in enumerate(zip(bufs["1"], bufs["0"])):    # every dense buffer (x, x1..x4 of every RDB)
+            assert rel_err(a, b) < 2e-2, ("dense buffer", r, rel_err(a, b))
+        assert rel_err(outs["1"], outs["0"]) < 2e-2
+        assert rel_err(outs["1"], ref) < 3e-2, rel_err(outs["1"], ref)

@@ -96,15 +96,21 @@ int ssr_conv2d_variant(const ssr_conv_desc* d);
 int ssr_conv2d_ck(int32_t dtype, int32_t KH);
 
 /*
- * Fused ResidualDenseBlock forward (rrdbnet_arch.py:37-44, and :68 for the third block of an RRDB), bf16,
- * num_feat 64 / num_grow_ch 32: x (channels [0,64) of `cur`) -> x1..x4 written to channels [64,192) of `cur`
- * and   out[0,64) = alpha5*(conv5(cat(x..x4)) + b5) + beta1*x + beta2*r2.
- * One launch keeps the whole dense block of an 8x8 tile (with its 5-pixel halo) resident in LDS.
- * `w[k]` are the forward-packed weights of conv1..5 (ssr_pack_weights, chunk = 32 channels).
+ * Fused ResidualDenseBlock (rrdbnet_arch.py:37-44, and :68 for the third block of an RRDB), bf16,
+ * num_feat 64 / num_grow_ch 32.  One launch keeps the whole dense block of an 8x8 tile (with its 5-pixel halo)
+ * resident in LDS; only the weights are streamed.
+ *   forward : in = x (64 ch) -> x1..x4 written to channels [64,192) of `slices`,
+ *             out[0,64) = alpha5*(conv5(cat(x..x4)) + b5) + beta1*x + beta2*r2;
+ *             w[k] = forward-packed weights of conv1..5 (ssr_pack_weights, 32-channel chunks), bias[k] their biases.
+ *   backward: in = d_out (64 ch, gradient w.r.t. the block output) -> dpre4..dpre1 (pre-activation gradients of
+ *             conv4..conv1, masked with lrelu'(x_k) read from `mask` = the forward `slices` buffer) written to
+ *             channels [64,192) of `slices`; out[0,64) = d x = gathered dgrad + beta1*d_out + beta2*r2;
+ *             w[j] = gather-packed weights of slice 4-j (ssr_pack_dgrad_gather; conv5's 0.2/0.04 folded in),
+ *             bias = NULL, alpha5 = 1.
  */
 typedef struct ssr_rdb_desc {
     int32_t dtype, N, H, W;
-    ssr_view cur, out;
+    ssr_view in, slices, out, mask;
     const void* w[5];
     const float* bias[5];
     float alpha5, beta1;
@@ -112,6 +118,7 @@ typedef struct ssr_rdb_desc {
     float beta2;
 } ssr_rdb_desc;
 int ssr_rdb_forward(const ssr_rdb_desc* d, void* stream);
+int ssr_rdb_backward(const ssr_rdb_desc* d, void* stream);
 
 /*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at

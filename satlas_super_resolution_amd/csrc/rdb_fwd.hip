@@ -134,27 +134,55 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const RbTile (&t
 // Epilogue of conv K < 5: x_K = lrelu(acc + bias), zero outside the image (one test per lane), packed to bf16 and
 // written to LDS slice K with four 8-byte stores.
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+struct RbPix {            // this lane's pixel of one M-tile of stage K
+    int p;                // linear index in the stage's region (may be >= P for padding lanes)
+    bool inside;          // inside the image (and p < P)
+    size_t gpix;          // clamped global pixel index (n*H + iy)*W + ix
+};
 template <int K>
-__device__ __forceinline__ void rb_store_slice(const f32x16& acc, int mt, const float* bias_lds, char* smem, int ty0,
-                                               int tx0, int H, int W, int i, int g) {
+__device__ __forceinline__ RbPix rb_pix(int mt, int i, int n, int ty0, int tx0, int H, int W) {
     constexpr int R = 18 - 2 * K, P = R * R, HK = 5 - K;
-    const int p = 32 * mt + i;
-    const int oy = p / R, ox = p - oy * R;
+    RbPix t;
+    t.p = 32 * mt + i;
+    const int oy = t.p / R, ox = t.p - oy * R;
     const int iy = ty0 - HK + oy, ix = tx0 - HK + ox;
-    const bool inside = p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;   // zero padding of the NEXT conv's input
-    char* row = smem + rb_slice_base(K) + (p < P ? p : P) * RB_AROW + g * 8;   // P = dummy row
+    t.inside = t.p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    t.gpix = (size_t)(n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
+    return t;
+}
+// forward: x_K = lrelu(acc + bias); backward: dpre = acc * lrelu'(x_k) (mk = the saved forward activation);
+// zero outside the image (zero padding of the NEXT stage's input); four 8-byte LDS stores per lane
+template <int K, bool BWD>
+__device__ __forceinline__ void rb_store_slice(const f32x16& acc, const RbPix& px, const float* bias_lds,
+                                               const bf16x4v (&mk)[4], char* smem, int g) {
+    constexpr int R = 18 - 2 * K, P = R * R;
+    char* row = smem + rb_slice_base(K) + (px.p < P ? px.p : P) * RB_AROW + g * 8;   // P = dummy row
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
         bf16x4v o;
+        if (BWD) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(inside ? lrelu(acc[4 * q4 + e] + bq[e]) : 0.f);
+            for (int e = 0; e < 4; ++e)
+                o[e] = (__bf16)(px.inside ? acc[4 * q4 + e] * lrelu_grad_from_out((float)mk[q4][e]) : 0.f);
+        } else {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(px.inside ? lrelu(acc[4 * q4 + e] + bq[e]) : 0.f);
+        }
         *reinterpret_cast<bf16x4v*>(row + 16 * q4) = o;
     }
 }
+// backward: the 16 channels of x_k (k = 5 - K) of this lane's pixel, from the saved forward buffer
+template <int K>
+__device__ __forceinline__ void rb_load_mask(const ssr_rdb_desc& d, const RbPix& px, int g, bf16x4v (&mk)[4]) {
+    const __bf16* mp = reinterpret_cast<const __bf16*>(d.mask.p) + px.gpix * d.mask.cs + d.mask.coff + 64 +
+                       32 * (5 - K - 1) + 4 * g;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) mk[q4] = *reinterpret_cast<const bf16x4v*>(mp + 8 * q4);
+}
 
 // cooperative write of the 8x8 core of LDS slice K (32 channels) to the dense buffer: one 16-B vector per thread
-template <int K>
+template <int K, bool BWD>
 __device__ __forceinline__ void rb_flush_core(const ssr_rdb_desc& d, const char* smem, int n, int ty0, int tx0,
                                               int tid) {
     constexpr int R = 18 - 2 * K, HK = 5 - K;
@@ -164,13 +192,15 @@ __device__ __forceinline__ void rb_flush_core(const ssr_rdb_desc& d, const char*
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + rb_slice_base(K) + p * RB_AROW + part * 16);
     const int iy = ty0 + cy, ix = tx0 + cx;
     if (iy < d.H && ix < d.W) {
-        __bf16* dst = reinterpret_cast<__bf16*>(d.cur.p) + ((size_t)(n * d.H + iy) * d.W + ix) * d.cur.cs + d.cur.coff +
-                      64 + 32 * (K - 1) + part * 8;
+        constexpr int KD = BWD ? 5 - K : K;      // backward stage K produces dpre_{5-K}
+        __bf16* dst = reinterpret_cast<__bf16*>(d.slices.p) + ((size_t)(n * d.H + iy) * d.W + ix) * d.slices.cs +
+                      d.slices.coff + 64 + 32 * (KD - 1) + part * 8;
         *reinterpret_cast<u32x4*>(dst) = v;
     }
 }
 
-__global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
+template <bool BWD>
+__global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
@@ -180,11 +210,7 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
     const int ty0 = ty_i * 8, tx0 = tx_i * 8;
-    const __bf16* __restrict__ w1 = reinterpret_cast<const __bf16*>(d.w[0]);
-    const __bf16* __restrict__ w2 = reinterpret_cast<const __bf16*>(d.w[1]);
-    const __bf16* __restrict__ w3 = reinterpret_cast<const __bf16*>(d.w[2]);
-    const __bf16* __restrict__ w4 = reinterpret_cast<const __bf16*>(d.w[3]);
-    const __bf16* __restrict__ w5 = reinterpret_cast<const __bf16*>(d.w[4]);
+    const int H = d.H, W = d.W;
     char* ring = smem + RB_RING;
     PROBE(0);
     const bool producer = wave == 4;
@@ -194,10 +220,10 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
         if (tid < 192) bias_lds[tid] = d.bias[k] ? d.bias[k][c] : 0.f;
     }
     if (producer) rb_issue_slab(d, 0, ring, lane);
-    // ---- input halo region x: 18x18 pixels x 64 channels -> X0 (2 planes of 32 channels, padded rows),
+    // ---- 64-channel input halo region (x / d_out): 18x18 pixels -> X0 (2 planes of 32 channels, padded rows),
     //      staged through registers so that the rows can be padded (conflict-free, immediate offsets) ----
     {
-        const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.cur.p);
+        const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.in.p);
         u32x4 rx[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -207,8 +233,8 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
             const int py = pix / 18, px = pix - py * 18;
             const int iy = ty0 - 5 + py, ix = tx0 - 5 + px;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (v < 2592 && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W)
-                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.H + iy) * d.W + ix) * d.cur.cs + d.cur.coff +
+            if (v < 2592 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * H + iy) * W + ix) * d.in.cs + d.in.coff +
                                                       plane * 32 + part * 8);
             rx[q] = val;
         }
@@ -219,9 +245,7 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
             if (v < 2592) *reinterpret_cast<u32x4*>(smem + RB_X0 + plane * RB_X0P + (r2 >> 2) * RB_AROW + (r2 & 3) * 16) = rx[q];
         }
     }
-    int stage = 0;   // ring stage holding the slab that is consumed next
     PROBE(1);
-
     if (producer) {
         // step q: the barrier publishes slab q (hipcc drains this wave's vmcnt(0) in front of it) and frees
         // stage (q+1) % 3, which was consumed in step q-2; then slab q+1 is put in flight under the MFMAs of step q
@@ -229,84 +253,86 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
             __syncthreads();
             if (q + 1 < RB_NSLAB) rb_issue_slab(d, q + 1, ring + ((q + 1) % RB_NSTAGE) * RB_SLAB, lane);
         }
-        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();   // conv5 tail barriers
+        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();   // stage-5 tail barriers
         return;
     }
-#define RB_STEP(UNUSED)                                                                       \
-    __syncthreads(); /* slab in `stage` has landed (producer) and all x_k writes are visible */ \
-    const char* slab = ring + stage * RB_SLAB;                                                \
+    // Consumer barrier: LDS writes complete (lgkmcnt) + s_barrier, but NO vmcnt drain — the MFMA waves have no
+    // LDS-DMA of their own; their global loads (masks, residual) and core stores stay in flight across steps.
+#define RB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int stage = 0;   // ring stage holding the slab that is consumed next
+#define RB_STEP()                                                                 \
+    RB_BAR(); /* slab in `stage` has landed (producer) and all slice writes are visible */ \
+    const char* slab = ring + stage * RB_SLAB;                                    \
     stage = stage + 1 == RB_NSTAGE ? 0 : stage + 1;
-#define RB_NEXT(W, WIDE, C, NT) 0
-
-    // ================= conv1: region 16x16 (8 M-tiles: wave w owns tiles w, w+4), K = x (2 chunks) ==========
+    // chunk c of stage K reads LDS slice S (plane P of the 64-channel input for S = 0):
+    //   forward  : x p0, x p1, x1, ..., x_{K-1}          (rrdbnet_arch.py:39-42 cat order)
+    //   backward : dpre_{6-K} .. dpre_4 (= slices K-1 .. 1), d_out p0, d_out p1   (ParamStore.add_rdb_gather order)
+#define RB_C(K, S, PL, NMT, ACC) { RB_STEP(); rb_contract<K, S, NMT, 2>(ACC, tl, smem, slab, PL, i, g, 0); }
+#define RB_CF(K, S, PL, NMT, ACC) { RB_STEP(); rb_flush_core<K - 1, BWD>(d, smem, n, ty0, tx0, tid); \
+                                    rb_contract<K, S, NMT, 2>(ACC, tl, smem, slab, PL, i, g, 0); }
+    bf16x4v mk0[4], mk1[4];
+    // ================= stage 1: region 16x16 (8 M-tiles: wave w owns tiles w, w+4), K = the 64-ch input =========
     {
         f32x16 acc[2];
         RbTile tl[2] = {rb_tile<1>(wave, i), rb_tile<1>(wave + 4, i)};
+        const RbPix p0 = rb_pix<1>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<1>(wave + 4, i, n, ty0, tx0, H, W);
+        if (BWD) { rb_load_mask<1>(d, p0, g, mk0); rb_load_mask<1>(d, p1, g, mk1); }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        { __syncthreads(); PROBE(8); RB_NEXT(w1, false, 1, 0); PROBE(9); const char* slab = ring + stage * RB_SLAB; stage = 1;
-          rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); PROBE(10); }
-        { __syncthreads(); PROBE(11); RB_NEXT(w2, false, 0, 0); PROBE(12); const char* slab = ring + stage * RB_SLAB; stage = 2;
-          rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); PROBE(13); }
-        const float* bias = bias_lds + 0 * 32;
-        rb_store_slice<1>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
-        rb_store_slice<1>(acc[1], wave + 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        RB_C(1, 0, 0, 2, acc) RB_C(1, 0, 1, 2, acc)
+        rb_store_slice<1, BWD>(acc[0], p0, bias_lds, mk0, smem, g);
+        rb_store_slice<1, BWD>(acc[1], p1, bias_lds, mk1, smem, g);
     }
     PROBE(2);
-    // ================= conv2: region 14x14 (7 M-tiles), K = x (2), x1 =======================================
+    // ================= stage 2: region 14x14 (7 M-tiles) =====================================================
     {
         f32x16 acc[2];
-        RbTile tl[2] = {rb_tile<2>(wave, i), rb_tile<2>(wave + 4 < 7 ? wave + 4 : 6, i)};
+        const int mt1 = wave + 4 < 7 ? wave + 4 : 6;
+        RbTile tl[2] = {rb_tile<2>(wave, i), rb_tile<2>(mt1, i)};
+        const RbPix p0 = rb_pix<2>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<2>(mt1, i, n, ty0, tx0, H, W);
+        if (BWD) { rb_load_mask<2>(d, p0, g, mk0); rb_load_mask<2>(d, p1, g, mk1); }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        { RB_STEP(RB_NEXT(w2, false, 1, 0)); rb_flush_core<1>(d, smem, n, ty0, tx0, tid);
-          rb_contract<2, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w2, false, 2, 0)); rb_contract<2, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
-        { RB_STEP(RB_NEXT(w3, false, 0, 0)); rb_contract<2, 1, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        const float* bias = bias_lds + 1 * 32;
-        rb_store_slice<2>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
-        if (wave + 4 < 7) rb_store_slice<2>(acc[1], wave + 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        if (BWD) { RB_CF(2, 1, 0, 2, acc) RB_C(2, 0, 0, 2, acc) RB_C(2, 0, 1, 2, acc) }
+        else     { RB_CF(2, 0, 0, 2, acc) RB_C(2, 0, 1, 2, acc) RB_C(2, 1, 0, 2, acc) }
+        rb_store_slice<2, BWD>(acc[0], p0, bias_lds + 32, mk0, smem, g);
+        if (wave + 4 < 7) rb_store_slice<2, BWD>(acc[1], p1, bias_lds + 32, mk1, smem, g);
     }
     PROBE(3);
-    // ================= conv3: region 12x12 (5 M-tiles: wave 0 owns tiles 0 and 4) ===========================
+    // ================= stage 3: region 12x12 (5 M-tiles: wave 0 owns tiles 0 and 4) ===========================
     {
         f32x16 acc[2];
         RbTile tl[2] = {rb_tile<3>(wave, i), rb_tile<3>(4, i)};
+        const RbPix p0 = rb_pix<3>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<3>(4, i, n, ty0, tx0, H, W);
+        if (BWD) { rb_load_mask<3>(d, p0, g, mk0); rb_load_mask<3>(d, p1, g, mk1); }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        { RB_STEP(RB_NEXT(w3, false, 1, 0)); rb_flush_core<2>(d, smem, n, ty0, tx0, tid);
-          rb_contract<3, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w3, false, 2, 0)); rb_contract<3, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
-        { RB_STEP(RB_NEXT(w3, false, 3, 0)); rb_contract<3, 1, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w4, false, 0, 0)); rb_contract<3, 2, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        const float* bias = bias_lds + 2 * 32;
-        rb_store_slice<3>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
-        if (wave == 0) rb_store_slice<3>(acc[1], 4, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        if (BWD) { RB_CF(3, 2, 0, 2, acc) RB_C(3, 1, 0, 2, acc) RB_C(3, 0, 0, 2, acc) RB_C(3, 0, 1, 2, acc) }
+        else     { RB_CF(3, 0, 0, 2, acc) RB_C(3, 0, 1, 2, acc) RB_C(3, 1, 0, 2, acc) RB_C(3, 2, 0, 2, acc) }
+        rb_store_slice<3, BWD>(acc[0], p0, bias_lds + 64, mk0, smem, g);
+        if (wave == 0) rb_store_slice<3, BWD>(acc[1], p1, bias_lds + 64, mk1, smem, g);
     }
     PROBE(4);
-    // ================= conv4: region 10x10 (4 M-tiles, one per wave) ========================================
+    // ================= stage 4: region 10x10 (4 M-tiles, one per wave) ========================================
     {
         f32x16 acc[1];
         RbTile tl[1] = {rb_tile<4>(wave, i)};
+        const RbPix p0 = rb_pix<4>(wave, i, n, ty0, tx0, H, W);
+        if (BWD) rb_load_mask<4>(d, p0, g, mk0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        { RB_STEP(RB_NEXT(w4, false, 1, 0)); rb_flush_core<3>(d, smem, n, ty0, tx0, tid);
-          rb_contract<4, 0, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w4, false, 2, 0)); rb_contract<4, 0, 1, 2>(acc, tl, smem, slab, 1, i, g, 0); }
-        { RB_STEP(RB_NEXT(w4, false, 3, 0)); rb_contract<4, 1, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w4, false, 4, 0)); rb_contract<4, 2, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        { RB_STEP(RB_NEXT(w5, true, 0, 0)); rb_contract<4, 3, 1, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        const float* bias = bias_lds + 3 * 32;
-        rb_store_slice<4>(acc[0], wave, bias, smem, ty0, tx0, d.H, d.W, i, g);
+        if (BWD) { RB_CF(4, 3, 0, 1, acc) RB_C(4, 2, 0, 1, acc) RB_C(4, 1, 0, 1, acc) RB_C(4, 0, 0, 1, acc) RB_C(4, 0, 1, 1, acc) }
+        else     { RB_CF(4, 0, 0, 1, acc) RB_C(4, 0, 1, 1, acc) RB_C(4, 1, 0, 1, acc) RB_C(4, 2, 0, 1, acc) RB_C(4, 3, 0, 1, acc) }
+        rb_store_slice<4, BWD>(acc[0], p0, bias_lds + 96, mk0, smem, g);
     }
     PROBE(5);
-    // ================= conv5: 8x8 core (2 M-tiles) x 64 channels: wave = (M-tile mt, k-substep kh); the 12 slabs
+    // ================= stage 5: 8x8 core (2 M-tiles) x 64 channels: wave = (M-tile mt, k-substep kh); the 12 slabs
     //                   (6 chunks x 2 N-tiles) stream through the same ring; halves are combined through LDS ======
     {
         const int mt = wave & 1, kh = wave >> 1;
@@ -314,54 +340,52 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
         RbTile tl[1] = {rb_tile<5>(mt, i)};
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[0][r] = 0.f; acc1[0][r] = 0.f; }
-        // residual of the RRDB tail (third block only): this lane's pixel, 16 channels = four 8-byte loads,
-        // issued now and consumed in the epilogue
+        // residual r2 (x_rrdb / d out_rrdb): this lane's pixel, 16 channels = four 8-byte loads, issued now and
+        // consumed in the epilogue
         const int nt = kh;                                     // k-half kh finishes N-tile kh
         const int q = 32 * mt + i, cy = q >> 3, cx = q & 7;    // this lane's core pixel
         const int iy = ty0 + cy, ix = tx0 + cx;
         const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
         bf16x4v r2v[4];
         if (r2p) {
-            const __bf16* rp = r2p + ((size_t)(n * d.H + min(iy, d.H - 1)) * d.W + min(ix, d.W - 1)) * d.r2.cs + d.r2.coff +
+            const __bf16* rp = r2p + ((size_t)(n * H + min(iy, H - 1)) * W + min(ix, W - 1)) * d.r2.cs + d.r2.coff +
                                nt * 32 + 4 * g;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const bf16x4v*>(rp + 8 * q4);
         }
-#define RB_C5(S, PLANE, C, NEXT)                                                                               \
-        { RB_STEP(NEXT); if (S == 0 && PLANE == 0) rb_flush_core<4>(d, smem, n, ty0, tx0, tid);                 \
-          rb_contract<5, S, 1, 1>(acc0, tl, smem, slab, PLANE, i, g, kh); }                                     \
-        { RB_STEP(if ((C) + 1 < 6) RB_NEXT(w5, true, (C) + 1, 0)); rb_contract<5, S, 1, 1>(acc1, tl, smem, slab, PLANE, i, g, kh); }
-        RB_C5(0, 0, 0, RB_NEXT(w5, true, 0, 1))
-        RB_C5(0, 1, 1, RB_NEXT(w5, true, 1, 1))
-        RB_C5(1, 0, 2, RB_NEXT(w5, true, 2, 1))
-        RB_C5(2, 0, 3, RB_NEXT(w5, true, 3, 1))
-        RB_C5(3, 0, 4, RB_NEXT(w5, true, 4, 1))
-        RB_C5(4, 0, 5, RB_NEXT(w5, true, 5, 1))
+#define RB_C5(S, PLANE, FLUSH)                                                                                  \
+        { RB_STEP(); if (FLUSH) rb_flush_core<4, BWD>(d, smem, n, ty0, tx0, tid);                                \
+          rb_contract<5, S, 1, 1>(acc0, tl, smem, slab, PLANE, i, g, kh); }                                      \
+        { RB_STEP(); rb_contract<5, S, 1, 1>(acc1, tl, smem, slab, PLANE, i, g, kh); }
+        if (BWD) { RB_C5(4, 0, 1) RB_C5(3, 0, 0) RB_C5(2, 0, 0) RB_C5(1, 0, 0) RB_C5(0, 0, 0) RB_C5(0, 1, 0) }
+        else     { RB_C5(0, 0, 1) RB_C5(0, 1, 0) RB_C5(1, 0, 0) RB_C5(2, 0, 0) RB_C5(3, 0, 0) RB_C5(4, 0, 0) }
 #undef RB_C5
         PROBE(6);
-        __syncthreads();   // ring is free: reduce scratch [2 mt][16][64] floats x 2 + output transpose slabs
+        RB_BAR();   // ring is free: reduce scratch [2 mt][16][64] floats + output transpose slabs
         // k-half kh = 0 finishes N-tile 0, kh = 1 finishes N-tile 1 (each needs the other's partial of its tile)
         float* mine = reinterpret_cast<float*>(ring) + (mt * 16) * 64 + lane;
         if (kh == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[r * 64] = acc1[0][r];
         }
-        __syncthreads();
+        RB_BAR();
         if (kh == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[0][r] += mine[r * 64];
         }
-        __syncthreads();
+        RB_BAR();
         if (kh == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[r * 64] = acc0[0][r];
         }
-        __syncthreads();
+        RB_BAR();
         if (kh == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[0][r] += mine[r * 64];
         }
-        // out = alpha5*(conv5 + b) + beta1*x (+ beta2*r2)                       (rrdbnet_arch.py:44, :68)
+        // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
+        // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
+        //                 + beta1*d_out + beta2*d_out_rrdb
         {
             const int p0 = (cy + 5) * 18 + cx + 5;
             const char* xrow = smem + RB_X0 + nt * RB_X0P + p0 * RB_AROW + g * 8;
@@ -388,8 +412,8 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
                 const int pix = v >> 2, part = v & 3;
                 const int qq = 32 * mt + pix, oy = ty0 + (qq >> 3), ox = tx0 + (qq & 7);
                 const u32x4 val = *reinterpret_cast<const u32x4*>(slabw + pix * 32 + part * 8);
-                if (oy < d.H && ox < d.W) {
-                    __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * d.H + oy) * d.W + ox) * d.out.cs +
+                if (oy < H && ox < W) {
+                    __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * H + oy) * W + ox) * d.out.cs +
                                   d.out.coff + nt * 32 + part * 8;
                     *reinterpret_cast<u32x4*>(dst) = val;
                 }
@@ -398,28 +422,37 @@ __global__ __launch_bounds__(320) void rdb_fwd_kernel(const ssr_rdb_desc d) {
     }
     PROBE(7);
 #undef RB_STEP
-#undef RB_NEXT
+#undef RB_C
+#undef RB_CF
+#undef RB_BAR
 }
 
 }  // namespace
 
-extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) {
+static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     if (!dp) return SSR_EINVAL;
     const ssr_rdb_desc& d = *dp;
     if (d.dtype != SSR_BF16) return SSR_EUNSUP;
-    if (!d.cur.p || !d.out.p || d.N <= 0 || d.H <= 0 || d.W <= 0) return SSR_EINVAL;
-    if ((d.cur.cs % 8) || (d.cur.coff % 8) || (d.out.cs % 8) || (d.out.coff % 8)) return SSR_EINVAL;
+    if (!d.in.p || !d.slices.p || !d.out.p || d.N <= 0 || d.H <= 0 || d.W <= 0) return SSR_EINVAL;
+    if ((d.in.cs % 8) || (d.in.coff % 8) || (d.slices.cs % 8) || (d.slices.coff % 8) || (d.out.cs % 8) || (d.out.coff % 8))
+        return SSR_EINVAL;
+    if (bwd && (!d.mask.p || (d.mask.cs % 4) || (d.mask.coff % 4))) return SSR_EINVAL;
+    if (d.r2.p && ((d.r2.cs % 4) || (d.r2.coff % 4))) return SSR_EINVAL;
     for (int k = 0; k < 5; ++k)
         if (!d.w[k]) return SSR_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rdb_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
+    static bool attr_done[2] = {false, false};
+    const void* kern = bwd ? reinterpret_cast<const void*>(rdb_kernel<true>) : reinterpret_cast<const void*>(rdb_kernel<false>);
+    if (!attr_done[bwd]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[bwd] = true;
     }
     const int tiles = d.N * ((d.H + 7) / 8) * ((d.W + 7) / 8);
-    hipLaunchKernelGGL(rdb_fwd_kernel, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    if (bwd) hipLaunchKernelGGL(rdb_kernel<true>, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    else hipLaunchKernelGGL(rdb_kernel<false>, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }
+
+extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, false); }
+extern "C" int ssr_rdb_backward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, true); }

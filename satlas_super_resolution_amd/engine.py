@@ -466,7 +466,7 @@ class GeneratorPlan:
             if self.fused_rdb:
                 rd = hip.RdbDesc()
                 rd.dtype, rd.N, rd.H, rd.W = self.dt, B, H, W
-                rd.cur, rd.out = view(cur, 0), dst
+                rd.inp, rd.slices, rd.out, rd.mask = view(cur, 0), view(cur, 0), dst, hip.NULL_VIEW
                 for k in range(5):
                     rd.w[k] = store.packed_fwd[f"{p}.conv{k + 1}"].data_ptr()
                     rd.bias[k] = store.ptr(f"{p}.conv{k + 1}.bias")
@@ -559,6 +559,19 @@ class GeneratorPlan:
             for k in (4, 3, 2, 1):
                 add_wg(f"{p}.conv{k}", view(cur, 0), view(dcur, nf + (k - 1) * gc), H, W, 1, H, W,
                        cin=nf + (k - 1) * gc)
+            if self.fused_rdb and os.environ.get("SSR_FUSED_RDB_BWD", "1") != "0":
+                # one launch for the whole dense-block backward (csrc/rdb_fwd.hip, rdb_kernel<true>)
+                rd = hip.RdbDesc()
+                rd.dtype, rd.N, rd.H, rd.W = self.dt, B, H, W
+                rd.inp, rd.slices, rd.out, rd.mask = d_out_r, view(dcur, 0), view(dcur, 0), view(cur, 0)
+                for jj in range(5):
+                    rd.w[jj] = store.gather[(p, 4 - jj)].data_ptr()
+                    rd.bias[jj] = None
+                rd.alpha5, rd.beta1 = 1.0, b5
+                rd.r2, rd.beta2 = (d_rrdb, 1.0) if j == 0 else (hip.NULL_VIEW, 0.0)
+                self._rdb_descs.append(rd)
+                Bk.add(hip.lib().ssr_rdb_backward, C.byref(rd), what=f"rdb bwd {p}")
+                continue
             # gather form: slice k <- one conv over [dpre_{k+1} .. dpre_4 | d_out]; every slice is written once,
             # masked by lrelu'(x_k) in the epilogue, so dgrad needs no read-modify-write
             for k in (4, 3, 2, 1):

@@ -51,7 +51,7 @@ class ConvDesc(C.Structure):
 
 class RdbDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("cur", View), ("out", View), ("w", C.c_void_p * 5), ("bias", C.c_void_p * 5),
+                ("inp", View), ("slices", View), ("out", View), ("mask", View), ("w", C.c_void_p * 5), ("bias", C.c_void_p * 5),
                 ("alpha5", C.c_float), ("beta1", C.c_float), ("r2", View), ("beta2", C.c_float)]
 
 
@@ -102,7 +102,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     l.ssr_conv2d_variant.argtypes = [C.POINTER(ConvDesc)]
     l.ssr_conv2d_ck.argtypes = [i32, i32]
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
+    l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     l.ssr_wgrad_tiles.argtypes = [i32, i32, i32]
     l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]

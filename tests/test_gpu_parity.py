@@ -482,3 +482,36 @@ def test_fused_rdb_forward_matches_per_conv_path(monkeypatch):
             assert rel_err(a, b) < 2e-2, ("dense buffer", r, rel_err(a, b))
         assert rel_err(outs["1"], outs["0"]) < 2e-2
         assert rel_err(outs["1"], ref) < 3e-2, rel_err(outs["1"], ref)
+
+
+def test_fused_rdb_backward_matches_per_conv_path(monkeypatch):
+    """rdb_kernel<true> (one launch per dense-block backward, bf16) against the per-conv gather path (bf16) behind
+    the SAME (fused) forward, so that both see identical LeakyReLU masks: every gradient buffer and every
+    parameter gradient; ragged size included."""
+    from oracle import esrgan_oracle as O
+    engine, hip = _mods()
+    kw = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32)
+    sd = O.generator_init(seed=4, **kw)
+    monkeypatch.setenv("SSR_FUSED_RDB", "1")
+    for (B, H, W) in [(2, 32, 32), (1, 19, 27)]:
+        torch.manual_seed(H)
+        x = torch.rand(B, 3, H, W)
+        gout = torch.randn(B, 3, 4 * H, 4 * W)
+        res = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SSR_FUSED_RDB_BWD", fused)
+            st = engine.ParamStore(engine.generator_specs(**kw), hip.BF16)
+            st.load_state_dict(sd)
+            plan = engine.GeneratorPlan(st, B, H, W, training=True, **kw)
+            st.pack()
+            plan.load_input(x.cuda())
+            plan.fwd.run()
+            plan.load_output_grad(gout.cuda())
+            st.grad.zero_()
+            plan.bwd.run()
+            res[fused] = ([b.float().cpu() for b in plan.dbufs], st.grad.clone().cpu())
+        for r, (a, b) in enumerate(zip(res["1"][0], res["0"][0])):
+            for c0, c1 in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 192)):
+                e = rel_err(a[..., c0:c1], b[..., c0:c1])
+                assert e < 3e-2, ("gradient buffer", r, "channels", c0, c1, e, (B, H, W))
+        assert rel_err(res["1"][1], res["0"][1]) < 3e-2

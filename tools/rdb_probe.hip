@@ -14,15 +14,17 @@ int main(int argc, char** argv) {
     const int cin[5] = {64, 96, 128, 160, 192}, cp[5] = {32, 32, 32, 32, 64};
     ssr_rdb_desc d{};
     for (int k = 0; k < 5; ++k) { size_t b = (size_t)cin[k] * 9 * cp[k] * 2; hipMalloc(&w[k], b); hipMemset(w[k], 0x3c, b); d.w[k] = w[k]; }
-    d.dtype = SSR_BF16; d.N = N; d.H = H; d.W = W; d.cur = {cur, CS, 0}; d.out = {out, CS, 0}; d.alpha5 = 0.2f; d.beta1 = 1.f;
+    d.dtype = SSR_BF16; d.N = N; d.H = H; d.W = W; d.in = {cur, CS, 0}; d.slices = {cur, CS, 0}; d.mask = {cur, CS, 0}; d.out = {out, CS, 0}; d.alpha5 = 0.2f; d.beta1 = 1.f;
     const int nblk = N * 16;
     unsigned long long* probe; hipMalloc(&probe, (size_t)nblk * 16 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &probe, sizeof(probe));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) ssr_rdb_forward(&d, 0);
+    const bool bwd = argc > 2;
+    auto run = [&]() { return bwd ? ssr_rdb_backward(&d, 0) : ssr_rdb_forward(&d, 0); };
+    for (int it = 0; it < 3; ++it) run();
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int it = 0; it < 20; ++it) ssr_rdb_forward(&d, 0);
+    for (int it = 0; it < 20; ++it) run();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h((size_t)nblk * 16);

@@ -46,12 +46,26 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="oracle threads (PyTorch CPU does not scale past ~16 on this network at batch 2)")
     return ap.parse_args()
 
 
 def conv_flops(d) -> float:
     """Algorithmic FLOPs of one ssr_conv2d launch: 2 * grid * Cout * taps * Cin_valid."""
     return 2.0 * d.N * d.Gh * d.Gw * d.Cout * d.KH * d.KW * (d.Cin + d.Cin2)
+
+
+WGRAD_FLOPS = {}   # layer-table device pointer -> algorithmic FLOPs of that batched launch
+
+
+def register_wgrad_flops(ts):
+    from satlas_super_resolution_amd import engine
+    import gc
+    for obj in gc.get_objects():
+        if isinstance(obj, engine.WgradBatch) and obj.layer_tab is not None:
+            WGRAD_FLOPS[obj.layer_tab.data_ptr()] = sum(
+                2.0 * L.N * L.Gh * L.Gw * L.Cout * obj.k * obj.k * L.Cin_w for L in obj.layers)
 
 
 def instrumented_step(ts, args):
@@ -71,6 +85,13 @@ def instrumented_step(ts, args):
                 v = lib.ssr_conv2d_variant(C.byref(d))
                 sym = f"conv_kernel<{args.dtype},K{v // 1000},S{(v // 100) % 10},NT{(v // 10) % 10},W{v % 10}>"
                 fl = conv_flops(d)
+            elif name in ("ssr_rdb_forward", "ssr_rdb_backward"):
+                d = a[0]._obj          # five 3x3 convs of one dense block: K = 64..192 -> N = 32,32,32,32,64
+                sym = "rdb_kernel<%s>" % ("true" if name.endswith("backward") else "false")
+                fl = 2.0 * 9 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) * d.N * d.H * d.W
+            elif name == "ssr_conv2d_wgrad":
+                sym = f"wgrad_kernel<{args.dtype},K{a[4]}>"
+                fl = WGRAD_FLOPS.get(a[0], 0.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*a, hip.stream_ptr())
@@ -90,6 +111,7 @@ def instrumented_step(ts, args):
     orig = engine.Launcher.run
     engine.Launcher.run = lambda self: wrap(self)
     use_graph, ts.use_graph = ts.use_graph, False
+    register_wgrad_flops(ts)
     try:
         ts.step()
     finally:
@@ -97,6 +119,7 @@ def instrumented_step(ts, args):
         ts.use_graph = use_graph
     torch.cuda.synchronize()
     agg, per_layer = {}, {}
+
     for sym, fl, e0, e1, what in records:
         secs = e0.elapsed_time(e1) * 1e-3
         a = agg.setdefault(sym, [0, 0.0, 0.0])
@@ -129,6 +152,7 @@ def wgrad_flops(ts):
 def cpu_baseline(args, c_in, c_d):
     from oracle import esrgan_oracle as O
     torch.manual_seed(0)
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     B = args.cpu_batch
     g0 = O.generator_init(num_in_ch=c_in, num_block=args.blocks, seed=0)
     d0 = O.discriminator_init(c_d, 64, seed=1)
@@ -215,7 +239,7 @@ def main():
     }
     if ctx.rank == 0 and not args.no_roofline:
         agg = instrumented_step(ts, args)
-        conv = {k: v for k, v in agg.items() if k.startswith("conv_kernel")}
+        conv = {k: v for k, v in agg.items() if v[2] > 0}      # MFMA kernels (algorithmic FLOPs known)
         dom = max(conv, key=lambda k: conv[k][1])
         n, secs, fl = conv[dom]
         traffic = None

@@ -145,8 +145,8 @@ typedef struct ssr_wgrad_item {
 
 int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
                      int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream);
-/* pixel tiles per image for the wgrad tiling (host helper for building items) */
-int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw);
+/* number of pixel tiles of a layer in the wgrad kernel selected by (dtype, KH): host helper for building items */
+int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH);
 
 /*
  * Weight packing (once per optimizer step; replaces cuDNN's internal filter transforms).

@@ -151,8 +151,9 @@ int dispatch_wgrad(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, i
 int ssr_wgrad_bf16_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW,
                             int S, hipStream_t st);
 
-extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw) {
-    return N * ((Gh + WG_TH - 1) / WG_TH) * ((Gw + WG_TW - 1) / WG_TW);
+extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH) {
+    const int th = dtype == SSR_BF16 ? wgrad_bf16_th(KH) : WG_TH;
+    return N * ((Gh + th - 1) / th) * ((Gw + WG_TW - 1) / WG_TW);
 }
 
 extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,

@@ -30,12 +30,13 @@ __device__ __forceinline__ bf16x8 tr_pair(const __bf16* lo, const __bf16* hi) {
 template <int KH, int KW, int S, bool SPLIT_TAPS>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* __restrict__ layers,
                                                          const ssr_wgrad_item* __restrict__ items) {
-    constexpr int PH = (WG_TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW;
+    constexpr int TH = wgrad_bf16_th(KH);                    // pixel-tile rows: 16 for 3x3, 8 for 4x4
+    constexpr int PH = (TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW;
     constexpr int NTAP = SPLIT_TAPS ? KW : KH * KW;
     constexpr int ROW = 32;                                  // bf16 per pixel row (64 B)
-    constexpr int NDY = WG_TH * WG_TW * 4 / 256;             // 16-B vectors per thread: dY tile
+    constexpr int NDY = TH * WG_TW * 4 / 256;             // 16-B vectors per thread: dY tile
     constexpr int NXV = (PH * PW * 4 + 255) / 256;           //                           X patch
-    constexpr int STAGE = (WG_TH * WG_TW + PH * PW) * ROW;   // bf16 elements per LDS stage
+    constexpr int STAGE = (TH * WG_TW + PH * PW) * ROW;   // bf16 elements per LDS stage
     static_assert(!SPLIT_TAPS || KH == 4, "tap-row split assumes 4 waves = KH");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* lds = reinterpret_cast<__bf16*>(smem);
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
     const ssr_wgrad_layer L = layers[it.layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5;
-    const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + WG_TH - 1) / WG_TH;
+    const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
     const int upshift = L.up == 2 ? 1 : 0;
     const int LH = L.Hi << upshift, LW = L.Wi << upshift;
     const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(L.x.p);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
         const int tx_i = b % tiles_x; b /= tiles_x;
         const int ty_i = b % tiles_y;
         const int n = b / tiles_y;
-        const int gy0 = ty_i * WG_TH, gx0 = tx_i * WG_TW;
+        const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
 #pragma unroll
         for (int q = 0; q < NDY; ++q) {
             const int v = tid + q * 256;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
     };
     auto store_tile = [&](int stage) {
         __bf16* ldy = lds + stage * STAGE;
-        __bf16* lx = ldy + WG_TH * WG_TW * ROW;
+        __bf16* lx = ldy + TH * WG_TW * ROW;
 #pragma unroll
         for (int q = 0; q < NDY; ++q) *reinterpret_cast<u32x4*>(ldy + (tid + q * 256) * 8) = rdy[q];
 #pragma unroll
@@ -123,11 +124,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
         const bool has_next = tile + 1 < it.tile_end;
         if (has_next) load_tile(tile + 1);
         const __bf16* ldy = lds + stage * STAGE;
-        const __bf16* lx = ldy + WG_TH * WG_TW * ROW;
-        constexpr int NROW = SPLIT_TAPS ? WG_TH : 2;          // tile rows (16-pixel k-steps) per wave
+        const __bf16* lx = ldy + TH * WG_TW * ROW;
+        constexpr int NROW = SPLIT_TAPS ? TH : TH / 4;        // tile rows (16-pixel k-steps) per wave
 #pragma unroll
         for (int s = 0; s < NROW; ++s) {
-            const int ty = SPLIT_TAPS ? s : 2 * wave + s;
+            const int ty = SPLIT_TAPS ? s : NROW * wave + s;
             const __bf16* ap = ldy + (ty * WG_TW + src_px) * ROW + src_ch;
             const bf16x8 a = tr_pair(ap, ap + 4 * ROW);
             if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
@@ -149,8 +150,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
 
 template <int KH, int KW, int S, bool SPLIT>
 int launch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {
-    constexpr int PH = (WG_TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW;
-    constexpr size_t stage_bytes = (size_t)(WG_TH * WG_TW + PH * PW) * 32 * 2;
+    constexpr int TH = wgrad_bf16_th(KH);
+    constexpr int PH = (TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW;
+    constexpr size_t stage_bytes = (size_t)(TH * WG_TW + PH * PW) * 32 * 2;
     constexpr size_t lds = 2 * stage_bytes > 4 * 16 * 64 * 4 ? 2 * stage_bytes : 4 * 16 * 64 * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = wgrad_bf16_kernel<KH, KW, S, SPLIT>;

@@ -10,7 +10,9 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     }
 }
 
-constexpr int WG_TH = 8, WG_TW = 16;   // pixel tile of one wgrad step
+constexpr int WG_TH = 8, WG_TW = 16;   // pixel tile of one wgrad step (fp32 kernels)
+// bf16 kernels: 16 rows for 3x3 layers (4 k-steps per wave per barrier), 8 for the 4x4 stride-2 layers (LDS)
+constexpr int wgrad_bf16_th(int KH) { return KH == 3 ? 8 : 8; }   // 16 rows measured slower for 3x3 (r01: 1.81 -> 2.23 ms)
 
 // Write the per-wave accumulators D[row = co][col = ci] (32x32 MFMA C layout) of all taps to
 // dW[co][ci][ky][kx] (fp32, OIHW).  3x3: the 4 waves hold partial sums over different pixels -> reduce

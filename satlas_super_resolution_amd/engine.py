@@ -350,7 +350,7 @@ def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View,
 class WgradBatch:
     """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride)."""
 
-    MAX_TILES_PER_ITEM = 128
+    MAX_TILES_PER_ITEM = {3: 128, 4: 64}   # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits
 
     def __init__(self, dtype: int, k: int, stride: int):
         self.dtype, self.k, self.stride = dtype, k, stride
@@ -361,8 +361,8 @@ class WgradBatch:
     def add(self, x: View, dy: View, N, hi, wi, up, cin, cout, gh, gw, alpha, dw_ptr, cin_w, db_ptr):
         li = len(self.layers)
         self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, dw_ptr, cin_w, db_ptr))
-        tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw)
-        splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM))
+        tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.dtype, self.k)
+        splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
         per = -(-tiles // splits)
         for co0 in range(0, cout, 32):
             for ci0 in range(0, cin_w, 32):

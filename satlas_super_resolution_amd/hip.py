@@ -132,7 +132,7 @@ def lib() -> C.CDLL:
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    l.ssr_wgrad_tiles.argtypes = [i32, i32, i32]
+    l.ssr_wgrad_tiles.argtypes = [i32, i32, i32, i32, i32]
     l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]
     l.ssr_pack_dgrad_gather.argtypes = [vp, i32, i32, vp]
     l.ssr_add_views.argtypes = [View, View, i32, i64, i32, vp]

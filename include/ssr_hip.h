@@ -88,6 +88,10 @@ typedef struct ssr_conv_desc {
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
+/* test / tuning hook: force a kernel family. 0 = automatic (ssr_conv2d), 1 = weight-stationary persistent
+ * kernel (SSR_EUNSUP if the descriptor does not fit it), 2 = skip it (K-resident or pipelined kernel),
+ * 3 = pipelined kernel only. */
+int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
 /* Which kernel instantiation ssr_conv2d dispatches this descriptor to, encoded as
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
  * used by bench.py to attribute launch durations to kernel symbols.  Negative on error. */

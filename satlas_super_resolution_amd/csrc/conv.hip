@@ -285,9 +285,13 @@ bool view_ok(const ssr_view& v, bool required) {
 // K-resident LDS-DMA kernel for the small generator-body layers (conv_res.hip)
 bool ssr_conv_res_try(const ssr_conv_desc& d, hipStream_t st, int* rc);
 bool ssr_conv_res_qualifies(const ssr_conv_desc& d);
+// weight-stationary persistent kernel for the large-spatial layers (conv_ws.hip)
+bool ssr_conv_ws_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
+bool ssr_conv_ws_qualifies(const ssr_conv_desc& d);
 
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
+    if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
     if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
     bool nt2, small;
     pick_tile(*dp, nt2, small);
@@ -299,7 +303,7 @@ extern "C" int ssr_conv2d_ck(int32_t dtype, int32_t KH) {
     return (KH == 4 ? 1 : 2) * 2 * vec;
 }
 
-extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) {
+static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     if (!dp) return SSR_EINVAL;
     const ssr_conv_desc& d = *dp;
     if (!view_ok(d.x, true) || !d.w || ((uintptr_t)d.w % 16) != 0) return SSR_EINVAL;
@@ -311,8 +315,15 @@ extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) {
     if (!d.x2.p && d.Cin2 != 0) return SSR_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = 0;
-    if (ssr_conv_res_try(d, st, &rc)) return rc;
+    if (impl == 1) return ssr_conv_ws_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+    if (impl == 0 && ssr_conv_ws_try(d, st, &rc, false)) return rc;
+    if (impl != 3 && ssr_conv_res_try(d, st, &rc)) return rc;
     if (d.dtype == SSR_F32) return dispatch_geom<float>(d, st);
     if (d.dtype == SSR_BF16) return dispatch_geom<__bf16>(d, st);
     return SSR_EUNSUP;
+}
+
+extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) { return conv2d_impl(dp, stream, 0); }
+extern "C" int ssr_conv2d_impl(const ssr_conv_desc* dp, void* stream, int32_t impl) {
+    return conv2d_impl(dp, stream, impl);
 }

@@ -1,0 +1,312 @@
+// Weight-stationary persistent 3x3 convolution for the large-spatial layers (bf16, Cin <= 64).
+//
+// The U-Net discriminator's and the generator tail's 3x3 layers at 128x128 / 64x64 have a huge pixel
+// count (B*16384) but tiny weights (<= 64x64x9).  In the generic kernel (conv.hip) every 128-pixel
+// workgroup re-stages the weight slab through LDS, runs 18..36 MFMAs per wave and pays a full
+// prologue + split-K reduce + epilogue: rocprofv3 shows 250..560 TFLOP/s (10..22 % of peak), one
+// workgroup per CU.  Here the weights never touch LDS:
+//   * a workgroup (4 waves) owns ONE 32-channel output tile and keeps its whole [9 taps][Cin][32] weight
+//     slice in REGISTERS (36 x 16-byte MFMA A-fragments per lane for Cin = 64) for its entire lifetime;
+//   * it is persistent: it walks 8x16-pixel tiles with stride gridDim.x; per tile only the input halo
+//     patch moves (global -> registers -> padded LDS rows, double buffered, ONE barrier per tile);
+//   * MFMA operands are swapped (A = weights, B = pixels) so each lane ends with 16 consecutive-ish
+//     channels of ONE pixel: bias / LeakyReLU / residual / mask / store are 8-byte vector ops, no
+//     transpose and no split-K reduce;
+//   * 2 workgroups per CU (57 KB LDS, <= 256 VGPRs): one runs MFMAs while the other is in its epilogue.
+// Same descriptor and epilogue contract as conv.hip (ssr_conv_desc).
+//
+// Replaces nn.Conv2d 3x3 (and its dgrad) at /root/reference/ssr/archs/discriminator_arch.py:28,38-40,44,67-69
+// and rrdbnet_arch.py:104,111-112,128,136 (conv0, conv7, conv8, conv9; conv_up2, conv_hr, conv_last).
+#include "common.h"
+#include <cstdlib>
+
+#ifdef SSR_PROBE
+#define WPROBE(k) do { if (threadIdx.x == 0 && tile == (int)blockIdx.x + (int)gridDim.x) g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WPROBE(k)
+#endif
+
+namespace {
+
+constexpr int WS_TH = 8, WS_TW = 16, WS_PH = WS_TH + 2, WS_PW = WS_TW + 2, WS_PIX = WS_PH * WS_PW;   // 180
+constexpr int WS_AROW = 80;                                   // bytes per patch row: 32 bf16 + 16 pad
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+
+#define WS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int NPL, int NT>   // 32-channel input planes (Cin <= 32*NPL), 32-channel output tiles per workgroup
+__global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(const ssr_conv_desc d) {
+    constexpr int PLANE = WS_PIX * WS_AROW;                   // 14,400 B
+    constexpr int BUF = NPL * PLANE;
+    constexpr int NV = NPL * WS_PIX * 4;                      // 16-B vectors per patch
+    constexpr int NPV = (NV + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BUF
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int co0 = blockIdx.y * 32 * NT;
+    const int tiles_x = (d.Gw + WS_TW - 1) / WS_TW, tiles_y = (d.Gh + WS_TH - 1) / WS_TH;
+    const int ntiles = d.N * tiles_y * tiles_x;
+    const int upshift = d.up == 2 ? 1 : 0;
+    const int LH = d.Hi << upshift, LW = d.Wi << upshift;
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
+
+    // ---- the stationary operand: [tap][plane][kk] 16-byte fragments of W[co0 + i][.] in registers ----
+    u32x4 wf[NT][9 * NPL * 2];
+    {
+        const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        wf[t][(tap * NPL + pl) * 2 + kk] = *reinterpret_cast<const u32x4*>(
+                            wg + ((size_t)(pl * 9 + tap) * d.CoutPad + co0 + t * 32 + i) * 32 + kk * 16 + g * 8);
+    }
+    const int co_l = 4 * g;                                   // + 8*q4 + e: this lane's 16 output channels
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * BUF);   // [32*NT] behind the two patch buffers
+    if (tid < 32 * NT) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
+
+    u32x4 rp[NPV];
+    auto load_patch = [&](int tile) {
+        int b = tile;
+        const int tx_i = b % tiles_x; b /= tiles_x;
+        const int ty_i = b % tiles_y;
+        const int n = b / tiles_y;
+        const int gy0 = ty_i * WS_TH, gx0 = tx_i * WS_TW;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            // consecutive lanes read consecutive 16-B parts of one pixel (all planes) and then the next pixel:
+            // a 64-channel NHWC row is one 128-B line, 8 lanes each -> a wave instruction touches 8 full lines
+            const int v = tid + q * 256;
+            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
+            const int pl = pp8 >> 2, part = pp8 & 3;
+            const int py = pix / WS_PW, px = pix - py * WS_PW;
+            const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+            const int c = pl * 32 + part * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < NV && ly >= 0 && ly < LH && lx >= 0 && lx < LW && c < d.Cin)
+                val = *reinterpret_cast<const u32x4*>(
+                    xg + ((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + c);
+            rp[q] = val;
+        }
+    };
+    auto store_patch = [&](int buf) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            const int v = tid + q * 256;
+            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
+            if (v < NV) *reinterpret_cast<u32x4*>(base + (pp8 >> 2) * PLANE + pix * WS_AROW + (pp8 & 3) * 16) = rp[q];
+        }
+    };
+
+    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
+    __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
+    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
+    const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
+    const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
+    const int a_off = ((2 * wave + (i >> 4)) * WS_PW + (i & 15)) * WS_AROW + g * 16;   // this lane's pixel
+    __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * 32 * NT);   // [32 px][32*NT co]
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        load_patch(tile);
+        store_patch(0);
+    }
+    WS_BAR();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        WPROBE(0);
+        const int next = tile + gridDim.x;
+#ifndef WS_NO_LOAD
+        if (next < ntiles) load_patch(next);
+#endif
+        WPROBE(1);
+        // ---- this lane's output pixel and its epilogue operands (in flight under the MFMAs) ----
+        int b = tile;
+        const int tx_i = b % tiles_x; b /= tiles_x;
+        const int ty_i = b % tiles_y;
+        const int n = b / tiles_y;
+        const int gy = ty_i * WS_TH + 2 * wave + (i >> 4), gx = tx_i * WS_TW + (i & 15);
+        const bool pvalid = gy < d.Gh && gx < d.Gw;
+        const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
+        const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
+        // ---- 9 taps x NPL planes x 2 k-substeps ----
+        WPROBE(2);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const char* ab = smem + buf * BUF + a_off;
+        // explicit software pipeline: the pixel fragment of step n + PF is read before the MFMAs of step n
+        constexpr int NSTEP = 18 * NPL, PF = 3;
+        u32x4 pxr[PF + 1];
+        auto px_addr = [&](int n) {   // step n = ((pl*3 + ky)*3 + kx)*2 + kk
+            const int kk = n & 1, tap = (n >> 1) % 9, pl = (n >> 1) / 9;
+            return ab + pl * PLANE + ((tap / 3) * WS_PW + (tap % 3)) * WS_AROW + kk * 32;
+        };
+#pragma unroll
+        for (int n = 0; n < NSTEP + PF; ++n) {
+            if (n < NSTEP) pxr[n % (PF + 1)] = *reinterpret_cast<const u32x4*>(px_addr(n));
+            if (n >= PF) {
+                const int m = n - PF, kk = m & 1, tap = (m >> 1) % 9, pl = (m >> 1) / 9;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#ifdef WS_ASM_AGPR
+                    // weights of the second output tile live in the accumulator half of the unified register file;
+                    // the MFMA reads them there directly (hipcc would copy them to VGPRs first)
+                    if (t == 1)
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+                                     : "+a"(acc[t]) : "a"(wf[t][(tap * NPL + pl) * 2 + kk]), "v"(pxr[m % (PF + 1)]));
+                    else
+#endif
+                    mma16<__bf16>(acc[t], wf[t][(tap * NPL + pl) * 2 + kk], pxr[m % (PF + 1)]);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < PF; ++n) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int n = 0; n < NSTEP; ++n) {
+            if (n + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        }
+        // ---- epilogue: this lane = one pixel x 16 channels (rows 8*q4 + 4*g + e of the C fragment); its
+        //      operands are loaded here, after the MFMA loop, to stay inside the 256-register budget (the
+        //      second workgroup on the CU covers the latency) ----
+        WPROBE(3);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bf16x4w q1[4], q2[4], qa[4], qm[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = co0 + t * 32 + 8 * q4 + co_l;
+                const int cc = c < d.Cout ? c : 0;                // clamped: always addressable
+                if (r1p) q1[q4] = *reinterpret_cast<const bf16x4w*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                if (r2p) q2[q4] = *reinterpret_cast<const bf16x4w*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
+                if (d.accumulate) qa[q4] = *reinterpret_cast<const bf16x4w*>(yp + pp * d.y.cs + d.y.coff + cc);
+                if (mp) qm[q4] = *reinterpret_cast<const bf16x4w*>(mp + pp * d.m.cs + d.m.coff + cc);
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = co0 + t * 32 + 8 * q4 + co_l;
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
+                bf16x4w o0, o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[t][4 * q4 + e] + bq[e];
+                    if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+                    v *= d.alpha;
+                    o0[e] = (__bf16)v;
+                    if (r1p) v += d.beta1 * (float)q1[q4][e];
+                    if (r2p) v += d.beta2 * (float)q2[q4][e];
+                    if (d.accumulate) v += (float)qa[q4][e];
+                    o1[e] = (__bf16)v;
+                    if (mp) v *= lrelu_grad_from_out((float)qm[q4][e]);
+                    o2[e] = (__bf16)v;
+                }
+                if (pvalid && c < d.Cout) {
+                    if (y0p) *reinterpret_cast<bf16x4w*>(y0p + pp * d.y0.cs + d.y0.coff + c) = o0;
+                    if (y1p) *reinterpret_cast<bf16x4w*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
+                }
+                // final output: transposed through the wave's slab so that a store instruction writes whole lines
+                *reinterpret_cast<bf16x4w*>(slab + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o2;
+            }
+        }
+        {
+            constexpr int PARTS = 4 * NT;                         // 16-B parts per pixel row of the tile
+#pragma unroll
+            for (int h = 0; h < 32 * PARTS / 64; ++h) {
+                const int v = h * 64 + lane;
+                const int pix = v / PARTS, part = v - pix * PARTS;
+                const int oy = ty_i * WS_TH + 2 * wave + (pix >> 4), ox = tx_i * WS_TW + (pix & 15);
+                const int c = co0 + part * 8;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(slab + pix * (32 * NT) + part * 8);
+#ifdef WS_NO_STORE
+                if (val[0] == 0x12345678u)
+#else
+                if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+#endif
+                    *reinterpret_cast<u32x4*>(yp + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * d.y.cs +
+                                              d.y.coff + c) = val;
+            }
+        }
+        WPROBE(4);
+        if (next < ntiles) store_patch(buf ^ 1);
+        WPROBE(5);
+        WS_BAR();
+        WPROBE(6);   // next patch visible; everyone is done reading the current one
+        buf ^= 1;
+    }
+}
+
+template <int NPL, int NT>
+int launch_ws(const ssr_conv_desc& d, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + 4 * 32 * 32 * NT * 2;
+    auto kern = conv_ws_kernel<NPL, NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int ntiles = d.N * ((d.Gh + WS_TH - 1) / WS_TH) * ((d.Gw + WS_TW - 1) / WS_TW);
+    const int ny = d.CoutPad / (32 * NT);
+    int gx = (NPL * NT > 2 ? 256 : 512) / ny;   // 1 or 2 workgroups per CU x 256 CUs, shared among the output tiles
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3(gx, ny, 1), dim3(256), lds, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+}  // namespace
+
+// 3x3 stride 1 bf16, Cin <= 64, large grid, single input, full-range residual / mask channel windows
+bool ssr_conv_ws_shape_ok(const ssr_conv_desc& d);
+bool ssr_conv_ws_qualifies(const ssr_conv_desc& d) {
+    static const bool off = [] { const char* e = getenv("SSR_CONV_WS"); return e && e[0] == '0'; }();
+    if (off || d.dtype != SSR_BF16) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p) return false;
+    if (d.Cin > 64 || (d.Cout % 8) != 0) return false;
+    if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
+    const long ntiles = (long)d.N * ((d.Gh + WS_TH - 1) / WS_TH) * ((d.Gw + WS_TW - 1) / WS_TW);
+    if (ntiles * (d.CoutPad / 32) < 2048) return false;                 // small grids: resident / fused kernels
+    // r01 measurements: with Cin <= 32 this kernel beats the pipelined one by 1.3-3x (conv0, conv9/conv_last dgrad);
+    // the 64-channel variant (one wave per SIMD, 288 weight registers) only ties it (epilogue instruction count),
+    // so it is opt-in (SSR_CONV_WS=2) until its epilogue is slimmed down
+    static const bool wide = [] { const char* e = getenv("SSR_CONV_WS"); return e && e[0] == '2'; }();
+    if (d.Cin > 32 && !wide) return false;
+    return ssr_conv_ws_shape_ok(d);
+}
+
+// everything except the grid-size heuristic (ssr_conv2d_impl can force this kernel on small shapes)
+bool ssr_conv_ws_shape_ok(const ssr_conv_desc& d) {
+    if (d.dtype != SSR_BF16) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p) return false;
+    if (d.Cin > 64 || (d.Cout % 8) != 0) return false;
+    if (d.Cin > 32 && (d.CoutPad % 64) != 0) return false;
+    if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
+    if (d.r1.p && d.r1_nc < d.Cout) return false;
+    if (d.r2.p && d.r2_nc < d.Cout) return false;
+    if (d.m.p && !(d.m_c0 == 0 && d.m_c1 >= d.Cout)) return false;
+    auto al = [](const ssr_view& v) { return !v.p || ((v.cs % 4) == 0 && (v.coff % 4) == 0 && ((uintptr_t)v.p % 8) == 0); };
+    return al(d.y) && al(d.y0) && al(d.y1) && al(d.r1) && al(d.r2) && al(d.m);
+}
+
+bool ssr_conv_ws_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
+    if (force ? !ssr_conv_ws_shape_ok(d) : !ssr_conv_ws_qualifies(d)) return false;
+    // Cin <= 32: 32-channel output tiles, 2 workgroups per CU; Cin <= 64: 64-channel tiles held by one wave per SIMD
+    // (288 weight registers) when the padded output width allows it
+    if (d.Cin <= 32) *rc = launch_ws<1, 1>(d, st);
+    else if (d.CoutPad % 64 == 0) *rc = launch_ws<2, 2>(d, st);
+    else return false;
+    return true;
+}

@@ -515,3 +515,37 @@ def test_fused_rdb_backward_matches_per_conv_path(monkeypatch):
                 e = rel_err(a[..., c0:c1], b[..., c0:c1])
                 assert e < 3e-2, ("gradient buffer", r, "channels", c0, c1, e, (B, H, W))
         assert rel_err(res["1"][1], res["0"][1]) < 3e-2
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B,up", [(64, 64, 16, 32, 2, 1), (8, 64, 9, 21, 1, 1), (32, 8, 16, 16, 1, 1),
+                                              (64, 128, 8, 16, 1, 1), (24, 32, 5, 7, 2, 2)])
+def test_weight_stationary_conv_matches_pipelined_kernel(cin, cout, H, W, B, up):
+    """csrc/conv_ws.hip forced through ssr_conv2d_impl(impl=1) against the pipelined kernel (impl=3) on the same
+    descriptor, with the whole epilogue contract switched on: bias, LeakyReLU, alpha, both residuals, dual
+    outputs, in-place accumulate, LReLU-backward mask, nearest x2 read."""
+    import ctypes as C
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cin + cout + H)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    Ho, Wo = H * up, W * up
+    mk = lambda h, w, c: (torch.randn(B, h, w, c, device="cuda") * 0.5).to(tdt).contiguous()
+    xb, r1, r2, m = mk(H, W, cin), mk(Ho, Wo, cout), mk(Ho, Wo, cout), mk(Ho, Wo, cout)
+    y_init = mk(Ho, Wo, cout)
+    outs = {}
+    for impl in (1, 3):
+        y, y0, y1 = y_init.clone(), torch.zeros_like(y_init), torch.zeros_like(y_init)
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), up=up, act=hip.ACT_LRELU, alpha=0.7, y0=hip.view(y0),
+                    r1=hip.view(r1), r1_nc=cout, beta1=0.5, r2=hip.view(r2), r2_nc=cout, beta2=-0.25, cin=cin)
+        d.y1 = hip.view(y1)
+        d.accumulate = 1
+        d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+        torch.cuda.synchronize()
+        outs[impl] = (y.float().cpu(), y0.float().cpu(), y1.float().cpu())
+    for a, b, nm in zip(outs[1], outs[3], ("y", "y0", "y1")):
+        assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))

@@ -34,7 +34,17 @@ typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 
 #define WS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int NPL, int NT>   // 32-channel input planes (Cin <= 32*NPL), 32-channel output tiles per workgroup
+// Epilogue variants.  The epilogue is VALU / issue bound (tools/ws_probe.hip: with every feature a run-time
+// flag it cost 6100 of the 12400 cycles of a 64->64 tile, ~800 instructions of selects and branches), so the
+// feature set is a template parameter: WS_GENERIC keeps the full ssr_conv_desc contract, the others are
+// branch-free straight-line code for the combinations the ESRGAN step actually launches.
+constexpr int WS_LRELU = 1, WS_MASK = 2, WS_R1 = 4, WS_ACC = 8, WS_GENERIC = -1;
+
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NPL, int NT, int EP>   // 32-channel input planes (Cin <= 32*NPL), 32-channel output tiles per workgroup
 __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(const ssr_conv_desc d) {
     constexpr int PLANE = WS_PIX * WS_AROW;                   // 14,400 B
     constexpr int BUF = NPL * PLANE;
@@ -70,38 +80,46 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * BUF);   // [32*NT] behind the two patch buffers
     if (tid < 32 * NT) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
 
+    // ---- patch staging: everything that does not depend on the tile is computed once ----
+    // vector v = tid + 256 q of the patch: consecutive lanes read consecutive 16-B parts of one pixel (all planes)
+    // and then the next pixel: a 64-channel NHWC row is one 128-B line -> a wave instruction touches 8 full lines
+    int p_rel[NPV], p_yx[NPV], p_lds[NPV];
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) {
+        const int v = tid + q * 256;
+        const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
+        const int pl = pp8 >> 2, part = pp8 & 3;
+        const int py = pix / WS_PW, px = pix - py * WS_PW;
+        const int c = pl * 32 + part * 8;
+        const bool ok = v < NV && c < d.Cin;
+        p_rel[q] = ((((py - 1) >> upshift) * d.Wi + ((px - 1) >> upshift)) * d.x.cs + c);
+        p_yx[q] = ok ? ((py - 1) & 0xffff) | ((px - 1) << 16) : 0x7fff7fff;   // never inside
+        p_lds[q] = pl * PLANE + pix * WS_AROW + part * 16;
+    }
     u32x4 rp[NPV];
-    auto load_patch = [&](int tile) {
-        int b = tile;
-        const int tx_i = b % tiles_x; b /= tiles_x;
-        const int ty_i = b % tiles_y;
-        const int n = b / tiles_y;
-        const int gy0 = ty_i * WS_TH, gx0 = tx_i * WS_TW;
+    auto load_patch = [&](int n, int gy0, int gx0) {
+        const __bf16* base = xg + ((size_t)(n * d.Hi + (gy0 >> upshift)) * d.Wi + (gx0 >> upshift)) * d.x.cs + d.x.coff;
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
-            // consecutive lanes read consecutive 16-B parts of one pixel (all planes) and then the next pixel:
-            // a 64-channel NHWC row is one 128-B line, 8 lanes each -> a wave instruction touches 8 full lines
-            const int v = tid + q * 256;
-            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
-            const int pl = pp8 >> 2, part = pp8 & 3;
-            const int py = pix / WS_PW, px = pix - py * WS_PW;
-            const int ly = gy0 + py - 1, lx = gx0 + px - 1;
-            const int c = pl * 32 + part * 8;
+            const int ly = gy0 + (int)(short)(p_yx[q] & 0xffff), lx = gx0 + (p_yx[q] >> 16);
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (v < NV && ly >= 0 && ly < LH && lx >= 0 && lx < LW && c < d.Cin)
-                val = *reinterpret_cast<const u32x4*>(
-                    xg + ((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + c);
+            if ((unsigned)ly < (unsigned)LH && (unsigned)lx < (unsigned)LW)
+                val = *reinterpret_cast<const u32x4*>(base + p_rel[q]);
             rp[q] = val;
         }
     };
     auto store_patch = [&](int buf) {
         char* base = smem + buf * BUF;
 #pragma unroll
-        for (int q = 0; q < NPV; ++q) {
-            const int v = tid + q * 256;
-            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
-            if (v < NV) *reinterpret_cast<u32x4*>(base + (pp8 >> 2) * PLANE + pix * WS_AROW + (pp8 & 3) * 16) = rp[q];
-        }
+        for (int q = 0; q < NPV; ++q)
+            if (tid + q * 256 < NV) *reinterpret_cast<u32x4*>(base + p_lds[q]) = rp[q];
+    };
+    auto decode = [&](int tile, int& n, int& gy0, int& gx0) {
+        int b = tile;
+        const int tx_i = b % tiles_x; b /= tiles_x;
+        const int ty_i = b % tiles_y;
+        n = b / tiles_y;
+        gy0 = ty_i * WS_TH; gx0 = tx_i * WS_TW;
     };
 
     __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
@@ -114,8 +132,10 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * 32 * NT);   // [32 px][32*NT co]
 
     int tile = blockIdx.x;
+    int n, gy0, gx0;
     if (tile < ntiles) {
-        load_patch(tile);
+        decode(tile, n, gy0, gx0);
+        load_patch(n, gy0, gx0);
         store_patch(0);
     }
     WS_BAR();
@@ -123,75 +143,116 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     for (; tile < ntiles; tile += gridDim.x) {
         WPROBE(0);
         const int next = tile + gridDim.x;
+        int n_n = 0, gy0_n = 0, gx0_n = 0;
 #ifndef WS_NO_LOAD
-        if (next < ntiles) load_patch(next);
+        if (next < ntiles) {
+            decode(next, n_n, gy0_n, gx0_n);
+            load_patch(n_n, gy0_n, gx0_n);
+        }
 #endif
         WPROBE(1);
-        // ---- this lane's output pixel and its epilogue operands (in flight under the MFMAs) ----
-        int b = tile;
-        const int tx_i = b % tiles_x; b /= tiles_x;
-        const int ty_i = b % tiles_y;
-        const int n = b / tiles_y;
-        const int gy = ty_i * WS_TH + 2 * wave + (i >> 4), gx = tx_i * WS_TW + (i & 15);
+        // ---- this lane's output pixel ----
+        const int gy = gy0 + 2 * wave + (i >> 4), gx = gx0 + (i & 15);
         const bool pvalid = gy < d.Gh && gx < d.Gw;
         const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
         const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
-        // ---- 9 taps x NPL planes x 2 k-substeps ----
+        // lean variants: the epilogue operands of this lane's pixel are requested now and land under the MFMAs
+        u32x2 q1[EP >= 0 && (EP & WS_R1) ? NT * 4 : 1], qa[EP >= 0 && (EP & WS_ACC) ? NT * 4 : 1],
+            qm[EP >= 0 && (EP & WS_MASK) ? NT * 4 : 1];
+        if constexpr (EP >= 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = co0 + t * 32 + 8 * q4 + co_l;
+                    const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
+                    if constexpr ((EP & WS_R1) != 0)
+                        q1[t * 4 + q4] = *reinterpret_cast<const u32x2*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                    if constexpr ((EP & WS_ACC) != 0)
+                        qa[t * 4 + q4] = *reinterpret_cast<const u32x2*>(yp + pp * d.y.cs + d.y.coff + cc);
+                    if constexpr ((EP & WS_MASK) != 0)
+                        qm[t * 4 + q4] = *reinterpret_cast<const u32x2*>(mp + pp * d.m.cs + d.m.coff + cc);
+                }
+        }
+        // ---- 9 taps x NPL planes x 2 k-substeps; accumulators start at the bias ----
         WPROBE(2);
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const char* ab = smem + buf * BUF + a_off;
-        // explicit software pipeline: the pixel fragment of step n + PF is read before the MFMAs of step n
-        constexpr int NSTEP = 18 * NPL, PF = 3;
-        u32x4 pxr[PF + 1];
-        auto px_addr = [&](int n) {   // step n = ((pl*3 + ky)*3 + kx)*2 + kk
-            const int kk = n & 1, tap = (n >> 1) % 9, pl = (n >> 1) / 9;
-            return ab + pl * PLANE + ((tap / 3) * WS_PW + (tap % 3)) * WS_AROW + kk * 32;
-        };
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
 #pragma unroll
-        for (int n = 0; n < NSTEP + PF; ++n) {
-            if (n < NSTEP) pxr[n % (PF + 1)] = *reinterpret_cast<const u32x4*>(px_addr(n));
-            if (n >= PF) {
-                const int m = n - PF, kk = m & 1, tap = (m >> 1) % 9, pl = (m >> 1) / 9;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-#ifdef WS_ASM_AGPR
-                    // weights of the second output tile live in the accumulator half of the unified register file;
-                    // the MFMA reads them there directly (hipcc would copy them to VGPRs first)
-                    if (t == 1)
-                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
-                                     : "+a"(acc[t]) : "a"(wf[t][(tap * NPL + pl) * 2 + kk]), "v"(pxr[m % (PF + 1)]));
-                    else
-#endif
-                    mma16<__bf16>(acc[t], wf[t][(tap * NPL + pl) * 2 + kk], pxr[m % (PF + 1)]);
-                }
+                for (int e = 0; e < 4; ++e) acc[t][4 * q4 + e] = EP >= 0 ? bq[e] : 0.f;
             }
-        }
+        const char* ab = smem + buf * BUF + a_off;
+        // explicit software pipeline: the pixel fragment of step n + PF is read before the MFMAs of step n.  The
+        // sched_barrier fences pin that order (one wave per SIMD in the 64-channel variant: nothing else hides
+        // the LDS latency).
+        constexpr int NSTEP = 18 * NPL, PF = 3;
+        u32x4 pxr[NSTEP];
+        auto issue = [&](auto n_c) {   // step n = ((pl*3 + ky)*3 + kx)*2 + kk
+            constexpr int s_ = decltype(n_c)::value;
+            constexpr int kk = s_ & 1, tap = (s_ >> 1) % 9, pl = (s_ >> 1) / 9;
+            pxr[s_] = *reinterpret_cast<const u32x4*>(ab + pl * PLANE + ((tap / 3) * WS_PW + (tap % 3)) * WS_AROW + kk * 32);
+        };
+        static_for<0, PF>([&](auto n_c) { issue(n_c); });
+        static_for<0, NSTEP>([&](auto n_c) {
+            constexpr int m = decltype(n_c)::value;
+            constexpr int kk = m & 1, tap = (m >> 1) % 9, pl = (m >> 1) / 9;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m + PF < NSTEP) issue(std::integral_constant<int, m + PF>{});
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < PF; ++n) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-        for (int n = 0; n < NSTEP; ++n) {
-            if (n + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-        }
-        // ---- epilogue: this lane = one pixel x 16 channels (rows 8*q4 + 4*g + e of the C fragment); its
-        //      operands are loaded here, after the MFMA loop, to stay inside the 256-register budget (the
-        //      second workgroup on the CU covers the latency) ----
+            for (int t = 0; t < NT; ++t) mma16<__bf16>(acc[t], wf[t][(tap * NPL + pl) * 2 + kk], pxr[m]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
         WPROBE(3);
+        if constexpr (EP >= 0) {
+            // ---- lean epilogue: this lane = one pixel x 16*NT channels (rows 8*q4 + 4*g + e of the C fragments) ----
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[t][4 * q4 + e];
+                        if constexpr ((EP & WS_LRELU) != 0) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu()
+                    }
+                    if constexpr ((EP & WS_R1) != 0) {
+                        const u32x2 r = q1[t * 4 + q4];
+                        v[0] += d.beta1 * bf16_lo(r[0]); v[1] += d.beta1 * bf16_hi(r[0]);
+                        v[2] += d.beta1 * bf16_lo(r[1]); v[3] += d.beta1 * bf16_hi(r[1]);
+                    }
+                    if constexpr ((EP & WS_ACC) != 0) {
+                        const u32x2 r = qa[t * 4 + q4];
+                        v[0] += bf16_lo(r[0]); v[1] += bf16_hi(r[0]); v[2] += bf16_lo(r[1]); v[3] += bf16_hi(r[1]);
+                    }
+                    if constexpr ((EP & WS_MASK) != 0) {
+                        const u32x2 r = qm[t * 4 + q4];
+                        v[0] *= lrelu_grad_from_out(bf16_lo(r[0])); v[1] *= lrelu_grad_from_out(bf16_hi(r[0]));
+                        v[2] *= lrelu_grad_from_out(bf16_lo(r[1])); v[3] *= lrelu_grad_from_out(bf16_hi(r[1]));
+                    }
+                    bf16x4w o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4w*>(slab + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o;
+                }
+        } else {
+        // ---- generic epilogue (full ssr_conv_desc contract); its operands are loaded after the MFMA loop to stay
+        //      inside the register budget ----
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            bf16x4w q1[4], q2[4], qa[4], qm[4];
+            bf16x4w q1g[4], q2g[4], qag[4], qmg[4];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int c = co0 + t * 32 + 8 * q4 + co_l;
                 const int cc = c < d.Cout ? c : 0;                // clamped: always addressable
-                if (r1p) q1[q4] = *reinterpret_cast<const bf16x4w*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
-                if (r2p) q2[q4] = *reinterpret_cast<const bf16x4w*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
-                if (d.accumulate) qa[q4] = *reinterpret_cast<const bf16x4w*>(yp + pp * d.y.cs + d.y.coff + cc);
-                if (mp) qm[q4] = *reinterpret_cast<const bf16x4w*>(mp + pp * d.m.cs + d.m.coff + cc);
+                if (r1p) q1g[q4] = *reinterpret_cast<const bf16x4w*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                if (r2p) q2g[q4] = *reinterpret_cast<const bf16x4w*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
+                if (d.accumulate) qag[q4] = *reinterpret_cast<const bf16x4w*>(yp + pp * d.y.cs + d.y.coff + cc);
+                if (mp) qmg[q4] = *reinterpret_cast<const bf16x4w*>(mp + pp * d.m.cs + d.m.coff + cc);
             }
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -204,11 +265,11 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                     if (d.act == SSR_ACT_LRELU) v = lrelu(v);
                     v *= d.alpha;
                     o0[e] = (__bf16)v;
-                    if (r1p) v += d.beta1 * (float)q1[q4][e];
-                    if (r2p) v += d.beta2 * (float)q2[q4][e];
-                    if (d.accumulate) v += (float)qa[q4][e];
+                    if (r1p) v += d.beta1 * (float)q1g[q4][e];
+                    if (r2p) v += d.beta2 * (float)q2g[q4][e];
+                    if (d.accumulate) v += (float)qag[q4][e];
                     o1[e] = (__bf16)v;
-                    if (mp) v *= lrelu_grad_from_out((float)qm[q4][e]);
+                    if (mp) v *= lrelu_grad_from_out((float)qmg[q4][e]);
                     o2[e] = (__bf16)v;
                 }
                 if (pvalid && c < d.Cout) {
@@ -219,22 +280,23 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                 *reinterpret_cast<bf16x4w*>(slab + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o2;
             }
         }
+        }
         {
             constexpr int PARTS = 4 * NT;                         // 16-B parts per pixel row of the tile
+            const size_t row0 = (size_t)(n * d.Ho + (gy0 + 2 * wave) * d.oys + d.oyo) * d.Wo + gx0 * d.oxs + d.oxo;
 #pragma unroll
             for (int h = 0; h < 32 * PARTS / 64; ++h) {
                 const int v = h * 64 + lane;
                 const int pix = v / PARTS, part = v - pix * PARTS;
-                const int oy = ty_i * WS_TH + 2 * wave + (pix >> 4), ox = tx_i * WS_TW + (pix & 15);
+                const int dy = pix >> 4, dx = pix & 15;
                 const int c = co0 + part * 8;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(slab + pix * (32 * NT) + part * 8);
 #ifdef WS_NO_STORE
                 if (val[0] == 0x12345678u)
 #else
-                if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+                if (gy0 + 2 * wave + dy < d.Gh && gx0 + dx < d.Gw && c < d.Cout)
 #endif
-                    *reinterpret_cast<u32x4*>(yp + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * d.y.cs +
-                                              d.y.coff + c) = val;
+                    *reinterpret_cast<u32x4*>(yp + (row0 + (size_t)dy * d.oys * d.Wo + dx * d.oxs) * d.y.cs + d.y.coff + c) = val;
             }
         }
         WPROBE(4);
@@ -243,13 +305,14 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
         WS_BAR();
         WPROBE(6);   // next patch visible; everyone is done reading the current one
         buf ^= 1;
+        n = n_n; gy0 = gy0_n; gx0 = gx0_n;
     }
 }
 
-template <int NPL, int NT>
-int launch_ws(const ssr_conv_desc& d, hipStream_t st) {
+template <int NPL, int NT, int EP>
+int launch_ws_ep(const ssr_conv_desc& d, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + 4 * 32 * 32 * NT * 2;
-    auto kern = conv_ws_kernel<NPL, NT>;
+    auto kern = conv_ws_kernel<NPL, NT, EP>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -267,6 +330,24 @@ int launch_ws(const ssr_conv_desc& d, hipStream_t st) {
     return SSR_OK;
 }
 
+template <int NPL, int NT>
+int launch_ws(const ssr_conv_desc& d, hipStream_t st) {
+    // lean epilogue variants: single output, alpha == 1, no second residual
+    if (!d.y0.p && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
+        const int ep = (d.act == SSR_ACT_LRELU ? WS_LRELU : 0) | (d.m.p ? WS_MASK : 0) | (d.r1.p ? WS_R1 : 0) |
+                       (d.accumulate ? WS_ACC : 0);
+        switch (ep) {
+            case 0: return launch_ws_ep<NPL, NT, 0>(d, st);
+            case WS_LRELU: return launch_ws_ep<NPL, NT, WS_LRELU>(d, st);
+            case WS_MASK: return launch_ws_ep<NPL, NT, WS_MASK>(d, st);
+            case WS_MASK | WS_ACC: return launch_ws_ep<NPL, NT, WS_MASK | WS_ACC>(d, st);
+            case WS_MASK | WS_R1: return launch_ws_ep<NPL, NT, WS_MASK | WS_R1>(d, st);
+            default: break;
+        }
+    }
+    return launch_ws_ep<NPL, NT, WS_GENERIC>(d, st);
+}
+
 }  // namespace
 
 // 3x3 stride 1 bf16, Cin <= 64, large grid, single input, full-range residual / mask channel windows
@@ -279,11 +360,8 @@ bool ssr_conv_ws_qualifies(const ssr_conv_desc& d) {
     if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
     const long ntiles = (long)d.N * ((d.Gh + WS_TH - 1) / WS_TH) * ((d.Gw + WS_TW - 1) / WS_TW);
     if (ntiles * (d.CoutPad / 32) < 2048) return false;                 // small grids: resident / fused kernels
-    // r01 measurements: with Cin <= 32 this kernel beats the pipelined one by 1.3-3x (conv0, conv9/conv_last dgrad);
-    // the 64-channel variant (one wave per SIMD, 288 weight registers) only ties it (epilogue instruction count),
-    // so it is opt-in (SSR_CONV_WS=2) until its epilogue is slimmed down
-    static const bool wide = [] { const char* e = getenv("SSR_CONV_WS"); return e && e[0] == '2'; }();
-    if (d.Cin > 32 && !wide) return false;
+    // r01 measurements (tools/ws_probe.hip): Cin <= 32 beats the pipelined kernel by 1.3-3x; the 64-channel variant
+    // (one wave per SIMD, 288 weight registers) by 1.5x once its epilogue is a branch-free instantiation
     return ssr_conv_ws_shape_ok(d);
 }
 

@@ -99,34 +99,37 @@ __device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const RbTile (&t
     const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + (kk0 * 2 + g) * 16;
     const char* ab[NMT];
 #pragma unroll
+#ifdef RB_X_NOCONF
+    for (int m = 0; m < NMT; ++m) ab[m] = sb + (i & 15) * RB_AROW + (tl[m].oy & 1) * 16 * RB_AROW;
+#else
     for (int m = 0; m < NMT; ++m) ab[m] = sb + (tl[m].oy * RS + tl[m].ox) * RB_AROW;
+#endif
     const int bsw = (i >> 2) & 3;
     const char* bb0 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw)) << 4);
     const char* bb1 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw) ^ 2) << 4);   // second k-substep (NKK == 2)
+    // Software pipeline, written out: there is one wave per SIMD, so LDS latency (>= 128 cycles) can only be
+    // hidden inside the wave.  Operand reads run RB_PF k-steps ahead of the MFMAs that consume them; the
+    // sched_barrier fences pin that order (left alone, hipcc sinks every ds_read next to its MFMA and emits
+    // `ds_read; s_waitcnt lgkmcnt(0); v_mfma` chains that run at ~40 % of the MFMA rate).
+    constexpr int NSTEP = 9 * NKK, RB_PF = NMT == 1 ? 4 : 3;
+    u32x4 bq[NSTEP], aq[NSTEP][NMT];
+    auto issue = [&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        constexpr int tap = n / NKK, kk = n % NKK, ky = tap / 3, kx = tap % 3;
+        bq[n] = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + tap * 32 * RB_WROW);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int m = 0; m < NMT; ++m)
+            aq[n][m] = *reinterpret_cast<const u32x4*>(ab[m] + ((DELTA + ky) * RS + DELTA + kx) * RB_AROW + kk * 32);
+    };
+    static_for<0, RB_PF>([&](auto n_c) { issue(n_c); });
+    static_for<0, NSTEP>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + RB_PF < NSTEP) issue(std::integral_constant<int, n + RB_PF>{});
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const u32x4 bv = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + (ky * 3 + kx) * 32 * RB_WROW);
-#pragma unroll
-                for (int m = 0; m < NMT; ++m) {
-                    const u32x4 a = *reinterpret_cast<const u32x4*>(
-                        ab[m] + ((DELTA + ky) * RS + DELTA + kx) * RB_AROW + kk * 32);
-                    mma16<__bf16>(acc[m], bv, a);   // A = weights (rows = co), B = pixels (cols): C[co][pixel]
-                }
-            }
-    // interleave: LDS latency (~130+ cycles) exceeds the 32..64 cycles of MFMA issue per step and there is one
-    // wave per SIMD, so operand reads run RB_PF steps ahead of the MFMAs that consume them
-    constexpr int RB_PF = 3, NSTEP = 9 * NKK;
-#pragma unroll
-    for (int n = 0; n < RB_PF; ++n) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMT, 0);
-#pragma unroll
-    for (int n = 0; n < NSTEP; ++n) {
-        if (n + RB_PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NMT, 0);
-    }
+        for (int m = 0; m < NMT; ++m) mma16<__bf16>(acc[m], bq[n], aq[n][m]);   // A = weights (rows = co), B = pixels
+    });
 }
 
 // C fragment with the operands swapped (weights = A): lane l owns ONE pixel (column l & 31 of the M-tile) and
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
         // stage (q+1) % 3, which was consumed in step q-2; then slab q+1 is put in flight under the MFMAs of step q
         for (int q = 0; q < RB_NSLAB; ++q) {
             __syncthreads();
+#ifndef RB_X_NODMA
             if (q + 1 < RB_NSLAB) rb_issue_slab(d, q + 1, ring + ((q + 1) % RB_NSTAGE) * RB_SLAB, lane);
+#endif
         }
         __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();   // stage-5 tail barriers
         return;
@@ -281,9 +286,18 @@ __global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#ifdef SSR_PROBE
+        PROBE(8);
+        { RB_STEP(); PROBE(9); rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
+        PROBE(10);
+        { RB_STEP(); PROBE(11); rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
+        PROBE(12);
+#else
         RB_C(1, 0, 0, 2, acc) RB_C(1, 0, 1, 2, acc)
+#endif
         rb_store_slice<1, BWD>(acc[0], p0, bias_lds, mk0, smem, g);
         rb_store_slice<1, BWD>(acc[1], p1, bias_lds, mk1, smem, g);
+        PROBE(13);
     }
     PROBE(2);
     // ================= stage 2: region 14x14 (7 M-tiles) =====================================================

@@ -1,14 +1,6 @@
 // Shared pieces of the weight-gradient kernels (fp32-MFMA and bf16-MFMA variants).
 #pragma once
 #include "common.h"
-#include <type_traits>
-
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 constexpr int WG_TH = 8, WG_TW = 16;   // pixel tile of one wgrad step (fp32 kernels)
 // bf16 kernels: 16 rows for 3x3 layers (4 k-steps per wave per barrier), 8 for the 4x4 stride-2 layers (LDS)

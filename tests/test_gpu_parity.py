@@ -549,3 +549,37 @@ def test_weight_stationary_conv_matches_pipelined_kernel(cin, cout, H, W, B, up)
         outs[impl] = (y.float().cpu(), y0.float().cpu(), y1.float().cpu())
     for a, b, nm in zip(outs[1], outs[3], ("y", "y0", "y1")):
         assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))
+
+
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "mask_r1"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 16, 32, 2), (16, 64, 9, 21, 1), (64, 128, 8, 16, 1)])
+def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
+    """The branch-free epilogue instantiations of csrc/conv_ws.hip (the combinations the train step launches:
+    forward LeakyReLU, plain, and the dgrad forms mask / mask+accumulate / mask+residual) against the pipelined
+    kernel on the same descriptor."""
+    import ctypes as C
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cin + cout + H + len(variant))
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    mk = lambda c: (torch.randn(B, H, W, c, device="cuda") * 0.5).to(tdt).contiguous()
+    xb, r1, m, y_init = mk(cin), mk(cout), mk(cout), mk(cout)
+    outs = {}
+    for impl in (1, 3):
+        y = y_init.clone()
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        kw = dict(act=hip.ACT_LRELU if variant == "lrelu" else hip.ACT_NONE, cin=cin)
+        if variant == "mask_r1":
+            kw.update(r1=hip.view(r1), r1_nc=cout, beta1=0.5)
+        d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), **kw)
+        if variant.startswith("mask"):
+            d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        if variant == "mask_acc":
+            d.accumulate = 1
+        hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+        torch.cuda.synchronize()
+        outs[impl] = y.float().cpu()
+    assert rel_err(outs[1], outs[3]) < 1e-2, rel_err(outs[1], outs[3])

@@ -1,20 +1,43 @@
-// Fused ResidualDenseBlock forward (bf16, num_feat = 64, num_grow_ch = 32): ONE launch for
+// Fused ResidualDenseBlock forward / backward (bf16, num_feat = 64, num_grow_ch = 32): ONE launch for
 // /root/reference/ssr/archs/rrdbnet_arch.py:37-44
 //     x1 = lrelu(conv1(x)); x2 = lrelu(conv2(cat(x,x1))); ... x5 = conv5(cat(x..x4)); return x5*0.2 + x
-// (and the RRDB tail `out*0.2 + x`, :68, when this is the third block).
+// (and the RRDB tail `out*0.2 + x`, :68, when this is the third block); rdb_kernel<true> is the gather-form
+// backward of the same block (ParamStore.add_rdb_gather): stage K produces dpre_{5-K} from [newer dpre | d_out].
 //
 // Why: at the measured batch (16 x 32x32 pixels) every per-conv launch is latency bound (8..12 us for
 // 0.6..1.5 GFLOP: launch + load latency + epilogue), and the five convs of a block are strictly
 // sequential.  Here a workgroup owns an 8x8 output tile of one image and keeps the WHOLE dense block
 // resident in LDS: the 18x18 input halo region (5-pixel halo) and the shrinking 16x16 / 14x14 / 12x12 /
-// 10x10 regions of x1..x4 never leave the CU between the convs; only the weights are streamed
-// (LDS-DMA, double buffered 18/36 KB slabs).  Cost: halo recompute (1.76x the MFMAs of the block);
-// gain: 5 launches -> 1, no re-load of activations, one latency chain per block instead of five.
-// x1..x4 are still written to the dense buffer (8x8 core only): training needs them for dgrad masks and wgrad.
+// 10x10 regions of x1..x4 never leave the CU between the convs; only the weights are streamed.
+// Cost: halo recompute (1.76x the MFMAs of the block); gain: 5 launches -> 1, no re-load of activations,
+// one latency chain per block instead of five.  x1..x4 are still written to the dense buffer (8x8 core
+// only): training needs them for dgrad masks and wgrad.
 //
-// LDS map (bytes): X0 2 x 336 rows | X1 256 | X2 208 | X3 144 | X4 112 rows of 64 B (32 bf16, source-side
-// XOR swizzle: physical 16-B part = logical ^ ((row >> 2) & 3)) = 89,088; weight ring 4 x 18,432 = 73,728.
-// Waves: 4, each owns whole 32-pixel M-tiles (tiles w, w+4); conv5: wave = (M-tile, 32-channel N-tile).
+// What bounds it (tools/rdb_probe.hip, tools/mfma_probe.hip): LDS bandwidth.  One v_mfma_f32_32x32x16_bf16 takes
+// 32 cycles and eats two 1-KiB operands; four SIMDs fetching both from LDS need exactly the 256 B/clk the LDS has.
+// Every wave therefore shares the weight fragment between two pixel tiles where it can (1.5 reads per MFMA),
+// and every ds_read_b128 must be conflict-free:
+//   * activation rows are 80 B (32 bf16 + 16 B pad), so row r starts at bank 20 r mod 64: the 16 lanes the
+//     hardware serves together hit disjoint banks iff their rows are distinct mod 16;
+//   * ALL slices use the same row pitch (18 pixels) and lane i of an M-tile owns a pixel with
+//     18*oy + ox == i (mod 16) (table rb_map, built at compile time).  A tap shift or a change of slice adds the
+//     same constant to every lane's row, so every operand read of every stage is conflict-free and its address
+//     is one per-lane base plus an immediate.
+//
+// LDS map: X0 2 planes x 324 rows | X1 286 | X2 248 | X3 210 | X4 172 rows (pitch 18, region side 18 - 2S) | dummy row
+// (padding lanes write there) = 125,200 B; weight ring 2 x 18,432 B (dense 64-B rows, 16-B parts XOR-swizzled by
+// (row >> 2) & 3); bias table; control words.
+//
+// Waves: 4 MFMA waves (whole 32-pixel M-tiles; conv5: wave = (M-tile, 32-channel N-tile)) + 6 PRODUCER waves that
+// stream the 26 weight slabs (479 KB per block): 16-byte global loads into registers, two slabs ahead, then
+// ds_write_b128 into the ring.  Why six: tools/l2_probe.hip — a wave streaming L2-resident data gets ~6.4 B/clk
+// however many loads it keeps in flight, and waves add up (2: 14, 4: 28, 6: 35, 8: 43 B/clk/CU); LDS-DMA is capped
+// at ~18 B/clk per CU for any number of waves.  Two producers delivered a slab per ~1000 cycles, slower than the
+// MFMAs consume them (576..1152 cycles).
+// After the prologue there is NO s_barrier: ring hand-over and slice completion are LDS flags
+//   ready[2]    (producers -> consumers)   per ring stage: producer parts stored so far (6 per slab)
+//   done_w[4]   (consumer w -> producers)  number of slabs wave w is finished with
+//   slice_cnt[] (consumers <-> consumers)  waves that have stored their part of slice K / arrived at the final sync
 #include "common.h"
 
 #ifdef SSR_PROBE   // tools/rdb_probe.hip
@@ -29,169 +52,287 @@
 namespace {
 
 constexpr int RB_AROW = 80;                        // bytes per activation row in LDS: 32 bf16 + 16 B pad
-constexpr int RB_WROW = 64;                        // bytes per weight row (dense: LDS-DMA writes lane-linearly)
+constexpr int RB_PITCH = 18;                       // rows per image row, every slice
+constexpr int RB_WROW = 64;                        // bytes per weight row
+constexpr int rb_rows(int s) { return s == 0 ? 324 : (17 - 2 * s) * RB_PITCH + 18 - 2 * s; }
 constexpr int RB_X0 = 0;                           // x: 2 planes x 324 rows
 constexpr int RB_X0P = 324 * RB_AROW;
-constexpr int RB_X1 = RB_X0 + 2 * RB_X0P;          // x1: 256 rows
-constexpr int RB_X2 = RB_X1 + 256 * RB_AROW;       // x2: 196 rows (+1 dummy row each: padding lanes write there)
-constexpr int RB_X3 = RB_X2 + 197 * RB_AROW;       // x3: 144 rows
-constexpr int RB_X4 = RB_X3 + 145 * RB_AROW;       // x4: 100 rows
-constexpr int RB_RING = RB_X4 + 101 * RB_AROW;
+constexpr int RB_X1 = RB_X0 + 2 * RB_X0P;
+constexpr int RB_X2 = RB_X1 + rb_rows(1) * RB_AROW;
+constexpr int RB_X3 = RB_X2 + rb_rows(2) * RB_AROW;
+constexpr int RB_X4 = RB_X3 + rb_rows(3) * RB_AROW;
+constexpr int RB_DUMMY = RB_X4 + rb_rows(4) * RB_AROW;
+constexpr int RB_RING = RB_DUMMY + RB_AROW;
 constexpr int RB_SLAB = 288 * RB_WROW;             // 9 taps x 32 co rows of 32 ci
-constexpr int RB_NSTAGE = 3;
-constexpr int RB_BIAS = RB_RING + RB_NSTAGE * RB_SLAB;   // [5 convs][64] fp32 bias table
-constexpr int RB_LDS = RB_BIAS + (4 * 32 + 64) * 4;   // conv k < 5 at k*32, conv5 at 128
+constexpr int RB_NSTAGE = 2;
+constexpr int RB_BIAS = RB_RING + RB_NSTAGE * RB_SLAB;   // [4 x 32 + 64] fp32 bias table: conv k < 5 at k*32, conv5 at 128
+constexpr int RB_CTL = RB_BIAS + (4 * 32 + 64) * 4;      // 16 control words
+constexpr int RB_LDS = RB_CTL + 64;
 static_assert(RB_LDS <= 160 * 1024, "LDS budget");
-static_assert(RB_NSTAGE * RB_SLAB >= 4 * 2048 + 2 * 2 * 4096, "ring doubles as reduce scratch + output slabs");
+static_assert(RB_NSTAGE * RB_SLAB >= 4 * 2048, "ring doubles as the output transpose slabs");
+constexpr int RB_NPROD = 6, RB_NTHREADS = 256 + 64 * RB_NPROD;
+// control words
+constexpr int CTL_READY = 0;     // [2] one counter per ring stage
+constexpr int CTL_DONE = 4;      // [4]
+constexpr int CTL_SLICE = 8;     // [1..4] slice K complete, [5] final sync
 
 __device__ __forceinline__ constexpr int rb_slice_base(int s) {   // slice 0 (plane 0), 1..4
     return s == 0 ? RB_X0 : s == 1 ? RB_X1 : s == 2 ? RB_X2 : s == 3 ? RB_X3 : RB_X4;
 }
 
-// Weight slab q of the block's schedule -> ring stage: 18 LDS-DMA wave-instructions (16 rows x 64 B each),
-// all issued by the PRODUCER wave (wave 4) so that the four MFMA waves never spend issue slots on loads.
-// Schedule: conv1 c0,c1 | conv2 c0..2 | conv3 c0..3 | conv4 c0..4 | conv5 (c0,n0),(c0,n1) ... (c5,n1) = 26 slabs.
+// ---- lane -> pixel map: stage K (region side R = 18 - 2K), M-tile t, lane i & 31 -> oy | ox << 5 | valid << 10 with
+//      (18*oy + ox) mod 16 == i mod 16.  Class c = pixels with that residue: for every oy at most one ox = (c - 2 oy)
+//      mod 16 < R; the class is enumerated by rising oy and M-tile t takes its entries 2t (lanes 0..15) and 2t+1 (lanes
+//      16..31).  Class sizes: R = 16: 16 (8 tiles), 14: 12..13 (7), 12: 8..10 (5), 10: 5..7 (4), 8: 4 (2) — the same
+//      tile counts as a linear walk.  Unused slots point at the class's first pixel with valid = 0. ----
+struct RbMap { unsigned short e[5][8][32]; };
+constexpr int rb_ntiles(int K) { return K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2; }
+constexpr RbMap rb_make_map() {
+    RbMap m{};
+    for (int K = 1; K <= 5; ++K) {
+        const int R = 18 - 2 * K, nt = rb_ntiles(K);
+        for (int c = 0; c < 16; ++c) {
+            int cnt = 0, first = 0;
+            for (int oy = 0; oy < R; ++oy) {
+                const int ox = ((c - 2 * oy) % 16 + 16) % 16;
+                if (ox >= R) continue;
+                const unsigned short v = (unsigned short)(oy | (ox << 5));
+                if (cnt == 0) first = v;
+                if (cnt < 2 * nt) m.e[K - 1][cnt >> 1][(cnt & 1) * 16 + c] = (unsigned short)(v | (1 << 10));
+                ++cnt;
+            }
+            for (int sl = cnt; sl < 2 * nt; ++sl) m.e[K - 1][sl >> 1][(sl & 1) * 16 + c] = (unsigned short)first;
+        }
+    }
+    return m;
+}
+constexpr bool rb_map_complete() {   // every region pixel is owned by exactly one (tile, lane)
+    constexpr RbMap m = rb_make_map();
+    for (int K = 1; K <= 5; ++K) {
+        const int R = 18 - 2 * K;
+        int n = 0;
+        for (int t = 0; t < rb_ntiles(K); ++t)
+            for (int i = 0; i < 32; ++i) {
+                const int e = m.e[K - 1][t][i];
+                if (!(e >> 10)) continue;
+                const int oy = e & 31, ox = (e >> 5) & 31;
+                if (oy >= R || ox >= R || ((RB_PITCH * oy + ox) & 15) != (i & 15)) return false;
+                ++n;
+            }
+        if (n != R * R) return false;
+    }
+    return true;
+}
+static_assert(rb_map_complete(), "lane -> pixel map must cover every region exactly once");
+__device__ const RbMap rb_map = rb_make_map();
+
+// Weight slab q of the block's schedule: conv1 j0,j1 | conv2 j0..2 | conv3 j0..3 | conv4 j0..4 | conv5 (j0,h0),(j0,h1)
+// ... (j5,h1) = 26 slabs of 18,432 B, where step j of conv K contracts LDS slice (j < 2 ? 0 (plane j) : j - 1): oldest
+// first, so that the slice produced by the previous stage is needed last.  Weight chunk in memory: forward = j
+// (rrdbnet_arch.py:39-42 cat order); backward = [dpre newest .. oldest | d_out p0 p1] (ParamStore.add_rdb_gather)
+// -> j < 2 ? K-1+j : K-j.
+//   conv1..4: [chunk of 32 ci][tap][32 co][32 ci]  -> 288 rows of 64 B, 16-B part XOR-swizzled by (row >> 2) & 3
+//   conv5   : [chunk of 16 ci][tap][64 co][16 ci]  -> 576 rows of 32 B (16-channel half h of chunk j, ALL 64 output
+//             channels), 16-B part XOR-swizzled by (row >> 3) & 1.  Every MFMA wave consumes every slab (9 MFMAs),
+//             so the two-stage ring double-buffers; with per-N-tile slabs each wave pair would own one ring stage.
+// A slab is 18 pieces of 1 KiB (one 16-B load per lane); producer pw moves pieces pw, pw+6, pw+12.
 constexpr int RB_NSLAB = 26;
-__device__ __forceinline__ void rb_issue_slab(const ssr_rdb_desc& d, int q, char* stage, int lane) {
-    int k, c, nt = 0;
-    if (q < 2) { k = 0; c = q; }
-    else if (q < 5) { k = 1; c = q - 2; }
-    else if (q < 9) { k = 2; c = q - 5; }
-    else if (q < 14) { k = 3; c = q - 9; }
-    else { k = 4; c = (q - 14) >> 1; nt = (q - 14) & 1; }
-    const int cp = k == 4 ? 64 : 32;
-    const __bf16* base = reinterpret_cast<const __bf16*>(d.w[k]) + (size_t)(c * 9 * cp + nt * 32) * 32;
+constexpr int RB_PV = 18 / RB_NPROD;
+template <bool BWD>
+__device__ __forceinline__ void rb_load_slab(const ssr_rdb_desc& d, int q, int lane, int pw, u32x4 (&r)[RB_PV]) {
+    int k, j, h = 0;
+    if (q < 2) { k = 0; j = q; }
+    else if (q < 5) { k = 1; j = q - 2; }
+    else if (q < 9) { k = 2; j = q - 5; }
+    else if (q < 14) { k = 3; j = q - 9; }
+    else { k = 4; j = (q - 14) >> 1; h = (q - 14) & 1; }
+    const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j;
+    if (k == 4) {
+        // source slab is contiguous; lane v = piece*64 + lane -> row v >> 1, part v & 1
+        const __bf16* base = reinterpret_cast<const __bf16*>(d.w[4]) + (size_t)(2 * c + h) * (9 * 64 * 16);
+#pragma unroll
+        for (int jj = 0; jj < RB_PV; ++jj) {
+            const int v = (jj * RB_NPROD + pw) * 64 + lane;
+            const int row = v >> 1, lp = (v & 1) ^ ((row >> 3) & 1);
+            r[jj] = *reinterpret_cast<const u32x4*>(base + row * 16 + lp * 8);
+        }
+        return;
+    }
+    const __bf16* base = reinterpret_cast<const __bf16*>(d.w[k]) + (size_t)(c * 9 * 32) * 32;
     const int lrow = lane >> 2, pp = lane & 3;
 #pragma unroll
-    for (int j = 0; j < 18; ++j) {
-        const int row = 16 * j + lrow;                      // = tap*32 + co
-        const int tap = row >> 5, co = row & 31, lp = pp ^ ((row >> 2) & 3);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + (tap * cp + co) * 32 + lp * 8),
-            (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
+    for (int jj = 0; jj < RB_PV; ++jj) {
+        const int row = 16 * (jj * RB_NPROD + pw) + lrow;   // = tap*32 + co
+        const int lp = pp ^ ((row >> 2) & 3);
+        r[jj] = *reinterpret_cast<const u32x4*>(base + row * 32 + lp * 8);
     }
 }
-
-struct RbTile {   // per-lane coordinates of one 32-pixel M-tile of a conv's output region
-    int oy, ox;   // position inside the region (clamped to a valid pixel for padding lanes)
-};
-
-template <int K>   // conv index 1..5; region side R = 18 - 2K, P = R*R pixels
-__device__ __forceinline__ RbTile rb_tile(int mt, int i) {
-    constexpr int R = 18 - 2 * K, P = R * R;
-    const int p = 32 * mt + i;
-    const int pc = p < P ? p : P - 1;
-    RbTile t;
-    t.oy = pc / R;
-    t.ox = pc - t.oy * R;
-    return t;
+__device__ __forceinline__ void rb_store_slab(char* stage, int lane, int pw, const u32x4 (&r)[RB_PV]) {
+#pragma unroll
+    for (int jj = 0; jj < RB_PV; ++jj)
+        *reinterpret_cast<u32x4*>(stage + (jj * RB_NPROD + pw) * 1024 + lane * 16) = r[jj];
 }
 
-// Contraction of one weight slab (32 input channels of slice S) into NMT accumulators.
-// KK0/NKK select the 16-channel k-substeps this wave handles (all: 0,2; k-split half: kh,1).
-// Every LDS address is one per-lane base plus a compile-time immediate; reads of tap n+1 are
-// scheduled in front of the MFMAs of tap n (one wave per SIMD: overlap must come from inside the wave).
-template <int K, int S, int NMT, int NKK>
-__device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const RbTile (&tl)[NMT], const char* smem,
-                                            const char* slab, int plane, int i, int g, int kk0) {
-    constexpr int RS = 18 - 2 * S;                 // side of slice S's region
+// ---- LDS flags ----
+__device__ __forceinline__ int rb_ld(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void rb_wait_ge(const int* p, int target) {
+    while (rb_ld(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+// Contraction of one weight slab (32 input channels of slice S) into NMT accumulators; po[m] = this lane's pixel of
+// M-tile m as a byte offset (18*oy + ox) * RB_AROW in the stage's own region.
+// Software pipeline, written out: there is one wave per SIMD, so LDS latency (>= 128 cycles) can only be hidden
+// inside the wave.  Operand reads run RB_PF k-steps ahead of the MFMAs that consume them; the sched_barrier fences
+// pin that order (left alone, hipcc sinks every ds_read next to its MFMA: `ds_read; s_waitcnt lgkmcnt(0); v_mfma`).
+// `mid` runs right after the LAST operand read of the slab has been issued (RB_PF k-steps before the end): the caller
+// hands the ring stage back there (LDS executes a wave's operations in order, so the flag write cannot overtake the
+// reads) and samples the next slab's ready counter, hiding the hand-over latency behind the remaining MFMAs.
+template <int K, int S, int NMT, typename Mid>
+__device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const int (&po)[NMT], const char* smem, const char* slab,
+                                            int plane, int i, int g, Mid&& mid) {
     constexpr int DELTA = K - S - 1;               // offset of conv K's output region inside slice S's region
-    const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + (kk0 * 2 + g) * 16;
+    const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + (DELTA * RB_PITCH + DELTA) * RB_AROW;
     const char* ab[NMT];
 #pragma unroll
-#ifdef RB_X_NOCONF
-    for (int m = 0; m < NMT; ++m) ab[m] = sb + (i & 15) * RB_AROW + (tl[m].oy & 1) * 16 * RB_AROW;
-#else
-    for (int m = 0; m < NMT; ++m) ab[m] = sb + (tl[m].oy * RS + tl[m].ox) * RB_AROW;
-#endif
+    for (int m = 0; m < NMT; ++m) ab[m] = sb + po[m];
     const int bsw = (i >> 2) & 3;
-    const char* bb0 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw)) << 4);
-    const char* bb1 = slab + i * RB_WROW + ((((kk0 * 2 + g) ^ bsw) ^ 2) << 4);   // second k-substep (NKK == 2)
-    // Software pipeline, written out: there is one wave per SIMD, so LDS latency (>= 128 cycles) can only be
-    // hidden inside the wave.  Operand reads run RB_PF k-steps ahead of the MFMAs that consume them; the
-    // sched_barrier fences pin that order (left alone, hipcc sinks every ds_read next to its MFMA and emits
-    // `ds_read; s_waitcnt lgkmcnt(0); v_mfma` chains that run at ~40 % of the MFMA rate).
-    constexpr int NSTEP = 9 * NKK, RB_PF = NMT == 1 ? 4 : 3;
+    const char* bb0 = slab + i * RB_WROW + ((g ^ bsw) << 4);
+    const char* bb1 = slab + i * RB_WROW + (((g ^ bsw) ^ 2) << 4);   // second 16-channel k-substep
+    constexpr int NSTEP = 18, RB_PF = NMT == 1 ? 4 : 3;
     u32x4 bq[NSTEP], aq[NSTEP][NMT];
     auto issue = [&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
-        constexpr int tap = n / NKK, kk = n % NKK, ky = tap / 3, kx = tap % 3;
+        constexpr int tap = n / 2, kk = n % 2, ky = tap / 3, kx = tap % 3;
+#ifdef RB_X_NOB
+        bq[n] = u32x4{0x3c003c00u + (unsigned)g, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#else
         bq[n] = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + tap * 32 * RB_WROW);
+#endif
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
-            aq[n][m] = *reinterpret_cast<const u32x4*>(ab[m] + ((DELTA + ky) * RS + DELTA + kx) * RB_AROW + kk * 32);
+#ifdef RB_X_NOA
+            aq[n][m] = u32x4{0x3c003c00u + (unsigned)i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#else
+            aq[n][m] = *reinterpret_cast<const u32x4*>(ab[m] + (ky * RB_PITCH + kx) * RB_AROW + kk * 32);
+#endif
     };
     static_for<0, RB_PF>([&](auto n_c) { issue(n_c); });
     static_for<0, NSTEP>([&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + RB_PF < NSTEP) issue(std::integral_constant<int, n + RB_PF>{});
+        if constexpr (n + RB_PF == NSTEP - 1) mid();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < NMT; ++m) mma16<__bf16>(acc[m], bq[n], aq[n][m]);   // A = weights (rows = co), B = pixels
     });
 }
 
+// conv5: one (chunk j, 16-channel half h) slab = 9 taps x 64 co rows of 32 B; this wave's N-tile nt -> rows tap*64 + nt*32 + i
+template <int S, typename Mid>
+__device__ __forceinline__ void rb_contract5(f32x16& acc, int po, const char* smem, const char* slab, int plane, int h, int nt,
+                                             int i, int g, Mid&& mid) {
+    constexpr int DELTA = 5 - S - 1;
+    const char* ab = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + h * 32 + (DELTA * RB_PITCH + DELTA) * RB_AROW + po;
+    const char* bb = slab + (nt * 32 + i) * 32 + ((g ^ ((i >> 3) & 1)) << 4);
+    constexpr int NSTEP = 9, RB_PF = 4;
+    u32x4 bq[NSTEP], aq[NSTEP];
+    auto issue = [&](auto n_c) {
+        constexpr int tap = decltype(n_c)::value;
+        bq[tap] = *reinterpret_cast<const u32x4*>(bb + tap * 64 * 32);
+        aq[tap] = *reinterpret_cast<const u32x4*>(ab + ((tap / 3) * RB_PITCH + tap % 3) * RB_AROW);
+    };
+    static_for<0, RB_PF>([&](auto n_c) { issue(n_c); });
+    static_for<0, NSTEP>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + RB_PF < NSTEP) issue(std::integral_constant<int, n + RB_PF>{});
+        if constexpr (n + RB_PF == NSTEP - 1) mid();
+        __builtin_amdgcn_sched_barrier(0);
+        mma16<__bf16>(acc, bq[n], aq[n]);
+    });
+}
+
 // C fragment with the operands swapped (weights = A): lane l owns ONE pixel (column l & 31 of the M-tile) and
 // 16 output channels co = 8*(r>>2) + 4*(l>>5) + (r&3): four runs of 4 consecutive channels.
-// Epilogue of conv K < 5: x_K = lrelu(acc + bias), zero outside the image (one test per lane), packed to bf16 and
-// written to LDS slice K with four 8-byte stores.
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
 struct RbPix {            // this lane's pixel of one M-tile of stage K
-    int p;                // linear index in the stage's region (may be >= P for padding lanes)
-    bool inside;          // inside the image (and p < P)
+    int po;               // (18*oy + ox) * RB_AROW in the stage's region
+    bool valid, inside;   // owns a region pixel / that pixel is inside the image
     size_t gpix;          // clamped global pixel index (n*H + iy)*W + ix
 };
 template <int K>
-__device__ __forceinline__ RbPix rb_pix(int mt, int i, int n, int ty0, int tx0, int H, int W) {
-    constexpr int R = 18 - 2 * K, P = R * R, HK = 5 - K;
+__device__ __forceinline__ RbPix rb_pix(int e, int n, int ty0, int tx0, int H, int W) {
+    constexpr int HK = 5 - K;
+    const int oy = e & 31, ox = (e >> 5) & 31;
     RbPix t;
-    t.p = 32 * mt + i;
-    const int oy = t.p / R, ox = t.p - oy * R;
+    t.po = (oy * RB_PITCH + ox) * RB_AROW;
+    t.valid = (e >> 10) != 0;
     const int iy = ty0 - HK + oy, ix = tx0 - HK + ox;
-    t.inside = t.p < P && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    t.inside = t.valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
     t.gpix = (size_t)(n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
     return t;
 }
-// forward: x_K = lrelu(acc + bias); backward: dpre = acc * lrelu'(x_k) (mk = the saved forward activation);
-// zero outside the image (zero padding of the NEXT stage's input); four 8-byte LDS stores per lane
-template <int K, bool BWD>
-__device__ __forceinline__ void rb_store_slice(const f32x16& acc, const RbPix& px, const float* bias_lds,
-                                               const bf16x4v (&mk)[4], char* smem, int g) {
-    constexpr int R = 18 - 2 * K, P = R * R;
-    char* row = smem + rb_slice_base(K) + (px.p < P ? px.p : P) * RB_AROW + g * 8;   // P = dummy row
+// accumulator start: the bias of this lane's 16 channels (forward) / zero (backward: the gather dgrad has no bias)
+template <bool BWD>
+__device__ __forceinline__ void rb_acc_init(f32x16& acc, const float* bias_lds, int g) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-        bf16x4v o;
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (!BWD) bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q4 + e] = bq[e];
+    }
+}
+// Epilogue of conv K < 5.  forward: x_K = lrelu(acc) (bias is already in acc); backward: dpre = acc * lrelu'(x_k)
+// (mk = the saved forward activation); zero outside the image (zero padding of the NEXT stage's input), packed to
+// bf16 and written to LDS slice K with four 8-byte stores.  The epilogue is issue bound (one wave per SIMD): max()
+// instead of compare+select, the image test applied to the packed words.
+template <int K, bool BWD>
+__device__ __forceinline__ void rb_store_slice(const f32x16& acc, const RbPix& px, const u32x2v (&mk)[4], char* smem, int g) {
+    char* row = smem + (px.valid ? rb_slice_base(K) + px.po : RB_DUMMY) + g * 8;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q4 + e];
         if (BWD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = (__bf16)(px.inside ? acc[4 * q4 + e] * lrelu_grad_from_out((float)mk[q4][e]) : 0.f);
+            v[0] *= lrelu_grad_from_out(bf_lo(mk[q4][0])); v[1] *= lrelu_grad_from_out(bf_hi(mk[q4][0]));
+            v[2] *= lrelu_grad_from_out(bf_lo(mk[q4][1])); v[3] *= lrelu_grad_from_out(bf_hi(mk[q4][1]));
         } else {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(px.inside ? lrelu(acc[4 * q4 + e] + bq[e]) : 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu(v)
         }
-        *reinterpret_cast<bf16x4v*>(row + 16 * q4) = o;
+        bf16x4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        u32x2v w = __builtin_bit_cast(u32x2v, o);
+        w[0] = px.inside ? w[0] : 0u;
+        w[1] = px.inside ? w[1] : 0u;
+        *reinterpret_cast<u32x2v*>(row + 16 * q4) = w;
     }
 }
 // backward: the 16 channels of x_k (k = 5 - K) of this lane's pixel, from the saved forward buffer
 template <int K>
-__device__ __forceinline__ void rb_load_mask(const ssr_rdb_desc& d, const RbPix& px, int g, bf16x4v (&mk)[4]) {
+__device__ __forceinline__ void rb_load_mask(const ssr_rdb_desc& d, const RbPix& px, int g, u32x2v (&mk)[4]) {
     const __bf16* mp = reinterpret_cast<const __bf16*>(d.mask.p) + px.gpix * d.mask.cs + d.mask.coff + 64 +
                        32 * (5 - K - 1) + 4 * g;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) mk[q4] = *reinterpret_cast<const bf16x4v*>(mp + 8 * q4);
+    for (int q4 = 0; q4 < 4; ++q4) mk[q4] = *reinterpret_cast<const u32x2v*>(mp + 8 * q4);
 }
 
 // cooperative write of the 8x8 core of LDS slice K (32 channels) to the dense buffer: one 16-B vector per thread
 template <int K, bool BWD>
 __device__ __forceinline__ void rb_flush_core(const ssr_rdb_desc& d, const char* smem, int n, int ty0, int tx0,
                                               int tid) {
-    constexpr int R = 18 - 2 * K, HK = 5 - K;
+    constexpr int HK = 5 - K;
     const int q = tid >> 2, part = tid & 3;
     const int cy = q >> 3, cx = q & 7;
-    const int p = (cy + HK) * R + cx + HK;
+    const int p = (cy + HK) * RB_PITCH + cx + HK;
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + rb_slice_base(K) + p * RB_AROW + part * 16);
     const int iy = ty0 + cy, ix = tx0 + cx;
     if (iy < d.H && ix < d.W) {
@@ -202,8 +343,69 @@ __device__ __forceinline__ void rb_flush_core(const ssr_rdb_desc& d, const char*
     }
 }
 
+struct RbCtx {            // what every stage needs
+    const ssr_rdb_desc& d;
+    char* smem;
+    char* ring;
+    int* ctl;
+    const float* bias_lds;
+    int n, ty0, tx0, tid, lane, wave, i, g;
+    int hint_q, hint;     // ready counter of slab hint_q's ring stage, sampled during the previous slab
+};
+// step q: wait for slab q / hand its ring stage back
+__device__ __forceinline__ const char* rb_acquire(RbCtx& c, int q) {
+    // slab q is the (q/2 + 1)-th user of stage q % 2: complete when the stage's counter has all its producer parts.
+    // (a producer cannot add for slab q + 2 before every consumer has released slab q, so the count is exact)
+    const int target = RB_NPROD * (q / RB_NSTAGE + 1);
+    if (!(c.hint_q == q && c.hint >= target))
+        while (rb_ld(c.ctl + CTL_READY + (q % RB_NSTAGE)) < target) {}
+    return c.ring + (q % RB_NSTAGE) * RB_SLAB;
+}
+__device__ __forceinline__ void rb_release(RbCtx& c, int upto) {   // this wave is finished with every slab < upto
+    if (c.lane == 0) __atomic_store_n(c.ctl + CTL_DONE + c.wave, upto, __ATOMIC_RELAXED);
+}
+// release slab q and sample the ready counter of slab q + 1
+__device__ __forceinline__ void rb_handover(RbCtx& c, int q) {
+    rb_release(c, q + 1);
+    c.hint_q = q + 1;
+    c.hint = rb_ld(c.ctl + CTL_READY + ((q + 1) % RB_NSTAGE));
+}
+
+// One growth conv (K = 1..4) for NMT M-tiles of this wave: chunks j = 0..K (slab Q0 + j), then the slice epilogue.
+template <int K, int NMT, bool BWD>
+__device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
+    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9;
+    f32x16 acc[NMT];
+    RbPix px[NMT];
+    int po[NMT];
+    u32x2v mk[NMT][4];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        px[m] = rb_pix<K>(ent[m], c.n, c.ty0, c.tx0, c.d.H, c.d.W);
+        po[m] = px[m].po;
+        if (BWD) rb_load_mask<K>(c.d, px[m], c.g, mk[m]);
+    }
+    rb_acc_init<BWD>(acc[0], c.bias_lds + 32 * (K - 1), c.g);
+#pragma unroll
+    for (int m = 1; m < NMT; ++m) acc[m] = acc[0];
+    static_for<0, K + 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int S = j < 2 ? 0 : j - 1, PL = j < 2 ? j : 0;
+        if constexpr (j == K && K > 1) {
+            // last chunk: slice K-1 (stored by the previous stage) must be complete; its 8x8 core also goes to the dense buffer
+            rb_wait_ge(c.ctl + CTL_SLICE + (K - 1), 4);
+            rb_flush_core<K - 1, BWD>(c.d, c.smem, c.n, c.ty0, c.tx0, c.tid);
+        }
+        const char* slab = rb_acquire(c, Q0 + j);
+        rb_contract<K, S, NMT>(acc, po, c.smem, slab, PL, c.i, c.g, [&] { rb_handover(c, Q0 + j); });
+    });
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) rb_store_slice<K, BWD>(acc[m], px[m], mk[m], c.smem, c.g);
+    if (c.lane == 0) __atomic_fetch_add(c.ctl + CTL_SLICE + K, 1, __ATOMIC_RELAXED);   // LDS ops of a wave execute in order
+}
+
 template <bool BWD>
-__global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
+__global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
@@ -215,22 +417,38 @@ __global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
     const int ty0 = ty_i * 8, tx0 = tx_i * 8;
     const int H = d.H, W = d.W;
     char* ring = smem + RB_RING;
+    int* ctl = reinterpret_cast<int*>(smem + RB_CTL);
     PROBE(0);
-    const bool producer = wave == 4;
+    const bool producer = wave >= 4;
+    const int pw = wave - 4;
     float* bias_lds = reinterpret_cast<float*>(smem + RB_BIAS);
     {
         const int k = tid < 128 ? tid >> 5 : 4, c = tid < 128 ? tid & 31 : tid - 128;   // 4 x 32 + 64 entries
         if (tid < 192) bias_lds[tid] = d.bias[k] ? d.bias[k][c] : 0.f;
+        if (tid >= 192 && tid < 208) ctl[tid - 192] = 0;
     }
-    if (producer) rb_issue_slab(d, 0, ring, lane);
+    // producers: a queue of RB_RQ slabs (this wave's 3 KiB of each) in registers.  The ring has only two stages (LDS is
+    // full), so run-ahead lives here: conv5 needs a slab per ~300 cycles, the six producers fetch one per ~480; the
+    // queue fills during stages 1..4, which consume a slab per 576..1152 cycles.
+    constexpr int RB_RQ = 8;
+    u32x4 wq[RB_RQ][RB_PV];
+    if (producer) static_for<0, RB_RQ>([&](auto uc) { rb_load_slab<BWD>(d, decltype(uc)::value, lane, pw, wq[decltype(uc)::value]); });
+    // MFMA waves: this lane's pixels (rb_map) for every stage, requested now
+    const int w4 = wave & 3;
+    const int e1a = rb_map.e[0][w4][i], e1b = rb_map.e[0][w4 + 4][i];
+    const int e2a = rb_map.e[1][w4][i], e2b = rb_map.e[1][w4 + 4 < 7 ? w4 + 4 : 6][i];
+    const int e3a = rb_map.e[2][w4][i], e3b = rb_map.e[2][4][i];
+    const int e4 = rb_map.e[3][w4][i], e5 = rb_map.e[4][w4 & 1][i];
+    const int e5s0 = rb_map.e[4][w4 & 1][lane >> 2], e5s1 = rb_map.e[4][w4 & 1][16 + (lane >> 2)];
     // ---- 64-channel input halo region (x / d_out): 18x18 pixels -> X0 (2 planes of 32 channels, padded rows),
-    //      staged through registers so that the rows can be padded (conflict-free, immediate offsets) ----
+    //      staged through registers so that the rows can be padded ----
     {
         const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.in.p);
-        u32x4 rx[9];
+        constexpr int NQ = (2592 + RB_NTHREADS - 1) / RB_NTHREADS;
+        u32x4 rx[NQ];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int v = tid + q * 320;                     // (plane, pixel, part): 2 x 324 x 4 = 2592 vectors
+        for (int q = 0; q < NQ; ++q) {
+            const int v = tid + q * RB_NTHREADS;             // (plane, pixel, part): 2 x 324 x 4 = 2592 vectors
             const int plane = v / 1296, r2 = v - plane * 1296;
             const int pix = r2 >> 2, part = r2 & 3;
             const int py = pix / 18, px = pix - py * 18;
@@ -242,190 +460,116 @@ __global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
             rx[q] = val;
         }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int v = tid + q * 320;
+        for (int q = 0; q < NQ; ++q) {
+            const int v = tid + q * RB_NTHREADS;
             const int plane = v / 1296, r2 = v - plane * 1296;
             if (v < 2592) *reinterpret_cast<u32x4*>(smem + RB_X0 + plane * RB_X0P + (r2 >> 2) * RB_AROW + (r2 & 3) * 16) = rx[q];
         }
     }
     PROBE(1);
+    __syncthreads();   // the only barrier: X0, bias table, zeroed control words
     if (producer) {
-        // step q: the barrier publishes slab q (hipcc drains this wave's vmcnt(0) in front of it) and frees
-        // stage (q+1) % 3, which was consumed in step q-2; then slab q+1 is put in flight under the MFMAs of step q
-        for (int q = 0; q < RB_NSLAB; ++q) {
-            __syncthreads();
-#ifndef RB_X_NODMA
-            if (q + 1 < RB_NSLAB) rb_issue_slab(d, q + 1, ring + ((q + 1) % RB_NSTAGE) * RB_SLAB, lane);
-#endif
-        }
-        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();   // stage-5 tail barriers
+        // slab s: registers (requested RB_RQ slabs ahead) -> ring
+        // stage s % 2 once every MFMA wave is finished with slab s - 2 -> publish.  LDS operations of a wave execute
+        // in order, so the flag write follows the data.
+        auto put = [&](int s_, const u32x4 (&r)[RB_PV]) {
+            if (s_ >= RB_NSTAGE) {
+                for (;;) {
+                    // inline asm: for a volatile / atomic LDS read hipcc emits `s_waitcnt vmcnt(0)` first, which would
+                    // wait for the refill loads issued a moment ago (one memory latency per slab)
+                    u32x4 dn;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(RB_CTL + 4 * CTL_DONE)) : "memory");
+                    if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= s_ - (RB_NSTAGE - 1)) break;
+                }
+            }
+            rb_store_slab(ring + (s_ % RB_NSTAGE) * RB_SLAB, lane, pw, r);
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(RB_CTL + 4 * (CTL_READY + (s_ % RB_NSTAGE)))), "v"(1) : "memory");
+        };
+        for (int s0 = 0; s0 < RB_NSLAB; s0 += RB_RQ)
+            static_for<0, RB_RQ>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int s_ = s0 + u;
+                if (s_ < RB_NSLAB) put(s_, wq[u]);
+                if (s_ + RB_RQ < RB_NSLAB) rb_load_slab<BWD>(d, s_ + RB_RQ, lane, pw, wq[u]);
+            });
         return;
     }
-    // Consumer barrier: LDS writes complete (lgkmcnt) + s_barrier, but NO vmcnt drain — the MFMA waves have no
-    // LDS-DMA of their own; their global loads (masks, residual) and core stores stay in flight across steps.
-#define RB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    int stage = 0;   // ring stage holding the slab that is consumed next
-#define RB_STEP()                                                                 \
-    RB_BAR(); /* slab in `stage` has landed (producer) and all slice writes are visible */ \
-    const char* slab = ring + stage * RB_SLAB;                                    \
-    stage = stage + 1 == RB_NSTAGE ? 0 : stage + 1;
-    // chunk c of stage K reads LDS slice S (plane P of the 64-channel input for S = 0):
-    //   forward  : x p0, x p1, x1, ..., x_{K-1}          (rrdbnet_arch.py:39-42 cat order)
-    //   backward : dpre_{6-K} .. dpre_4 (= slices K-1 .. 1), d_out p0, d_out p1   (ParamStore.add_rdb_gather order)
-#define RB_C(K, S, PL, NMT, ACC) { RB_STEP(); rb_contract<K, S, NMT, 2>(ACC, tl, smem, slab, PL, i, g, 0); }
-#define RB_CF(K, S, PL, NMT, ACC) { RB_STEP(); rb_flush_core<K - 1, BWD>(d, smem, n, ty0, tx0, tid); \
-                                    rb_contract<K, S, NMT, 2>(ACC, tl, smem, slab, PL, i, g, 0); }
-    bf16x4v mk0[4], mk1[4];
-    // ================= stage 1: region 16x16 (8 M-tiles: wave w owns tiles w, w+4), K = the 64-ch input =========
-    {
-        f32x16 acc[2];
-        RbTile tl[2] = {rb_tile<1>(wave, i), rb_tile<1>(wave + 4, i)};
-        const RbPix p0 = rb_pix<1>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<1>(wave + 4, i, n, ty0, tx0, H, W);
-        if (BWD) { rb_load_mask<1>(d, p0, g, mk0); rb_load_mask<1>(d, p1, g, mk1); }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-#ifdef SSR_PROBE
-        PROBE(8);
-        { RB_STEP(); PROBE(9); rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 0, i, g, 0); }
-        PROBE(10);
-        { RB_STEP(); PROBE(11); rb_contract<1, 0, 2, 2>(acc, tl, smem, slab, 1, i, g, 0); }
-        PROBE(12);
-#else
-        RB_C(1, 0, 0, 2, acc) RB_C(1, 0, 1, 2, acc)
-#endif
-        rb_store_slice<1, BWD>(acc[0], p0, bias_lds, mk0, smem, g);
-        rb_store_slice<1, BWD>(acc[1], p1, bias_lds, mk1, smem, g);
-        PROBE(13);
-    }
+    // ---------------- MFMA waves ----------------
+    RbCtx c{d, smem, ring, ctl, bias_lds, n, ty0, tx0, tid, lane, wave, i, g, -1, 0};
+    // stage 1: 16x16 region, 8 M-tiles (wave w: tiles w, w+4); stage 2: 14x14, 7 tiles (wave 3 has one);
+    // stage 3: 12x12, 5 tiles (wave 0 has two); stage 4: 10x10, 4 tiles
+    { const int ent[2] = {e1a, e1b}; rb_stage<1, 2, BWD>(c, ent); }
     PROBE(2);
-    // ================= stage 2: region 14x14 (7 M-tiles) =====================================================
-    {
-        f32x16 acc[2];
-        const int mt1 = wave + 4 < 7 ? wave + 4 : 6;
-        RbTile tl[2] = {rb_tile<2>(wave, i), rb_tile<2>(mt1, i)};
-        const RbPix p0 = rb_pix<2>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<2>(mt1, i, n, ty0, tx0, H, W);
-        if (BWD) { rb_load_mask<2>(d, p0, g, mk0); rb_load_mask<2>(d, p1, g, mk1); }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        if (BWD) { RB_CF(2, 1, 0, 2, acc) RB_C(2, 0, 0, 2, acc) RB_C(2, 0, 1, 2, acc) }
-        else     { RB_CF(2, 0, 0, 2, acc) RB_C(2, 0, 1, 2, acc) RB_C(2, 1, 0, 2, acc) }
-        rb_store_slice<2, BWD>(acc[0], p0, bias_lds + 32, mk0, smem, g);
-        if (wave + 4 < 7) rb_store_slice<2, BWD>(acc[1], p1, bias_lds + 32, mk1, smem, g);
-    }
+    if (wave < 3) { const int ent[2] = {e2a, e2b}; rb_stage<2, 2, BWD>(c, ent); }
+    else          { const int ent[1] = {e2a};      rb_stage<2, 1, BWD>(c, ent); }
     PROBE(3);
-    // ================= stage 3: region 12x12 (5 M-tiles: wave 0 owns tiles 0 and 4) ===========================
-    {
-        f32x16 acc[2];
-        RbTile tl[2] = {rb_tile<3>(wave, i), rb_tile<3>(4, i)};
-        const RbPix p0 = rb_pix<3>(wave, i, n, ty0, tx0, H, W), p1 = rb_pix<3>(4, i, n, ty0, tx0, H, W);
-        if (BWD) { rb_load_mask<3>(d, p0, g, mk0); rb_load_mask<3>(d, p1, g, mk1); }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        if (BWD) { RB_CF(3, 2, 0, 2, acc) RB_C(3, 1, 0, 2, acc) RB_C(3, 0, 0, 2, acc) RB_C(3, 0, 1, 2, acc) }
-        else     { RB_CF(3, 0, 0, 2, acc) RB_C(3, 0, 1, 2, acc) RB_C(3, 1, 0, 2, acc) RB_C(3, 2, 0, 2, acc) }
-        rb_store_slice<3, BWD>(acc[0], p0, bias_lds + 64, mk0, smem, g);
-        if (wave == 0) rb_store_slice<3, BWD>(acc[1], p1, bias_lds + 64, mk1, smem, g);
-    }
+    if (wave == 0) { const int ent[2] = {e3a, e3b}; rb_stage<3, 2, BWD>(c, ent); }
+    else           { const int ent[1] = {e3a};      rb_stage<3, 1, BWD>(c, ent); }
     PROBE(4);
-    // ================= stage 4: region 10x10 (4 M-tiles, one per wave) ========================================
-    {
-        f32x16 acc[1];
-        RbTile tl[1] = {rb_tile<4>(wave, i)};
-        const RbPix p0 = rb_pix<4>(wave, i, n, ty0, tx0, H, W);
-        if (BWD) rb_load_mask<4>(d, p0, g, mk0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-        if (BWD) { RB_CF(4, 3, 0, 1, acc) RB_C(4, 2, 0, 1, acc) RB_C(4, 1, 0, 1, acc) RB_C(4, 0, 0, 1, acc) RB_C(4, 0, 1, 1, acc) }
-        else     { RB_CF(4, 0, 0, 1, acc) RB_C(4, 0, 1, 1, acc) RB_C(4, 1, 0, 1, acc) RB_C(4, 2, 0, 1, acc) RB_C(4, 3, 0, 1, acc) }
-        rb_store_slice<4, BWD>(acc[0], p0, bias_lds + 96, mk0, smem, g);
-    }
+    { const int ent[1] = {e4}; rb_stage<4, 1, BWD>(c, ent); }
     PROBE(5);
-    // ================= stage 5: 8x8 core (2 M-tiles) x 64 channels: wave = (M-tile mt, k-substep kh); the 12 slabs
-    //                   (6 chunks x 2 N-tiles) stream through the same ring; halves are combined through LDS ======
+    // ================= stage 5: 8x8 core (2 M-tiles) x 64 channels: wave = (M-tile mt, N-tile nt); the 12 slabs
+    //                   (6 chunks x 2 channel halves, all 64 output channels each) stream through the same ring ======
     {
-        const int mt = wave & 1, kh = wave >> 1;
-        f32x16 acc0[1], acc1[1];                               // N-tile 0 / 1
-        RbTile tl[1] = {rb_tile<5>(mt, i)};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[0][r] = 0.f; acc1[0][r] = 0.f; }
+        const int nt = wave >> 1;
+        f32x16 acc[1];
+        const int cy = e5 & 31, cx = (e5 >> 5) & 31;           // this lane's core pixel (always valid: 2 x 32 = 64)
+        const int po[1] = {(cy * RB_PITCH + cx) * RB_AROW};
+        // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
+        // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
+        //                 + beta1*d_out + beta2*d_out_rrdb
+        // (alpha5 multiplies the bias too: the accumulator starts at b5 and is scaled as a whole)
+        rb_acc_init<BWD>(acc[0], bias_lds + 128 + nt * 32, g);
         // residual r2 (x_rrdb / d out_rrdb): this lane's pixel, 16 channels = four 8-byte loads, issued now and
         // consumed in the epilogue
-        const int nt = kh;                                     // k-half kh finishes N-tile kh
-        const int q = 32 * mt + i, cy = q >> 3, cx = q & 7;    // this lane's core pixel
         const int iy = ty0 + cy, ix = tx0 + cx;
         const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
-        bf16x4v r2v[4];
+        u32x2v r2v[4];
         if (r2p) {
             const __bf16* rp = r2p + ((size_t)(n * H + min(iy, H - 1)) * W + min(ix, W - 1)) * d.r2.cs + d.r2.coff +
                                nt * 32 + 4 * g;
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const bf16x4v*>(rp + 8 * q4);
+            for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const u32x2v*>(rp + 8 * q4);
         }
-#define RB_C5(S, PLANE, FLUSH)                                                                                  \
-        { RB_STEP(); if (FLUSH) rb_flush_core<4, BWD>(d, smem, n, ty0, tx0, tid);                                \
-          rb_contract<5, S, 1, 1>(acc0, tl, smem, slab, PLANE, i, g, kh); }                                      \
-        { RB_STEP(); rb_contract<5, S, 1, 1>(acc1, tl, smem, slab, PLANE, i, g, kh); }
-        if (BWD) { RB_C5(4, 0, 1) RB_C5(3, 0, 0) RB_C5(2, 0, 0) RB_C5(1, 0, 0) RB_C5(0, 0, 0) RB_C5(0, 1, 0) }
-        else     { RB_C5(0, 0, 1) RB_C5(0, 1, 0) RB_C5(1, 0, 0) RB_C5(2, 0, 0) RB_C5(3, 0, 0) RB_C5(4, 0, 0) }
-#undef RB_C5
+        static_for<0, 12>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, j = t / 2, h = t % 2;
+            constexpr int S = j < 2 ? 0 : j - 1, PL = j < 2 ? j : 0;
+            if constexpr (t == 10) {
+                rb_wait_ge(ctl + CTL_SLICE + 4, 4);
+                rb_flush_core<4, BWD>(d, smem, n, ty0, tx0, tid);
+            }
+            const char* slab = rb_acquire(c, 14 + t);
+            rb_contract5<S>(acc[0], po[0], smem, slab, PL, h, nt, i, g, [&] { rb_handover(c, 14 + t); });
+        });
         PROBE(6);
-        RB_BAR();   // ring is free: reduce scratch [2 mt][16][64] floats + output transpose slabs
-        // k-half kh = 0 finishes N-tile 0, kh = 1 finishes N-tile 1 (each needs the other's partial of its tile)
-        float* mine = reinterpret_cast<float*>(ring) + (mt * 16) * 64 + lane;
-        if (kh == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r * 64] = acc1[0][r];
-        }
-        RB_BAR();
-        if (kh == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[0][r] += mine[r * 64];
-        }
-        RB_BAR();
-        if (kh == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r * 64] = acc0[0][r];
-        }
-        RB_BAR();
-        if (kh == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[0][r] += mine[r * 64];
-        }
-        // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
-        // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
-        //                 + beta1*d_out + beta2*d_out_rrdb
+        if (lane == 0) __atomic_fetch_add(ctl + CTL_SLICE + 5, 1, __ATOMIC_RELAXED);
+        rb_wait_ge(ctl + CTL_SLICE + 5, 4);   // every wave is finished with the ring: it becomes the output transpose slabs
         {
-            const int p0 = (cy + 5) * 18 + cx + 5;
-            const char* xrow = smem + RB_X0 + nt * RB_X0P + p0 * RB_AROW + g * 8;
-            const float* b5 = bias_lds + 128 + nt * 32;
-            __bf16* slabw = reinterpret_cast<__bf16*>(ring + 2 * 16 * 64 * 4 + wave * 2048);   // [32 px][32 co] bf16
+            const char* xrow = smem + RB_X0 + nt * RB_X0P + ((cy + 5) * RB_PITCH + cx + 5) * RB_AROW + g * 8;
+            __bf16* slabw = reinterpret_cast<__bf16*>(ring + wave * 2048);   // [32 px][32 co] bf16
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(b5 + 8 * q4 + 4 * g);
-                const bf16x4v xv = *reinterpret_cast<const bf16x4v*>(xrow + 16 * q4);
+                const u32x2v xw = *reinterpret_cast<const u32x2v*>(xrow + 16 * q4);
+                const float xv[4] = {bf_lo(xw[0]), bf_hi(xw[0]), bf_lo(xw[1]), bf_hi(xw[1])};
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r2p) { rv[0] = bf_lo(r2v[q4][0]); rv[1] = bf_hi(r2v[q4][0]); rv[2] = bf_lo(r2v[q4][1]); rv[3] = bf_hi(r2v[q4][1]); }
                 bf16x4v o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float a = kh == 0 ? acc0[0][4 * q4 + e] : acc1[0][4 * q4 + e];
-                    float v = d.alpha5 * (a + bq[e]) + d.beta1 * (float)xv[e];
-                    if (r2p) v += d.beta2 * (float)r2v[q4][e];
+                    float v = d.alpha5 * acc[0][4 * q4 + e] + d.beta1 * xv[e];
+                    if (r2p) v += d.beta2 * rv[e];
                     o[e] = (__bf16)v;
                 }
                 *reinterpret_cast<bf16x4v*>(slabw + i * 32 + 8 * q4 + 4 * g) = o;
             }
-            // the wave's 32 px x 64 B tile -> 128 16-byte vectors: 2 per lane
+            // the wave's 32 px x 64 B tile -> 128 16-byte vectors: 2 per lane (row = the lane of the M-tile that owns it)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int v = h * 64 + lane;
-                const int pix = v >> 2, part = v & 3;
-                const int qq = 32 * mt + pix, oy = ty0 + (qq >> 3), ox = tx0 + (qq & 7);
-                const u32x4 val = *reinterpret_cast<const u32x4*>(slabw + pix * 32 + part * 8);
+                const int row = v >> 2, part = v & 3;
+                const int es = h ? e5s1 : e5s0;
+                const int oy = ty0 + (es & 31), ox = tx0 + ((es >> 5) & 31);
+                const u32x4 val = *reinterpret_cast<const u32x4*>(slabw + row * 32 + part * 8);
                 if (oy < H && ox < W) {
                     __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * H + oy) * W + ox) * d.out.cs +
                                   d.out.coff + nt * 32 + part * 8;
@@ -435,10 +579,6 @@ __global__ __launch_bounds__(320) void rdb_kernel(const ssr_rdb_desc d) {
         }
     }
     PROBE(7);
-#undef RB_STEP
-#undef RB_C
-#undef RB_CF
-#undef RB_BAR
 }
 
 }  // namespace
@@ -462,8 +602,8 @@ static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
         attr_done[bwd] = true;
     }
     const int tiles = d.N * ((d.H + 7) / 8) * ((d.W + 7) / 8);
-    if (bwd) hipLaunchKernelGGL(rdb_kernel<true>, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
-    else hipLaunchKernelGGL(rdb_kernel<false>, dim3(tiles), dim3(320), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    if (bwd) hipLaunchKernelGGL(rdb_kernel<true>, dim3(tiles), dim3(RB_NTHREADS), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    else hipLaunchKernelGGL(rdb_kernel<false>, dim3(tiles), dim3(RB_NTHREADS), RB_LDS, reinterpret_cast<hipStream_t>(stream), d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }

@@ -108,6 +108,7 @@ class ParamStore:
                                   pd.data_ptr() if s.dgrad_packed else None,
                                   s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d))
         self._pack_items = items
+        self.repacked: Dict[Tuple[str, int], torch.Tensor] = {}
         # gathered dense-block dgrad weights (filled by add_rdb_gather)
         self.gather: Dict[Tuple[str, int], torch.Tensor] = {}
         self.gather_rows: Dict[Tuple[str, int], int] = {}
@@ -182,14 +183,43 @@ class ParamStore:
             hip.check(hip.lib().ssr_pack_dgrad_gather(self.seg_table.data_ptr(), len(self._seg_items), self.dtype,
                                                       hip.stream_ptr()), "ssr_pack_dgrad_gather")
 
-    def add_rdb_gather(self, prefix: str, nf: int, gc: int, a5: float):
+    def add_repack(self, name: str, ck: int) -> torch.Tensor:
+        """An extra forward packing [K chunk of `ck`][tap][CoutPad][ck] of layer `name` (refreshed by pack() like the
+        default one).  The fused dense-block kernel streams conv5 in 16-channel chunks (csrc/rdb_fwd.hip)."""
+        key = (name, ck)
+        if key in self.repacked:
+            return self.repacked[key]
+        s = self.specs[name]
+        cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck)
+        buf = torch.zeros(s.k * s.k * cout_pad * cin_pad, dtype=hip.torch_dtype(self.dtype), device=self.device)
+        woff, _ = self.offsets[name + (".weight_orig" if s.sn else ".weight")]
+        inv = (self.sigma.data_ptr() + 4 * self.sn_names.index(name)) if s.sn else None
+        self._pack_items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, buf.data_ptr(), None, s.cout, s.cin, s.k, s.k,
+                                         s.stride, cout_pad, cin_pad, rup(s.cin, 32), rup(rup(s.cout, 8), ck), ck, ck))
+        self.pack_table = hip.device_table(self._pack_items)
+        self.repacked[key] = buf
+        return buf
+
+    def add_rdb_gather(self, prefix: str, nf: int, gc: int, a5: float, ck0: int = 0):
         """Packed weights of the gather-form backward of one ResidualDenseBlock (rrdbnet_arch.py:37-44):
         slice k (0: the 64-ch block input, 1..4: x1..x4) <- conv3x3 over [dpre_{k+1}..dpre_4 | d_out],
-        conv5's part pre-scaled by a5 (0.2, or 0.04 inside the third RDB: :44,:68)."""
+        conv5's part pre-scaled by a5 (0.2, or 0.04 inside the third RDB: :44,:68).  ck0 > 0 adds a second packing of
+        slice 0 in K chunks of ck0 (key (prefix, 'k0', ck0)) for the fused backward kernel."""
+        tdt = hip.torch_dtype(self.dtype)
+        if ck0 and (prefix, "k0", ck0) not in self.gather:
+            K = 4 * gc + nf
+            rows_pad, kpad = rup(nf, 32), rup(K, ck0)
+            buf = torch.zeros(kpad * 9 * rows_pad, dtype=tdt, device=self.device)
+            self.gather[(prefix, "k0", ck0)] = buf
+            for jj in range(1, 6):
+                cout_j = nf if jj == 5 else gc
+                self._seg_items.append(hip.PackSeg(self.ptr(f"{prefix}.conv{jj}.weight"), buf.data_ptr(),
+                                                   a5 if jj == 5 else 1.0, cout_j, nf + (jj - 1) * gc, 0, nf,
+                                                   (jj - 1) * gc, rows_pad, ck0))
+            self.seg_table = None
         if (prefix, 0) in self.gather:
             return
         ck = hip.lib().ssr_conv2d_ck(self.dtype, 3)
-        tdt = hip.torch_dtype(self.dtype)
         for k in range(5):
             nout = nf if k == 0 else gc
             ci0 = 0 if k == 0 else nf + (k - 1) * gc
@@ -470,6 +500,7 @@ class GeneratorPlan:
                 for k in range(5):
                     rd.w[k] = store.packed_fwd[f"{p}.conv{k + 1}"].data_ptr()
                     rd.bias[k] = store.ptr(f"{p}.conv{k + 1}.bias")
+                rd.w[4] = store.add_repack(f"{p}.conv5", 16).data_ptr()   # conv5 streams in 16-channel half chunks
                 if j < 2:
                     rd.alpha5, rd.beta1, rd.r2, rd.beta2 = 0.2, 1.0, hip.NULL_VIEW, 0.0
                 else:
@@ -554,12 +585,13 @@ class GeneratorPlan:
                 rr = 3 * i + 2
                 d_rrdb = view(self.g_body_out) if rr == n_rdb - 1 else view(self.dbufs[rr + 1], 0)
                 a5, b5 = 0.2, 1.0
-            store.add_rdb_gather(p, nf, gc, a5)
+            fused_bwd = self.fused_rdb and os.environ.get("SSR_FUSED_RDB_BWD", "1") != "0"
+            store.add_rdb_gather(p, nf, gc, a5, ck0=16 if fused_bwd else 0)
             add_wg(f"{p}.conv5", view(cur, 0), d_out_r, H, W, 1, H, W, alpha=a5, cin=cd)
             for k in (4, 3, 2, 1):
                 add_wg(f"{p}.conv{k}", view(cur, 0), view(dcur, nf + (k - 1) * gc), H, W, 1, H, W,
                        cin=nf + (k - 1) * gc)
-            if self.fused_rdb and os.environ.get("SSR_FUSED_RDB_BWD", "1") != "0":
+            if fused_bwd:
                 # one launch for the whole dense-block backward (csrc/rdb_fwd.hip, rdb_kernel<true>)
                 rd = hip.RdbDesc()
                 rd.dtype, rd.N, rd.H, rd.W = self.dt, B, H, W
@@ -567,6 +599,7 @@ class GeneratorPlan:
                 for jj in range(5):
                     rd.w[jj] = store.gather[(p, 4 - jj)].data_ptr()
                     rd.bias[jj] = None
+                rd.w[4] = store.gather[(p, "k0", 16)].data_ptr()   # slice 0 streams in 16-channel half chunks
                 rd.alpha5, rd.beta1 = 1.0, b5
                 rd.r2, rd.beta2 = (d_rrdb, 1.0) if j == 0 else (hip.NULL_VIEW, 0.0)
                 self._rdb_descs.append(rd)

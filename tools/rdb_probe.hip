@@ -35,8 +35,8 @@ int main(int argc, char** argv) {
     const char* names[] = {"", "issue x + slab0", "conv1", "conv2", "conv3", "conv4", "conv5 mfma", "conv5 epilogue"};
     for (int k = 1; k < 8; ++k) printf("  %-18s %10.1f ticks avg\n", names[k], ph[k] / nblk);
     double q[16] = {0};
-    for (int b = 0; b < nblk; ++b) for (int k = 8; k < 14; ++k) q[k] += double(h[b * 16 + k] - h[b * 16 + (k == 8 ? 1 : k - 1)]);
-    const char* n2[] = {"stage1 setup", "barrier1", "contract1", "barrier2", "contract2", "store slice"};
+    for (int b = 0; b < nblk; ++b) for (int k = 8; k < 14; ++k) q[k] += double(h[b * 16 + k] - h[b * 16 + (k == 8 ? 5 : k - 1)]);
+    const char* n2[] = {"c5 setup+acq0", "contract0", "rel+acq1", "contract1", "rel+acq2", "contract2"};
     for (int k = 8; k < 14; ++k) printf("    %-12s %9.1f\n", n2[k - 8], q[k] / nblk);
     return 0;
 }

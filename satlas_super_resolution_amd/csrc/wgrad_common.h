@@ -3,8 +3,8 @@
 #include "common.h"
 
 constexpr int WG_TH = 8, WG_TW = 16;   // pixel tile of one wgrad step (fp32 kernels)
-// bf16 kernels: 16 rows for 3x3 layers (4 k-steps per wave per barrier), 8 for the 4x4 stride-2 layers (LDS)
-constexpr int wgrad_bf16_th(int KH) { return KH == 3 ? 8 : 8; }   // 16 rows measured slower for 3x3 (r01: 1.81 -> 2.23 ms)
+// bf16 kernels: 16 rows for 3x3 layers (4 k-steps per MFMA wave per ring hand-over), 8 for the 4x4 stride-2 layers (LDS)
+constexpr int wgrad_bf16_th(int KH) { return KH == 3 ? 16 : 8; }
 
 // Write the per-wave accumulators D[row = co][col = ci] (32x32 MFMA C layout) of all taps to
 // dW[co][ci][ky][kx] (fp32, OIHW).  3x3: the 4 waves hold partial sums over different pixels -> reduce

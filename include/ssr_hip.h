@@ -90,7 +90,7 @@ typedef struct ssr_conv_desc {
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
 /* test / tuning hook: force a kernel family. 0 = automatic (ssr_conv2d), 1 = weight-stationary persistent
  * kernel (SSR_EUNSUP if the descriptor does not fit it), 2 = skip it (K-resident or pipelined kernel),
- * 3 = pipelined kernel only. */
+ * 3 = pipelined kernel only, 4 = big-tile kernel (32x16 pixels x 64 channels per workgroup; SSR_EUNSUP if unfit). */
 int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
 /* Which kernel instantiation ssr_conv2d dispatches this descriptor to, encoded as
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
@@ -120,6 +120,11 @@ typedef struct ssr_rdb_desc {
     float alpha5, beta1;
     ssr_view r2;
     float beta2;
+    /* optional L2 warm-up: the five weight arrays of the NEXT launch on this stream (NULL / 0 = none).  Every block
+     * touches its share of the lines of its own XCD's L2 while it computes, so that the next dense block's weight
+     * stream (479 KB, re-read by all 256 blocks) hits L2 instead of the Infinity Cache / HBM. */
+    const void* w_next[5];
+    int32_t w_next_bytes[5];
 } ssr_rdb_desc;
 int ssr_rdb_forward(const ssr_rdb_desc* d, void* stream);
 int ssr_rdb_backward(const ssr_rdb_desc* d, void* stream);

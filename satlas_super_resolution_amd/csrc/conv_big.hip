@@ -1,0 +1,366 @@
+// Big-tile 3x3 stride-1 convolution for the wide U-Net discriminator layers (bf16, Cin >= 64, CoutPad % 64 == 0).
+//
+// The generic kernel (conv.hip) gives a workgroup 128 pixels x 64 output channels: per 32-channel chunk it stages
+// an 11.5 KB input patch and a 36.9 KB weight slab, i.e. every 128 pixels re-read the weights (conv6 forward at
+// 128x128, B = 16: 300 MB of weight traffic against 94 MB of activations), each wave fetches 12 KB per 1152 cycles of
+// MFMAs — twice what a wave can pull (~6.4 B/clk, tools/l2_probe.hip) — and needs 1.5 LDS operand reads per MFMA.
+// rocprofv3 r01: 400..630 TFLOP/s on conv4/5/6 and their dgrads.
+// Here a workgroup (4 waves, one per SIMD, the whole register file) owns 32 x 16 pixels x 64 output channels:
+//   * register tiling 4 pixel tiles x 2 channel tiles per wave (8 accumulators): 6 operand reads feed 8 MFMAs
+//     (0.75 per MFMA) and the weight slab is amortised over 512 pixels;
+//   * per 32-channel chunk: 49 KB patch + 46 KB weights in ONE LDS stage (80-byte padded rows), the next chunk
+//     waits in registers (19 x 16 B per lane) while 144 MFMAs per wave run: 4.1 B/clk per wave;
+//   * lane i of a pixel tile owns pixel (row i >> 4, column i or (i + 14) & 15 for the second row): rows are distinct
+//     mod 16 inside the hardware's 16-lane read groups for every tap -> conflict-free ds_read_b128 (pitch 18);
+//   * operands swapped (A = weights, B = pixels): a lane ends with ONE pixel x 16 channels per channel tile; the
+//     epilogue is pixel-per-lane, branch-free per feature set (template), outputs leave as 16-byte vectors.
+// Same descriptor and epilogue contract as conv.hip (ssr_conv_desc).
+//
+// Replaces nn.Conv2d 3x3 forward / dgrad at /root/reference/ssr/archs/discriminator_arch.py:35-37,55,59,63
+// (conv4, conv5, conv6 and the dgrads of conv4..conv6) when the pixel count fills the chip.
+#include "common.h"
+#include <cstdlib>
+
+#ifdef SSR_PROBE   // tools/big_probe.hip
+#define BPROBE(k) do { if (threadIdx.x == 0) g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BPROBE_C(k) do { if (threadIdx.x == 0 && c == 1) g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BPROBE(k)
+#define BPROBE_C(k)
+#endif
+
+namespace {
+
+constexpr int CB_TH = 32, CB_TW = 16, CB_PH = CB_TH + 2, CB_PW = CB_TW + 2, CB_NPIX = CB_PH * CB_PW;   // 612
+constexpr int CB_AROW = 80;                                  // bytes per LDS row: 32 bf16 + 16 pad
+constexpr int CB_PATCH = CB_NPIX * CB_AROW;                  // 48,960
+constexpr int CB_WROWS = 9 * 64;
+constexpr int CB_WBYTES = CB_WROWS * CB_AROW;                // 46,080
+constexpr int CB_BIAS = CB_PATCH + CB_WBYTES;                // 64 floats
+constexpr int CB_LDS = CB_BIAS + 256;
+constexpr int CB_NPV = (CB_NPIX * 4 + 255) / 256;            // 10 patch vectors per thread
+constexpr int CB_NWV = CB_WROWS * 4 / 256;                   // 9 weight vectors per thread
+static_assert(CB_NPV + CB_NWV == 19, "19 staging vectors per thread: one per k-step + one");
+static_assert(CB_LDS <= 160 * 1024 && 4 * 32 * 64 * 2 <= CB_PATCH, "LDS budget / output slabs fit in the patch area");
+
+constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_GENERIC = -1;
+typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cb_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float cb_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// pixel of lane-slot s (0..31) of pixel tile m of wave w: tile rows 8w + 2m, 8w + 2m + 1
+__device__ __forceinline__ void cb_pixel(int w, int m, int s, int& row, int& col) {
+    row = 8 * w + 2 * m + (s >> 4);
+    col = s < 16 ? s : ((s + 14) & 15);
+}
+
+template <int EP>
+__global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int tiles_x = (d.Gw + CB_TW - 1) / CB_TW, tiles_y = (d.Gh + CB_TH - 1) / CB_TH;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * CB_TH, gx0 = tx_i * CB_TW;
+    const int co0 = blockIdx.y * 64;
+    const int upshift = d.up == 2 ? 1 : 0;
+    const int LH = d.Hi << upshift, LW = d.Wi << upshift;
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
+    const int nchunks = (d.Cin + 31) / 32;
+    const size_t wchunk = (size_t)9 * d.CoutPad * 32;
+
+    float* bias_lds = reinterpret_cast<float*>(smem + CB_BIAS);
+    if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
+
+    // ---- staging descriptors (independent of the chunk) ----
+    int pgo[CB_NPV], plo[CB_NPV], wgo[CB_NWV], wlo[CB_NWV];
+#pragma unroll
+    for (int q = 0; q < CB_NPV; ++q) {
+        const int v = tid + q * 256;
+        const int pix = v >> 2, part = v & 3;
+        const int py = pix / CB_PW, px = pix - py * CB_PW;
+        const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+        const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+        pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
+        plo[q] = v < CB_NPIX * 4 ? pix * CB_AROW + part * 16 : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < CB_NWV; ++q) {
+        const int v = tid + q * 256;
+        const int row = v >> 2, part = v & 3;                  // row = tap*64 + co
+        wgo[q] = ((row >> 6) * d.CoutPad + co0 + (row & 63)) * 32 + part * 8;
+        wlo[q] = CB_PATCH + row * CB_AROW + part * 16;
+    }
+    u32x4 rp[CB_NPV], rw[CB_NWV];
+    // one staging load (vector j of the 19 per thread).  A wave that issues its loads back to back sits in the issue
+    // of each one until the previous has drained (~170 cycles per 1-KiB instruction: the ~6.4 B/clk per-wave limit of
+    // tools/l2_probe.hip) and cannot issue MFMAs meanwhile, so the loads of chunk c+1 are sprinkled over the k-steps
+    // of chunk c, one per step.
+    auto load_one = [&](int c, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int c0 = c * 32;
+        if constexpr (j < CB_NPV) {
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[j] + c0);
+            rp[j] = val;
+        } else {
+            rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
+        }
+    };
+    auto load_chunk = [&](int c) { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(c, jc); }); };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int q = 0; q < CB_NPV; ++q)
+            if (plo[q] >= 0) *reinterpret_cast<u32x4*>(smem + plo[q]) = rp[q];
+#pragma unroll
+        for (int q = 0; q < CB_NWV; ++q) *reinterpret_cast<u32x4*>(smem + wlo[q]) = rw[q];
+    };
+
+    // ---- this lane's pixels (one per pixel tile) ----
+    int a_off[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        int row, col;
+        cb_pixel(wave, m, i, row, col);
+        a_off[m] = (row * CB_PW + col) * CB_AROW + g * 16;
+    }
+    const int b_off = CB_PATCH + i * CB_AROW + g * 16;
+    const int co_l = 4 * g;                                   // + 8*q4 + e: this lane's 16 channels of a channel tile
+
+    BPROBE(0);
+    load_chunk(0);
+    __syncthreads();                                          // bias table
+    BPROBE(1);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = EP >= 0 ? bq[e] : 0.f;       // lean variants: accumulators start at the bias
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m][t][4 * q4 + e] = v0;
+            }
+        }
+
+    for (int c = 0; c < nchunks; ++c) {
+        BPROBE_C(2);
+        if (c > 0) __syncthreads();                           // everyone is finished reading the previous chunk
+        BPROBE_C(3);
+        store_chunk();
+        BPROBE_C(4);
+        __syncthreads();
+        BPROBE_C(5);
+        const bool has_next = c + 1 < nchunks;
+        // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
+        // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
+        constexpr int NSTEP = 18, CB_PF = 2;
+        u32x4 wq[NSTEP][2], pq[NSTEP][4];
+        auto issue = [&](auto sc) {
+            constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                wq[s_][t] = *reinterpret_cast<const u32x4*>(smem + b_off + (tap * 64 + t * 32) * CB_AROW + kk * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                pq[s_][m] = *reinterpret_cast<const u32x4*>(smem + a_off[m] + ((tap / 3) * CB_PW + tap % 3) * CB_AROW + kk * 32);
+        };
+        static_for<0, CB_PF>([&](auto sc) { issue(sc); });
+        static_for<0, NSTEP>([&](auto sc) {
+            constexpr int s_ = decltype(sc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s_ + CB_PF < NSTEP) issue(std::integral_constant<int, s_ + CB_PF>{});
+            if (has_next) {
+                load_one(c + 1, std::integral_constant<int, s_>{});
+                if constexpr (s_ == NSTEP - 1) load_one(c + 1, std::integral_constant<int, NSTEP>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) mma16<__bf16>(acc[m][t], wq[s_][t], pq[s_][m]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        BPROBE_C(6);
+    }
+    BPROBE(7);
+    __syncthreads();                                          // patch area becomes the output transpose slabs
+
+    // ---- epilogue: per pixel tile m this lane = one pixel x (2 x 16) channels ----
+    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
+    __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
+    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
+    const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
+    const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
+    __bf16* slab = reinterpret_cast<__bf16*>(smem) + wave * (32 * 64);   // [32 lane-slots][64 co]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        int row, col;
+        cb_pixel(wave, m, i, row, col);
+        const int gy = gy0 + row, gx = gx0 + col;
+        const bool pvalid = gy < d.Gh && gx < d.Gw;
+        const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
+        const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
+        if constexpr (EP >= 0) {
+            u32x2c q1[8], qa[8], qm[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = co0 + t * 32 + 8 * q4 + co_l;
+                    const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
+                    if constexpr ((EP & CB_R1) != 0) q1[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                    if constexpr ((EP & CB_ACC) != 0) qa[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(yp + pp * d.y.cs + d.y.coff + cc);
+                    if constexpr ((EP & CB_MASK) != 0) qm[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(mp + pp * d.m.cs + d.m.coff + cc);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[m][t][4 * q4 + e];
+                        if constexpr ((EP & CB_LRELU) != 0) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu()
+                    }
+                    if constexpr ((EP & CB_R1) != 0) {
+                        const u32x2c r = q1[t * 4 + q4];
+                        v[0] += d.beta1 * cb_lo(r[0]); v[1] += d.beta1 * cb_hi(r[0]);
+                        v[2] += d.beta1 * cb_lo(r[1]); v[3] += d.beta1 * cb_hi(r[1]);
+                    }
+                    if constexpr ((EP & CB_ACC) != 0) {
+                        const u32x2c r = qa[t * 4 + q4];
+                        v[0] += cb_lo(r[0]); v[1] += cb_hi(r[0]); v[2] += cb_lo(r[1]); v[3] += cb_hi(r[1]);
+                    }
+                    if constexpr ((EP & CB_MASK) != 0) {
+                        const u32x2c r = qm[t * 4 + q4];
+                        v[0] *= lrelu_grad_from_out(cb_lo(r[0])); v[1] *= lrelu_grad_from_out(cb_hi(r[0]));
+                        v[2] *= lrelu_grad_from_out(cb_lo(r[1])); v[3] *= lrelu_grad_from_out(cb_hi(r[1]));
+                    }
+                    bf16x4c o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4c*>(slab + i * 64 + t * 32 + 8 * q4 + co_l) = o;
+                }
+        } else {
+            // generic epilogue: the full ssr_conv_desc contract with run-time flags
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x4c q1g[4], q2g[4], qag[4], qmg[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = co0 + t * 32 + 8 * q4 + co_l;
+                    const int cc = c < d.Cout ? c : 0;
+                    if (r1p) q1g[q4] = *reinterpret_cast<const bf16x4c*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                    if (r2p) q2g[q4] = *reinterpret_cast<const bf16x4c*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
+                    if (d.accumulate) qag[q4] = *reinterpret_cast<const bf16x4c*>(yp + pp * d.y.cs + d.y.coff + cc);
+                    if (mp) qmg[q4] = *reinterpret_cast<const bf16x4c*>(mp + pp * d.m.cs + d.m.coff + cc);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = co0 + t * 32 + 8 * q4 + co_l;
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
+                    bf16x4c o0, o1, o2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[m][t][4 * q4 + e] + bq[e];
+                        if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+                        v *= d.alpha;
+                        o0[e] = (__bf16)v;
+                        if (r1p) v += d.beta1 * (float)q1g[q4][e];
+                        if (r2p) v += d.beta2 * (float)q2g[q4][e];
+                        if (d.accumulate) v += (float)qag[q4][e];
+                        o1[e] = (__bf16)v;
+                        if (mp) v *= lrelu_grad_from_out((float)qmg[q4][e]);
+                        o2[e] = (__bf16)v;
+                    }
+                    if (pvalid && c < d.Cout) {
+                        if (y0p) *reinterpret_cast<bf16x4c*>(y0p + pp * d.y0.cs + d.y0.coff + c) = o0;
+                        if (y1p) *reinterpret_cast<bf16x4c*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
+                    }
+                    *reinterpret_cast<bf16x4c*>(slab + i * 64 + t * 32 + 8 * q4 + co_l) = o2;
+                }
+            }
+        }
+        // the wave's [32 px][64 co] slab -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int v = h * 64 + lane;
+            const int s_ = v >> 3, part = v & 7;
+            int prow, pcol;
+            cb_pixel(wave, m, s_, prow, pcol);
+            const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(slab + s_ * 64 + part * 8);
+            if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+                *reinterpret_cast<u32x4*>(yp + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * d.y.cs +
+                                          d.y.coff + c) = val;
+        }
+    }
+    BPROBE(8);
+}
+
+template <int EP>
+int launch_big(const ssr_conv_desc& d, hipStream_t st) {
+    auto kern = conv_big_kernel<EP>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW);
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, 1), dim3(256), CB_LDS, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+}  // namespace
+
+// everything except the grid-size heuristic (ssr_conv2d_impl(impl = 4) forces this kernel on small shapes)
+bool ssr_conv_big_shape_ok(const ssr_conv_desc& d) {
+    if (d.dtype != SSR_BF16) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p) return false;
+    if (d.Cin < 32 || (d.CoutPad % 64) != 0 || (d.Cout % 8) != 0) return false;
+    if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
+    if (d.r1.p && d.r1_nc < d.Cout) return false;
+    if (d.r2.p && d.r2_nc < d.Cout) return false;
+    if (d.m.p && !(d.m_c0 == 0 && d.m_c1 >= d.Cout)) return false;
+    auto al = [](const ssr_view& v) { return !v.p || ((v.cs % 4) == 0 && (v.coff % 4) == 0 && ((uintptr_t)v.p % 8) == 0); };
+    auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
+    return al16(d.y) && al(d.y0) && al(d.y1) && al(d.r1) && al(d.r2) && al(d.m);
+}
+
+bool ssr_conv_big_qualifies(const ssr_conv_desc& d) {
+    static const bool off = [] { const char* e = getenv("SSR_CONV_BIGTILE"); return e && e[0] == '0'; }();
+    if (off || !ssr_conv_big_shape_ok(d)) return false;
+    if (d.Cin <= 64) return false;                            // weight-stationary kernel (conv_ws.hip) territory
+    const long wgs = (long)d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW) * (d.CoutPad / 64);
+    return wgs >= 128;                                        // at least half the CUs get a 512-pixel tile
+}
+
+bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
+    if (force ? !ssr_conv_big_shape_ok(d) : !ssr_conv_big_qualifies(d)) return false;
+    if (!d.y0.p && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
+        const int ep = (d.act == SSR_ACT_LRELU ? CB_LRELU : 0) | (d.m.p ? CB_MASK : 0) | (d.r1.p ? CB_R1 : 0) |
+                       (d.accumulate ? CB_ACC : 0);
+        switch (ep) {
+            case 0: *rc = launch_big<0>(d, st); return true;
+            case CB_LRELU: *rc = launch_big<CB_LRELU>(d, st); return true;
+            case CB_LRELU | CB_R1: *rc = launch_big<CB_LRELU | CB_R1>(d, st); return true;
+            case CB_MASK: *rc = launch_big<CB_MASK>(d, st); return true;
+            case CB_MASK | CB_ACC: *rc = launch_big<CB_MASK | CB_ACC>(d, st); return true;
+            case CB_MASK | CB_R1: *rc = launch_big<CB_MASK | CB_R1>(d, st); return true;
+            default: break;
+        }
+    }
+    *rc = launch_big<CB_GENERIC>(d, st);
+    return true;
+}

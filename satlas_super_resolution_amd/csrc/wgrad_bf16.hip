@@ -168,7 +168,11 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
 #pragma unroll
             for (int q = 0; q < C::NLV; ++q) {
                 const int v = lt + q * 256;
+#ifndef WG_X_NOWRITE
                 if (v < C::NDYV + C::NXV) *reinterpret_cast<u32x4*>(base + v * 16) = r[q];
+#else
+                if (r[q][0] == 0x12345u) *reinterpret_cast<u32x4*>(base + v * 16) = r[q];
+#endif
             }
             if (do_bias) {
 #pragma unroll
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
         auto issue = [&](auto nc) {
             constexpr int n = decltype(nc)::value, s = n / (1 + NTAP), r = n % (1 + NTAP);
             const int ty = SPLIT_TAPS ? s : NROW * wave + s;
+#ifdef WG_X_NOREAD
+            if constexpr (true) { op[n] = __builtin_bit_cast(bf16x8, u32x4{0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}); (void)ty; } else
+#endif
             if constexpr (r == 0) {
                 const __bf16* ap = ldy + (ty * WG_TW + src_px) * ROW + src_ch;
                 op[n] = tr_pair(ap, ap + 4 * ROW);
@@ -252,7 +259,11 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
                 if (lane == 0) __atomic_store_n(ctl + WGC_DONE + wave, k + 1, __ATOMIC_RELAXED);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef WG_X_NOMFMA
+            if constexpr (r == 1)
+#else
             if constexpr (r != 0)
+#endif
                 acc[r - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[s * (1 + NTAP)], op[n], acc[r - 1], 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);

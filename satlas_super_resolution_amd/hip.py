@@ -52,7 +52,8 @@ class ConvDesc(C.Structure):
 class RdbDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("inp", View), ("slices", View), ("out", View), ("mask", View), ("w", C.c_void_p * 5), ("bias", C.c_void_p * 5),
-                ("alpha5", C.c_float), ("beta1", C.c_float), ("r2", View), ("beta2", C.c_float)]
+                ("alpha5", C.c_float), ("beta1", C.c_float), ("r2", View), ("beta2", C.c_float),
+                ("w_next", C.c_void_p * 5), ("w_next_bytes", C.c_int32 * 5)]
 
 
 class WgradLayer(C.Structure):

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert hip.lib().ssr_conv2d(ctypes.byref(d), None) == -1          # all-zero descriptor -> SSR_EINVAL, no launch
     assert hip.lib().ssr_conv2d_wgrad(None, None, 0, 0, 3, 3, 1, None) == -1
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.F32, 3) == 16 * 4 * 2
-    assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.BF16, 3) == 16 * 4 * 2
+    assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.BF16, 3) == 16 * 2 * 2   # 16x16-pixel tiles
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):

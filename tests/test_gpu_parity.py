@@ -583,3 +583,41 @@ def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
         torch.cuda.synchronize()
         outs[impl] = y.float().cpu()
     assert rel_err(outs[1], outs[3]) < 1e-2, rel_err(outs[1], outs[3])
+
+
+
+@pytest.mark.parametrize("variant", ["lrelu", "lrelu_r1", "mask", "mask_acc", "mask_r1", "plain", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(128, 64, 32, 32, 2), (96, 128, 37, 21, 1), (256, 64, 16, 48, 1)])
+def test_big_tile_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
+    """csrc/conv_big.hip (32x16-pixel x 64-channel workgroup tiles, 4x2 register tiling, rotated lane->pixel map)
+    forced through ssr_conv2d_impl(impl=4) against the pipelined kernel (impl=3) on the same descriptor: every
+    branch-free epilogue instantiation plus the generic one (alpha, both residuals, dual outputs), ragged sizes."""
+    import ctypes as C
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cin + cout + H + len(variant))
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    mk = lambda c: (torch.randn(B, H, W, c, device="cuda") * 0.5).to(tdt).contiguous()
+    xb, r1, r2, m, y_init = mk(cin), mk(cout), mk(cout), mk(cout), mk(cout)
+    outs = {}
+    for impl in (4, 3):
+        y, y0 = y_init.clone(), torch.zeros_like(y_init)
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        kw = dict(act=hip.ACT_LRELU if variant in ("lrelu", "lrelu_r1", "generic") else hip.ACT_NONE, cin=cin)
+        if variant in ("mask_r1", "lrelu_r1", "generic"):
+            kw.update(r1=hip.view(r1), r1_nc=cout, beta1=0.5)
+        if variant == "generic":
+            kw.update(alpha=0.7, y0=hip.view(y0), r2=hip.view(r2), r2_nc=cout, beta2=-0.25)
+        d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), **kw)
+        if variant.startswith("mask") or variant == "generic":
+            d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        if variant in ("mask_acc", "generic"):
+            d.accumulate = 1
+        hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+        torch.cuda.synchronize()
+        outs[impl] = (y.float().cpu(), y0.float().cpu())
+    for a, b, nm in zip(outs[4], outs[3], ("y", "y0")):
+        assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))

@@ -30,57 +30,55 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
+// One thread owns one (output row, k) pair of the packed layout and moves all KH*KW taps of it: the fp32 source
+// taps of a pair are contiguous (36 / 64 bytes) and for a fixed tap consecutive threads write consecutive packed
+// elements.  (r01 rocprofv3: the element-per-thread version with 64-bit div/mod per element and stride-KK gathers
+// took 110 us per launch, 4 launches per step.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restrict__ items) {
     const ssr_pack_item it = items[blockIdx.y];
     const int KK = it.KH * it.KW;
     const float inv = it.inv_scale ? 1.0f / it.inv_scale[0] : 1.0f;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (it.dst_fwd) {   // [chunk][tap][CoutPad][ck]
         T* __restrict__ dst = reinterpret_cast<T*>(it.dst_fwd);
-        const int ck = it.ck_fwd;
-        const long total = (long)KK * it.CoutPad * it.CinPad;
-        for (long e = t0; e < total; e += stride) {
-            const int cc = (int)(e % ck);
-            long q = e / ck;
-            const int co = (int)(q % it.CoutPad); q /= it.CoutPad;
-            const int tap = (int)(q % KK), ci = (int)(q / KK) * ck + cc;
-            float v = 0.f;
-            if (co < it.Cout && ci < it.Cin) v = it.src[((long)co * it.Cin + ci) * KK + tap] * inv;
-            dst[e] = from_f32<T>(v);
+        const int ck = it.ck_fwd, total = it.CoutPad * it.CinPad;
+        for (int t = t0; t < total; t += stride) {
+            const int cc = t % ck, q = t / ck;
+            const int co = q % it.CoutPad, chunk = q / it.CoutPad;
+            const int ci = chunk * ck + cc;
+            const bool ok = co < it.Cout && ci < it.Cin;
+            const float* __restrict__ sp = it.src + ((size_t)co * it.Cin + ci) * KK;
+            T* dp = dst + ((size_t)chunk * KK * it.CoutPad + co) * ck + cc;
+            for (int tap = 0; tap < KK; ++tap) dp[(size_t)tap * it.CoutPad * ck] = from_f32<T>(ok ? sp[tap] * inv : 0.f);
         }
     }
     if (it.dst_dgrad) {
         T* __restrict__ dst = reinterpret_cast<T*>(it.dst_dgrad);
-        const int ck = it.ck_dgrad;
-        if (it.stride == 1) {
-            // Wd[chunk][tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
-            const long total = (long)KK * it.CinPadO * it.CoutPadI;
-            for (long e = t0; e < total; e += stride) {
-                const int cc = (int)(e % ck);
-                long q = e / ck;
-                const int o = (int)(q % it.CinPadO); q /= it.CinPadO;
-                const int tap = (int)(q % KK), k = (int)(q / KK) * ck + cc;
-                float v = 0.f;
-                if (k < it.Cout && o < it.Cin) v = it.src[((long)k * it.Cin + o) * KK + (KK - 1 - tap)] * inv;
-                dst[e] = from_f32<T>(v);
-            }
-        } else {
-            // 4x4 stride-2 transposed conv as four output-parity classes of 2x2 taps:
-            // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x); [cls][chunk][t][o][ck]
-            const long per_cls = (long)4 * it.CinPadO * it.CoutPadI;
-            for (long e = t0; e < 4 * per_cls; e += stride) {
-                const int cls = (int)(e / per_cls);
-                long q = e - cls * per_cls;
-                const int cc = (int)(q % ck); q /= ck;
-                const int o = (int)(q % it.CinPadO); q /= it.CinPadO;
-                const int t = (int)(q & 3), k = (int)(q >> 2) * ck + cc;
-                const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
-                const int ky = py ? 2 - 2 * ty : 3 - 2 * ty, kx = px ? 2 - 2 * tx : 3 - 2 * tx;
-                float v = 0.f;
-                if (k < it.Cout && o < it.Cin) v = it.src[((long)k * it.Cin + o) * 16 + ky * 4 + kx] * inv;
-                dst[e] = from_f32<T>(v);
+        const int ck = it.ck_dgrad, total = it.CinPadO * it.CoutPadI;
+        for (int t = t0; t < total; t += stride) {
+            const int cc = t % ck, q = t / ck;
+            const int o = q % it.CinPadO, chunk = q / it.CinPadO;
+            const int k = chunk * ck + cc;
+            const bool ok = k < it.Cout && o < it.Cin;
+            const float* __restrict__ sp = it.src + ((size_t)k * it.Cin + o) * KK;
+            if (it.stride == 1) {
+                // Wd[chunk][tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
+                T* dp = dst + ((size_t)chunk * KK * it.CinPadO + o) * ck + cc;
+                for (int tap = 0; tap < KK; ++tap)
+                    dp[(size_t)tap * it.CinPadO * ck] = from_f32<T>(ok ? sp[KK - 1 - tap] * inv : 0.f);
+            } else {
+                // 4x4 stride-2 transposed conv as four output-parity classes of 2x2 taps:
+                // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x); [cls][chunk][t][o][ck]
+                const size_t per_cls = (size_t)4 * it.CinPadO * it.CoutPadI;
+                for (int cls = 0; cls < 4; ++cls)
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int py = cls >> 1, px = cls & 1, ty = tt >> 1, tx = tt & 1;
+                        const int ky = py ? 2 - 2 * ty : 3 - 2 * ty, kx = px ? 2 - 2 * tx : 3 - 2 * tx;
+                        dst[cls * per_cls + (((size_t)chunk * 4 + tt) * it.CinPadO + o) * ck + cc] =
+                            from_f32<T>(ok ? sp[ky * 4 + kx] * inv : 0.f);
+                    }
             }
         }
     }
@@ -90,15 +88,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_seg_kernel(const ssr_pack_seg* __restrict__ items) {
     const ssr_pack_seg it = items[blockIdx.y];
     T* __restrict__ dst = reinterpret_cast<T*>(it.dst);
-    const long total = (long)it.Cout * 9 * it.rows_pad;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int kk = (int)(e % it.Cout);          // fastest: consecutive k -> consecutive cc in dst
-        long q = e / it.Cout;
-        const int o = (int)(q % it.rows_pad), tap = (int)(q / it.rows_pad);
+    const int total = it.Cout * it.rows_pad;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int kk = t % it.Cout, o = t / it.Cout;    // fastest: consecutive k -> consecutive cc in dst
         const int k = it.kbase + kk, chunk = k / it.ck, cc = k - chunk * it.ck;
-        float v = 0.f;
-        if (o < it.nci) v = it.scale * it.src[((long)kk * it.Cin + it.ci0 + o) * 9 + (8 - tap)];
-        dst[(((long)chunk * 9 + tap) * it.rows_pad + o) * it.ck + cc] = from_f32<T>(v);
+        const bool ok = o < it.nci;
+        const float* __restrict__ sp = it.src + ((size_t)kk * it.Cin + it.ci0 + o) * 9;
+        T* dp = dst + ((size_t)chunk * 9 * it.rows_pad + o) * it.ck + cc;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) dp[(size_t)tap * it.rows_pad * it.ck] = from_f32<T>(ok ? it.scale * sp[8 - tap] : 0.f);
     }
 }
 

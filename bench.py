@@ -85,6 +85,11 @@ def instrumented_step(ts, args):
                 v = lib.ssr_conv2d_variant(C.byref(d))
                 sym = f"conv_kernel<{args.dtype},K{v // 1000},S{(v // 100) % 10},NT{(v // 10) % 10},W{v % 10}>"
                 fl = conv_flops(d)
+            elif name == "ssr_conv2d_batch":
+                ds, n = a[0], a[1]      # n descriptors of identical geometry in one launch (parity classes of a stride-2 dgrad)
+                v = lib.ssr_conv2d_variant(C.byref(ds[0]))
+                sym = f"conv_kernel4<{args.dtype},K{v // 1000},S{(v // 100) % 10},NT{(v // 10) % 10}>"
+                fl = sum(conv_flops(ds[k]) for k in range(n))
             elif name in ("ssr_rdb_forward", "ssr_rdb_backward"):
                 d = a[0]._obj          # five 3x3 convs of one dense block: K = 64..192 -> N = 32,32,32,32,64
                 sym = "rdb_kernel<%s>" % ("true" if name.endswith("backward") else "false")

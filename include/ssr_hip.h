@@ -88,6 +88,9 @@ typedef struct ssr_conv_desc {
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
+/* n <= 4 descriptors (host array) of identical geometry in ONE launch where the kernel family supports it (the four
+ * output-parity classes of a 4x4 stride-2 dgrad, built by the host as 2x2 stride-1 convolutions); otherwise n launches. */
+int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream);
 /* test / tuning hook: force a kernel family. 0 = automatic (ssr_conv2d), 1 = weight-stationary persistent
  * kernel (SSR_EUNSUP if the descriptor does not fit it), 2 = skip it (K-resident or pipelined kernel),
  * 3 = pipelined kernel only, 4 = big-tile kernel (32x16 pixels x 64 channels per workgroup; SSR_EUNSUP if unfit). */

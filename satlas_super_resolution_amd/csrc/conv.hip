@@ -25,7 +25,7 @@
 namespace {
 
 template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
-__global__ __launch_bounds__(64 * MW * KS) void conv_kernel(const ssr_conv_desc d) {
+__device__ __forceinline__ void conv_body(const ssr_conv_desc& d) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int KSTEPS = (KH == 4) ? 1 : 2;          // 16-byte k-reads per tap per chunk
     constexpr int CK = KSTEPS * 2 * VEC, VPR = 2 * KSTEPS, CKP = CK + VEC, BN = 32 * NT;
@@ -223,6 +223,42 @@ __global__ __launch_bounds__(64 * MW * KS) void conv_kernel(const ssr_conv_desc 
 }
 
 template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
+__global__ __launch_bounds__(64 * MW * KS) void conv_kernel(const ssr_conv_desc d) {
+    conv_body<T, KH, KW, S, NT, MW, KS>(d);
+}
+// up to four descriptors of identical geometry in one launch (blockIdx.z selects): the four output-parity classes of
+// a stride-2 transposed convolution (r01 rocprofv3: 36 launches of 19..24 us per step, each a quarter of the chip)
+struct ssr_conv_desc4 { ssr_conv_desc d[4]; };
+template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
+__global__ __launch_bounds__(64 * MW * KS) void conv_kernel4(const ssr_conv_desc4 p) {
+    conv_body<T, KH, KW, S, NT, MW, KS>(p.d[blockIdx.z]);
+}
+
+template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
+int launch_conv4(const ssr_conv_desc* ds, int n, hipStream_t st) {
+    constexpr int VEC = DT<T>::VEC, KSTEPS = (KH == 4) ? 1 : 2, CK = KSTEPS * 2 * VEC, CKP = CK + VEC, BN = 32 * NT;
+    constexpr int TH = 2 * MW, TW = 16, PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+    constexpr size_t stage = (size_t)(PH * PW + KH * KW * BN) * CKP * sizeof(T);
+    constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
+    constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
+    auto kern = conv_kernel4<T, KH, KW, S, NT, MW, KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    ssr_conv_desc4 p;
+    for (int k = 0; k < 4; ++k) p.d[k] = ds[k < n ? k : 0];
+    const ssr_conv_desc& d = ds[0];
+    const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, n), dim3(64 * MW * KS), lds, st, p);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+template <typename T, int KH, int KW, int S, int NT, int MW, int KS>
 int launch_conv(const ssr_conv_desc& d, hipStream_t st) {
     constexpr int VEC = DT<T>::VEC, KSTEPS = (KH == 4) ? 1 : 2, CK = KSTEPS * 2 * VEC, CKP = CK + VEC, BN = 32 * NT;
     constexpr int TH = 2 * MW, TW = 16, PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
@@ -330,6 +366,40 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
 }
 
 extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) { return conv2d_impl(dp, stream, 0); }
+
+// n (<= 4) descriptors that differ only in pointers / padding / output offsets: one launch when they are 2x2 stride-1
+// bf16 layers of identical geometry (the parity classes of a 4x4 stride-2 dgrad), otherwise n launches.
+extern "C" int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream) {
+    if (!ds || n <= 0 || n > 4) return SSR_EINVAL;
+    bool same = ds[0].dtype == SSR_BF16 && ds[0].KH == 2 && ds[0].KW == 2 && ds[0].stride == 1;
+    for (int k = 1; k < n && same; ++k)
+        same = ds[k].dtype == ds[0].dtype && ds[k].KH == 2 && ds[k].KW == 2 && ds[k].stride == 1 && ds[k].N == ds[0].N &&
+               ds[k].Gh == ds[0].Gh && ds[k].Gw == ds[0].Gw && ds[k].CoutPad == ds[0].CoutPad && ds[k].Cin == ds[0].Cin &&
+               ds[k].Cin2 == ds[0].Cin2 && ds[k].Hi == ds[0].Hi && ds[k].Wi == ds[0].Wi && ds[k].up == ds[0].up;
+    static const bool off = [] { const char* e = getenv("SSR_CONV_BATCH"); return e && e[0] == '0'; }();
+    if (same && !off) {
+        for (int k = 0; k < n; ++k) {
+            const ssr_conv_desc& d = ds[k];
+            if (!view_ok(d.x, true) || !d.w || ((uintptr_t)d.w % 16) != 0 || !d.y.p || d.y.cs <= 0 || d.Cin <= 0 || (d.Cin % 8) != 0 ||
+                d.CoutPad <= 0 || (d.CoutPad % 32) != 0 || d.Cout > d.CoutPad || !(d.up == 1 || d.up == 2) || d.N <= 0 || d.Gh <= 0 ||
+                d.Gw <= 0 || (d.x2.p && (d.Cin2 <= 0 || (d.Cin2 % 8) != 0 || !view_ok(d.x2, true))) || (!d.x2.p && d.Cin2 != 0))
+                return SSR_EINVAL;
+        }
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        bool nt2, small;
+        pick_tile(ds[0], nt2, small);
+        // the class launches together fill the chip: use the tile shape the 4x larger grid would get
+        const long tiles4 = (long)((ds[0].Gw + 15) / 16) * ((ds[0].Gh + 7) / 8) * ds[0].N * (ds[0].CoutPad / (nt2 ? 64 : 32)) * n;
+        small = tiles4 < 384;
+        if (nt2) return small ? launch_conv4<__bf16, 2, 2, 1, 2, 2, 2>(ds, n, st) : launch_conv4<__bf16, 2, 2, 1, 2, 4, 2>(ds, n, st);
+        return small ? launch_conv4<__bf16, 2, 2, 1, 1, 2, 2>(ds, n, st) : launch_conv4<__bf16, 2, 2, 1, 1, 4, 2>(ds, n, st);
+    }
+    for (int k = 0; k < n; ++k) {
+        const int rc = conv2d_impl(ds + k, stream, 0);
+        if (rc != SSR_OK) return rc;
+    }
+    return SSR_OK;
+}
 extern "C" int ssr_conv2d_impl(const ssr_conv_desc* dp, void* stream, int32_t impl) {
     return conv2d_impl(dp, stream, impl);
 }

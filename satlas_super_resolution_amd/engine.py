@@ -317,8 +317,9 @@ class _ConvBuilder:
         wbase = self.store.packed_dgrad[name].data_ptr()
         esz = 4 if self.dt == hip.F32 else 2
         classes = [(0, 0)] if s.stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
-        for (py, px) in classes:
-            d = ConvDesc()
+        arr = (ConvDesc * len(classes))()
+        for ic, (py, px) in enumerate(classes):
+            d = arr[ic]
             d.dtype = self.dt
             d.x, d.N, d.Hi, d.Wi, d.up = dy, self.N, gh, gw, 1
             d.Cin = rup(s.cout, 8) if cin_dy is None else cin_dy
@@ -344,8 +345,11 @@ class _ConvBuilder:
             d.r2, d.r2_nc, d.beta2 = r2, r2_nc, beta2
             d.accumulate = accumulate
             d.m, d.m_c0, d.m_c1 = m, m_c0, m_c1
-            self.keep.append(d)
-            L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad {name}")
+        self.keep.append(arr)
+        if len(classes) == 1:
+            L.add(hip.lib().ssr_conv2d, C.byref(arr[0]), what=f"conv dgrad {name}")
+        else:   # the four parity classes in one launch (csrc/conv.hip, ssr_conv2d_batch)
+            L.add(hip.lib().ssr_conv2d_batch, arr, len(classes), what=f"conv dgrad {name}")
 
 
 def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View, c1: int, x2: View, c2: int, gh: int,

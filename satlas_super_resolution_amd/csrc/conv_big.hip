@@ -41,9 +41,9 @@ constexpr int CB_LDS = CB_BIAS + 256;
 constexpr int CB_NPV = (CB_NPIX * 4 + 255) / 256;            // 10 patch vectors per thread
 constexpr int CB_NWV = CB_WROWS * 4 / 256;                   // 9 weight vectors per thread
 static_assert(CB_NPV + CB_NWV == 19, "19 staging vectors per thread: one per k-step + one");
-static_assert(CB_LDS <= 160 * 1024 && 4 * 32 * 64 * 2 <= CB_PATCH, "LDS budget / output slabs fit in the patch area");
+static_assert(CB_LDS <= 160 * 1024 && 2 * 4 * 32 * 64 * 2 <= CB_PATCH, "LDS budget / output slabs fit in the patch area");
 
-constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_GENERIC = -1;
+constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_Y0 = 16, CB_GENERIC = -1;   // Y0: second output = activation before the residual
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float cb_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
     const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
     const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
     __bf16* slab = reinterpret_cast<__bf16*>(smem) + wave * (32 * 64);   // [32 lane-slots][64 co]
+    __bf16* slab0 = slab + 4 * (32 * 64);                                // second output (lean Y0 variants)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         int row, col;
@@ -230,6 +231,12 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[m][t][4 * q4 + e];
                         if constexpr ((EP & CB_LRELU) != 0) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu()
+                    }
+                    if constexpr ((EP & CB_Y0) != 0) {   // y0 = act(conv + bias), before the residual
+                        bf16x4c o0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o0[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4c*>(slab0 + i * 64 + t * 32 + 8 * q4 + co_l) = o0;
                     }
                     if constexpr ((EP & CB_R1) != 0) {
                         const u32x2c r = q1[t * 4 + q4];
@@ -291,18 +298,22 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
             }
         }
         // the wave's [32 px][64 co] slab -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
+        auto flush = [&](const __bf16* sl, __bf16* __restrict__ out, const ssr_view& vw) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int v = h * 64 + lane;
-            const int s_ = v >> 3, part = v & 7;
-            int prow, pcol;
-            cb_pixel(wave, m, s_, prow, pcol);
-            const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(slab + s_ * 64 + part * 8);
-            if (oy < d.Gh && ox < d.Gw && c < d.Cout)
-                *reinterpret_cast<u32x4*>(yp + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * d.y.cs +
-                                          d.y.coff + c) = val;
-        }
+            for (int h = 0; h < 4; ++h) {
+                const int v = h * 64 + lane;
+                const int s_ = v >> 3, part = v & 7;
+                int prow, pcol;
+                cb_pixel(wave, m, s_, prow, pcol);
+                const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * 64 + part * 8);
+                if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+                    *reinterpret_cast<u32x4*>(out + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * vw.cs +
+                                              vw.coff + c) = val;
+            }
+        };
+        flush(slab, yp, d.y);
+        if constexpr (EP >= 0 && (EP & CB_Y0) != 0) flush(slab0, y0p, d.y0);
     }
     BPROBE(8);
 }
@@ -348,13 +359,15 @@ bool ssr_conv_big_qualifies(const ssr_conv_desc& d) {
 
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_big_shape_ok(d) : !ssr_conv_big_qualifies(d)) return false;
-    if (!d.y0.p && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
+    auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
+    if ((!d.y0.p || al16(d.y0)) && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
         const int ep = (d.act == SSR_ACT_LRELU ? CB_LRELU : 0) | (d.m.p ? CB_MASK : 0) | (d.r1.p ? CB_R1 : 0) |
-                       (d.accumulate ? CB_ACC : 0);
+                       (d.accumulate ? CB_ACC : 0) | (d.y0.p ? CB_Y0 : 0);
         switch (ep) {
             case 0: *rc = launch_big<0>(d, st); return true;
             case CB_LRELU: *rc = launch_big<CB_LRELU>(d, st); return true;
             case CB_LRELU | CB_R1: *rc = launch_big<CB_LRELU | CB_R1>(d, st); return true;
+            case CB_LRELU | CB_R1 | CB_Y0: *rc = launch_big<CB_LRELU | CB_R1 | CB_Y0>(d, st); return true;
             case CB_MASK: *rc = launch_big<CB_MASK>(d, st); return true;
             case CB_MASK | CB_ACC: *rc = launch_big<CB_MASK | CB_ACC>(d, st); return true;
             case CB_MASK | CB_R1: *rc = launch_big<CB_MASK | CB_R1>(d, st); return true;

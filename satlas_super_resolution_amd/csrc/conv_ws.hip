@@ -38,7 +38,7 @@ typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 // flag it cost 6100 of the 12400 cycles of a 64->64 tile, ~800 instructions of selects and branches), so the
 // feature set is a template parameter: WS_GENERIC keeps the full ssr_conv_desc contract, the others are
 // branch-free straight-line code for the combinations the ESRGAN step actually launches.
-constexpr int WS_LRELU = 1, WS_MASK = 2, WS_R1 = 4, WS_ACC = 8, WS_GENERIC = -1;
+constexpr int WS_LRELU = 1, WS_MASK = 2, WS_R1 = 4, WS_ACC = 8, WS_Y1 = 16, WS_GENERIC = -1;   // Y1: second output = value before the mask
 
 __device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
     const int a_off = ((2 * wave + (i >> 4)) * WS_PW + (i & 15)) * WS_AROW + g * 16;   // this lane's pixel
     __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * 32 * NT);   // [32 px][32*NT co]
+    __bf16* slab1 = slab + 4 * (32 * 32 * NT);                // second output (lean Y1 variants)
 
     int tile = blockIdx.x;
     int n, gy0, gx0;
@@ -229,6 +230,12 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                         const u32x2 r = qa[t * 4 + q4];
                         v[0] += bf16_lo(r[0]); v[1] += bf16_hi(r[0]); v[2] += bf16_lo(r[1]); v[3] += bf16_hi(r[1]);
                     }
+                    if constexpr ((EP & WS_Y1) != 0) {   // y1 = value before the LeakyReLU-backward mask
+                        bf16x4w o1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o1[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4w*>(slab1 + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o1;
+                    }
                     if constexpr ((EP & WS_MASK) != 0) {
                         const u32x2 r = qm[t * 4 + q4];
                         v[0] *= lrelu_grad_from_out(bf16_lo(r[0])); v[1] *= lrelu_grad_from_out(bf16_hi(r[0]));
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
             }
         }
         }
-        {
+        auto flush = [&](const __bf16* sl, __bf16* __restrict__ out, const ssr_view& vw) {
             constexpr int PARTS = 4 * NT;                         // 16-B parts per pixel row of the tile
             const size_t row0 = (size_t)(n * d.Ho + (gy0 + 2 * wave) * d.oys + d.oyo) * d.Wo + gx0 * d.oxs + d.oxo;
 #pragma unroll
@@ -290,15 +297,17 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                 const int pix = v / PARTS, part = v - pix * PARTS;
                 const int dy = pix >> 4, dx = pix & 15;
                 const int c = co0 + part * 8;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(slab + pix * (32 * NT) + part * 8);
+                const u32x4 val = *reinterpret_cast<const u32x4*>(sl + pix * (32 * NT) + part * 8);
 #ifdef WS_NO_STORE
                 if (val[0] == 0x12345678u)
 #else
                 if (gy0 + 2 * wave + dy < d.Gh && gx0 + dx < d.Gw && c < d.Cout)
 #endif
-                    *reinterpret_cast<u32x4*>(yp + (row0 + (size_t)dy * d.oys * d.Wo + dx * d.oxs) * d.y.cs + d.y.coff + c) = val;
+                    *reinterpret_cast<u32x4*>(out + (row0 + (size_t)dy * d.oys * d.Wo + dx * d.oxs) * vw.cs + vw.coff + c) = val;
             }
-        }
+        };
+        flush(slab, yp, d.y);
+        if constexpr (EP >= 0 && (EP & WS_Y1) != 0) flush(slab1, y1p, d.y1);
         WPROBE(4);
         if (next < ntiles) store_patch(buf ^ 1);
         WPROBE(5);
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
 
 template <int NPL, int NT, int EP>
 int launch_ws_ep(const ssr_conv_desc& d, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + 4 * 32 * 32 * NT * 2;
+    constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + (EP >= 0 && (EP & WS_Y1) ? 2 : 1) * 4 * 32 * 32 * NT * 2;
     auto kern = conv_ws_kernel<NPL, NT, EP>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -333,15 +342,17 @@ int launch_ws_ep(const ssr_conv_desc& d, hipStream_t st) {
 template <int NPL, int NT>
 int launch_ws(const ssr_conv_desc& d, hipStream_t st) {
     // lean epilogue variants: single output, alpha == 1, no second residual
-    if (!d.y0.p && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
+    auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
+    if (!d.y0.p && (!d.y1.p || al16(d.y1)) && !d.r2.p && d.alpha == 1.f) {
         const int ep = (d.act == SSR_ACT_LRELU ? WS_LRELU : 0) | (d.m.p ? WS_MASK : 0) | (d.r1.p ? WS_R1 : 0) |
-                       (d.accumulate ? WS_ACC : 0);
+                       (d.accumulate ? WS_ACC : 0) | (d.y1.p ? WS_Y1 : 0);
         switch (ep) {
             case 0: return launch_ws_ep<NPL, NT, 0>(d, st);
             case WS_LRELU: return launch_ws_ep<NPL, NT, WS_LRELU>(d, st);
             case WS_MASK: return launch_ws_ep<NPL, NT, WS_MASK>(d, st);
             case WS_MASK | WS_ACC: return launch_ws_ep<NPL, NT, WS_MASK | WS_ACC>(d, st);
             case WS_MASK | WS_R1: return launch_ws_ep<NPL, NT, WS_MASK | WS_R1>(d, st);
+            case WS_MASK | WS_Y1: return launch_ws_ep<NPL, NT, WS_MASK | WS_Y1>(d, st);
             default: break;
         }
     }

@@ -551,7 +551,7 @@ def test_weight_stationary_conv_matches_pipelined_kernel(cin, cout, H, W, B, up)
         assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))
 
 
-@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "mask_r1"])
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "mask_r1", "mask_y1"])
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 16, 32, 2), (16, 64, 9, 21, 1), (64, 128, 8, 16, 1)])
 def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
     """The branch-free epilogue instantiations of csrc/conv_ws.hip (the combinations the train step launches:
@@ -568,7 +568,7 @@ def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
     xb, r1, m, y_init = mk(cin), mk(cout), mk(cout), mk(cout)
     outs = {}
     for impl in (1, 3):
-        y = y_init.clone()
+        y, y1 = y_init.clone(), torch.zeros_like(y_init)
         cb = engine._ConvBuilder(st, B)
         L = engine.Launcher()
         kw = dict(act=hip.ACT_LRELU if variant == "lrelu" else hip.ACT_NONE, cin=cin)
@@ -579,14 +579,17 @@ def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
             d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
         if variant == "mask_acc":
             d.accumulate = 1
+        if variant == "mask_y1":
+            d.y1 = hip.view(y1)
         hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
         torch.cuda.synchronize()
-        outs[impl] = y.float().cpu()
-    assert rel_err(outs[1], outs[3]) < 1e-2, rel_err(outs[1], outs[3])
+        outs[impl] = (y.float().cpu(), y1.float().cpu())
+    for a, b, nm in zip(outs[1], outs[3], ("y", "y1")):
+        assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))
 
 
 
-@pytest.mark.parametrize("variant", ["lrelu", "lrelu_r1", "mask", "mask_acc", "mask_r1", "plain", "generic"])
+@pytest.mark.parametrize("variant", ["lrelu", "lrelu_r1", "lrelu_r1_y0", "mask", "mask_acc", "mask_r1", "plain", "generic"])
 @pytest.mark.parametrize("cin,cout,H,W,B", [(128, 64, 32, 32, 2), (96, 128, 37, 21, 1), (256, 64, 16, 48, 1)])
 def test_big_tile_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
     """csrc/conv_big.hip (32x16-pixel x 64-channel workgroup tiles, 4x2 register tiling, rotated lane->pixel map)
@@ -606,9 +609,11 @@ def test_big_tile_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
         y, y0 = y_init.clone(), torch.zeros_like(y_init)
         cb = engine._ConvBuilder(st, B)
         L = engine.Launcher()
-        kw = dict(act=hip.ACT_LRELU if variant in ("lrelu", "lrelu_r1", "generic") else hip.ACT_NONE, cin=cin)
-        if variant in ("mask_r1", "lrelu_r1", "generic"):
+        kw = dict(act=hip.ACT_LRELU if variant in ("lrelu", "lrelu_r1", "lrelu_r1_y0", "generic") else hip.ACT_NONE, cin=cin)
+        if variant in ("mask_r1", "lrelu_r1", "lrelu_r1_y0", "generic"):
             kw.update(r1=hip.view(r1), r1_nc=cout, beta1=0.5)
+        if variant == "lrelu_r1_y0":
+            kw.update(y0=hip.view(y0))
         if variant == "generic":
             kw.update(alpha=0.7, y0=hip.view(y0), r2=hip.view(r2), r2_nc=cout, beta2=-0.25)
         d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), **kw)

@@ -159,6 +159,8 @@ int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* it
                      int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream);
 /* number of pixel tiles of a layer in the wgrad kernel selected by (dtype, KH): host helper for building items */
 int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH);
+/* input-channel width of a work item (ci0 must be a multiple of it; co0 a multiple of 32) for that kernel */
+int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH);
 
 /*
  * Weight packing (once per optimizer step; replaces cuDNN's internal filter transforms).

@@ -321,6 +321,249 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
     GPROBE(8);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 stride 1: 32 co x 64 ci per workgroup, the 18 (tap, 32-channel half) units dealt to the four MFMA waves.
+// Why (tools/wgrad_probe.hip): with 32 x 32 tiles the loaders had to deliver a 37 KB tile per 1280 MFMA cycles and got
+// 16.8 B/clk — they fetch 64-byte slices of 384-byte NHWC pixels (half of every 128-byte line is wasted) — so the
+// MFMA waves idled half the time.  A 64-channel X patch is whole lines, the dY tile is shared by twice the MFMAs
+// (22 B/clk needed), every wave sees ALL pixels of the tile for its 4..5 units (80 accumulator registers, no cross-wave
+// reduction at the end), and the X patch sits in LDS as two dense 64-byte-row planes (conflict-free transpose reads).
+// ------------------------------------------------------------------------------------------------------------------
+struct Wg3 {
+    static constexpr int TH = 16, PH = 18, PW = 18, ROW = 32;
+    static constexpr int NDYV = TH * WG_TW * 4;              // 1024 vectors: dY tile [256 px][32 co]
+    static constexpr int NXV = PH * PW * 8;                  // 2592 vectors: X patch [324 px][64 ci]
+    static constexpr int NLV = (NDYV + NXV + 255) / 256;     // 15 per loader thread
+    static constexpr int XPLANE = PH * PW * 64;              // bytes of one 32-channel plane
+    static constexpr int STAGE = NDYV * 16 + 2 * XPLANE;     // 57,856 B
+    static constexpr int NST = 2;
+    static constexpr int CTL = NST * STAGE;
+    static constexpr int LDS = CTL + 256;
+    static_assert(LDS <= 160 * 1024 && 32 * 64 * 9 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
+};
+
+template <int NU>
+__device__ __forceinline__ void wg3_contract(f32x16 (&acc)[5], const __bf16* ldy, const int (&uoff)[5], int src_px, int src_ch,
+                                             int* done_word, int k, int lane) {
+    constexpr int NOP = Wg3::TH * (1 + NU), PF = 8;
+    bf16x8 op[NOP];
+    const __bf16* lxb = ldy + Wg3::NDYV * 8;                  // X planes behind the dY tile
+    auto issue = [&](auto nc) {
+        constexpr int n = decltype(nc)::value, s = n / (1 + NU), r = n % (1 + NU);
+        if constexpr (r == 0) {
+            const __bf16* ap = ldy + (s * WG_TW + src_px) * Wg3::ROW + src_ch;
+            op[n] = tr_pair(ap, ap + 4 * Wg3::ROW);
+        } else {
+            const __bf16* bp = lxb + uoff[r - 1] + (s * Wg3::PW + src_px) * Wg3::ROW + src_ch;
+            op[n] = tr_pair(bp, bp + 4 * Wg3::ROW);
+        }
+    };
+    static_for<0, PF>([&](auto nc) { issue(nc); });
+    static_for<0, NOP>([&](auto nc) {
+        constexpr int n = decltype(nc)::value, s = n / (1 + NU), r = n % (1 + NU);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
+        if constexpr (n + PF == NOP - 1) {
+            if (lane == 0) __atomic_store_n(done_word, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (r != 0)
+            acc[r - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[s * (1 + NU)], op[n], acc[r - 1], 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_layer* __restrict__ layers,
+                                                            const ssr_wgrad_item* __restrict__ items) {
+    using C = Wg3;
+    constexpr int TH = C::TH, PW = C::PW, NST = C::NST;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ctl = reinterpret_cast<int*>(smem + C::CTL);
+    const ssr_wgrad_item it = items[blockIdx.x];
+    const ssr_wgrad_layer L = layers[it.layer];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
+    const int ntile = it.tile_end - it.tile_begin;
+    if (tid < 64) ctl[tid] = 0;
+    GPROBE(0);
+    __syncthreads();   // the only barrier
+
+    if (wave >= 4) {
+        // =============================== loader waves ===============================
+        const int lt = tid - 256;
+        const int upshift = L.up == 2 ? 1 : 0;
+        const int LH = L.Hi << upshift, LW = L.Wi << upshift;
+        const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(L.x.p);
+        const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(L.dy.p);
+        constexpr int QDY = C::NDYV / 256;                     // vector q of a thread is a dY vector iff q < QDY
+        int rel[C::NLV], yx[C::NLV], lo[C::NLV];               // global offset rel. to the tile origin, (y, x), LDS offset
+#pragma unroll
+        for (int q = 0; q < C::NLV; ++q) {
+            const int v = lt + q * 256;
+            if (q < QDY) {
+                const int pix = v >> 2, part = v & 3;
+                const int y = pix >> 4, x = pix & 15;
+                rel[q] = (y * L.Gw + x) * L.dy.cs + part * 8;
+                yx[q] = (it.co0 + part * 8 < L.Cout) ? (y | (x << 16)) : 0x7fff7fff;   // never inside
+                lo[q] = v * 16;
+            } else {
+                const int vx = v - C::NDYV;
+                const int pix = vx >> 3, part = vx & 7;        // 8 x 16 B = the 64 channels of one pixel: a whole line
+                const int py = pix / PW, px = pix - py * PW;
+                const int y = py - L.pad_y, x = px - L.pad_x;
+                rel[q] = ((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + part * 8;
+                yx[q] = (vx < C::NXV && it.ci0 + part * 8 < L.Cin) ? ((y & 0xffff) | (x << 16)) : 0x7fff7fff;
+                lo[q] = vx < C::NXV ? C::NDYV * 16 + (part >> 2) * C::XPLANE + pix * 64 + (part & 3) * 16 : -1;
+            }
+        }
+        const bool do_bias = L.db != nullptr && it.ci0 == 0;
+        float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4 ra[C::NLV], rb[C::NLV];
+        auto load_tile = [&](int k, u32x4 (&r)[C::NLV]) {
+            int b = it.tile_begin + k;
+            const int tx_i = b % tiles_x; b /= tiles_x;
+            const int ty_i = b % tiles_y;
+            const int n = b / tiles_y;
+            const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
+            const __bf16* dyb = dyg + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs + L.dy.coff + it.co0;
+            const __bf16* xb = xg + ((size_t)(n * L.Hi + (gy0 >> upshift)) * L.Wi + (gx0 >> upshift)) * L.x.cs + L.x.coff + it.ci0;
+#pragma unroll
+            for (int q = 0; q < C::NLV; ++q) {
+                const int y = (int)(short)(yx[q] & 0xffff), x = yx[q] >> 16;
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (q < QDY) {
+                    if (gy0 + y < L.Gh && gx0 + x < L.Gw) val = *reinterpret_cast<const u32x4*>(dyb + rel[q]);
+                } else {
+                    if ((unsigned)(gy0 + y) < (unsigned)LH && (unsigned)(gx0 + x) < (unsigned)LW)
+                        val = *reinterpret_cast<const u32x4*>(xb + rel[q]);
+                }
+                r[q] = val;
+            }
+        };
+        auto put = [&](int k, int st, const u32x4 (&r)[C::NLV]) {
+            if (k >= NST) {
+                for (;;) {
+                    u32x4 dn;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(C::CTL + 4 * WGC_DONE)) : "memory");
+                    if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= k - NST + 1) break;
+                }
+            }
+            char* base = smem + st * C::STAGE;
+#pragma unroll
+            for (int q = 0; q < C::NLV; ++q)
+                if (lo[q] >= 0) *reinterpret_cast<u32x4*>(base + lo[q]) = r[q];
+            if (do_bias) {
+#pragma unroll
+                for (int q = 0; q < QDY; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bacc[2 * e] += __builtin_bit_cast(float, r[q][e] << 16);
+                        bacc[2 * e + 1] += __builtin_bit_cast(float, r[q][e] & 0xffff0000u);
+                    }
+            }
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WGC_READY + st))), "v"(1) : "memory");
+        };
+        if (ntile > 0) load_tile(0, ra);
+        int st = 0;
+        for (int k = 0; k < ntile; k += 2) {
+            if (k + 1 < ntile) load_tile(k + 1, rb);
+            put(k, st, ra);
+            st ^= 1;
+            if (k + 2 < ntile) load_tile(k + 2, ra);
+            if (k + 1 < ntile) {
+                put(k + 1, st, rb);
+                st ^= 1;
+            }
+        }
+        if (do_bias) {
+            float* bl = reinterpret_cast<float*>(ctl + WGC_BIAS);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(bl + (lt & 3) * 8 + e, bacc[e]);
+            if (lane == 0) __atomic_fetch_add(ctl + WGC_LSYNC, 1, __ATOMIC_RELAXED);
+            while (wg_ld(ctl + WGC_LSYNC) < 4) {}
+            if (lt < 32 && it.co0 + lt < L.Cout) atomicAdd(L.db + it.co0 + lt, L.alpha * bl[lt]);
+        }
+        return;
+    }
+
+    // =============================== MFMA waves ===============================
+    const int g = lane >> 5;
+    const int t16 = lane & 15;
+    const int src_px = 8 * g + (t16 >> 2);
+    const int src_ch = 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+    // units u = tap + 9 * half; wave w owns u = w, w + 4, ...; a tile with <= 32 valid input channels has no second half
+    const int nci = min(64, L.Cin_w - it.ci0);
+    const int nunit = nci > 32 ? 18 : 9;
+    int uoff[5], utap[5], usub[5];
+    int nu = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int u = wave + 4 * j;
+        const bool ok = u < nunit;
+        const int uu = ok ? u : wave;                          // harmless duplicate address for unused slots
+        utap[j] = uu % 9; usub[j] = uu / 9;
+        uoff[j] = usub[j] * (C::XPLANE / 2) + ((utap[j] / 3) * PW + utap[j] % 3) * C::ROW;   // bf16 elements
+        nu += ok ? 1 : 0;
+    }
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int st = 0, target = 4;
+    for (int k = 0; k < ntile; ++k) {
+        while (wg_ld(ctl + WGC_READY + st) < target) {}
+        const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+        int* dw_ = ctl + WGC_DONE + wave;
+        if (nu == 5) wg3_contract<5>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
+        else if (nu == 4) wg3_contract<4>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
+        else if (nu == 3) wg3_contract<3>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
+        else wg3_contract<2>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
+        if (st == 1) target += 4;
+        st ^= 1;
+    }
+    GPROBE(7);
+    // =============================== write-out ===============================
+    // every wave holds complete sums for its units: D[row = co][col = ci] -> LDS tile [co][64 ci][9 taps] (stride 9 floats
+    // between lanes: conflict-free) -> contiguous fp32 atomic adds (each co row of the tile is 64 * 9 consecutive floats)
+    float* red = reinterpret_cast<float*>(smem);
+    int phase = 0;
+    wg_sync4(ctl + WGC_SYNC, phase, lane);   // all four waves are finished reading the ring
+    const int i = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j < nu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(mfma32_row(r, g) * 64 + usub[j] * 32 + i) * 9 + utap[j]] = L.alpha * acc[j][r];
+        }
+    }
+    wg_sync4(ctl + WGC_SYNC, phase, lane);
+    float* __restrict__ dw = L.dw;
+    constexpr int NOUT = 32 * 64 * 9;
+#pragma unroll 8
+    for (int q = 0; q < NOUT / 256; ++q) {
+        const int e = tid + q * 256;
+        const int co = e / 576, rem = e - co * 576;
+        if (it.co0 + co < L.Cout && rem < nci * 9)
+            atomicAdd(dw + ((size_t)(it.co0 + co) * L.Cin_w + it.ci0) * 9 + rem, red[e]);
+    }
+    GPROBE(8);
+}
+
+int launch_k3(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_k3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg3::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_k3_kernel, dim3(n_items), dim3(512), Wg3::LDS, st, layers, items);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
 template <int KH, int KW, int S, bool SPLIT>
 int launch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {
     using C = WgCfg<KH, KW, S, SPLIT>;
@@ -341,7 +584,7 @@ int launch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_ite
 
 int ssr_wgrad_bf16_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW,
                             int S, hipStream_t st) {
-    if (KH == 3 && KW == 3 && S == 1) return launch<3, 3, 1, false>(layers, items, n_items, st);
+    if (KH == 3 && KW == 3 && S == 1) return launch_k3(layers, items, n_items, st);
     if (KH == 4 && KW == 4 && S == 2) return launch<4, 4, 2, true>(layers, items, n_items, st);
     return SSR_EUNSUP;
 }

@@ -399,7 +399,7 @@ class WgradBatch:
         splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
         per = -(-tiles // splits)
         for co0 in range(0, cout, 32):
-            for ci0 in range(0, cin_w, 32):
+            for ci0 in range(0, cin_w, hip.lib().ssr_wgrad_ci_tile(self.dtype, self.k)):
                 for sp in range(splits):
                     b, e = sp * per, min(tiles, (sp + 1) * per)
                     if b < e:

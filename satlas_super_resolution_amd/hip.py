@@ -103,7 +103,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    l.ssr_wgrad_ci_tile.argtypes = [i32, i32]
     l.ssr_wgrad_tiles.argtypes = [i32, i32, i32, i32, i32]
     l.ssr_pack_weights.argtypes = [vp, i32, i32, vp]
     l.ssr_pack_dgrad_gather.argtypes = [vp, i32, i32, vp]

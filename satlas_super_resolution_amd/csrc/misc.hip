@@ -200,40 +200,56 @@ template <> struct VecIO<__bf16> {
     }
 };
 
+// One thread = one INPUT pixel x 16 bytes of channels -> its 2x2 block of outputs: the block needs the 3x3 input
+// neighbourhood (9 loads for 4 outputs instead of 16) and the index arithmetic is 32-bit and amortised over 4 outputs
+// (r01 rocprofv3: the output-pixel-per-thread version with 64-bit div/mod ran at ~2.5x its HBM time).  The arithmetic
+// per output is exactly bil_src's: even outputs blend rows (i-1, i) with (.25, .75) — (i, i) with (1, 0) at the border —
+// odd outputs rows (i, min(i+1, n-1)) with (.75, .25).
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(ssr_view a, ssr_view b, ssr_view y, int N, int H, int W,
                                                              int C) {
     constexpr int V = VecIO<T>::N;
-    const int H2 = 2 * H, W2 = 2 * W, CV = C / V;
-    const long total = (long)N * H2 * W2 * CV;
+    const int W2 = 2 * W, CV = C / V;
+    const int total = N * H * W * CV;
     const T* __restrict__ ap = reinterpret_cast<const T*>(a.p);
     const T* __restrict__ bp = reinterpret_cast<const T*>(b.p);
     T* __restrict__ yp = reinterpret_cast<T*>(y.p);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % CV) * V;
-        long q = e / CV;
-        const int ox = (int)(q % W2); q /= W2;
-        const int oy = (int)(q % H2);
-        const int n = (int)(q / H2);
-        int y0, y1, x0, x1;
-        float ly0, ly1, lx0, lx1;
-        bil_src(oy, H, y0, y1, ly0, ly1);
-        bil_src(ox, W, x0, x1, lx0, lx1);
-        float t00[V], t01[V], t10[V], t11[V], o[V];
-        auto rd = [&](int yy, int xx, float (&f)[V]) {
-            const long p = ((long)n * H + yy) * W + xx;
-            VecIO<T>::load(ap + p * a.cs + a.coff + c, f);
-            if (bp) {
-                float g[V];
-                VecIO<T>::load(bp + p * b.cs + b.coff + c, g);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int c = (e % CV) * V;
+        int q = e / CV;
+        const int ix = q % W; q /= W;
+        const int iy = q % H;
+        const int n = q / H;
+        const int ys[3] = {iy > 0 ? iy - 1 : 0, iy, iy < H - 1 ? iy + 1 : iy};
+        const int xs[3] = {ix > 0 ? ix - 1 : 0, ix, ix < W - 1 ? ix + 1 : ix};
+        float t[3][3][V];
 #pragma unroll
-                for (int k = 0; k < V; ++k) f[k] += g[k];
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const size_t p = (size_t)(n * H + ys[r]) * W + xs[cc];
+                VecIO<T>::load(ap + p * a.cs + a.coff + c, t[r][cc]);
+                if (bp) {
+                    float g[V];
+                    VecIO<T>::load(bp + p * b.cs + b.coff + c, g);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) t[r][cc][k] += g[k];
+                }
             }
-        };
-        rd(y0, x0, t00); rd(y0, x1, t01); rd(y1, x0, t10); rd(y1, x1, t11);
+        // even output: rows t[0], t[1] with (.25, .75) — (1, 0) at the border, where t[0] == t[1] anyway; odd: t[1], t[2] (.75, .25)
+        const float wya[2] = {iy > 0 ? 0.25f : 1.f, 0.75f}, wyb[2] = {iy > 0 ? 0.75f : 0.f, 0.25f};
+        const float wxa[2] = {ix > 0 ? 0.25f : 1.f, 0.75f}, wxb[2] = {ix > 0 ? 0.75f : 0.f, 0.25f};
 #pragma unroll
-        for (int k = 0; k < V; ++k) o[k] = ly0 * (lx0 * t00[k] + lx1 * t01[k]) + ly1 * (lx0 * t10[k] + lx1 * t11[k]);
-        VecIO<T>::store(yp + (((long)n * H2 + oy) * W2 + ox) * y.cs + y.coff + c, o);
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float o[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    o[k] = wya[py] * (wxa[px] * t[py][px][k] + wxb[px] * t[py][px + 1][k]) +
+                           wyb[py] * (wxa[px] * t[py + 1][px][k] + wxb[px] * t[py + 1][px + 1][k]);
+                VecIO<T>::store(yp + ((size_t)(n * 2 * H + 2 * iy + py) * W2 + 2 * ix + px) * y.cs + y.coff + c, o);
+            }
     }
 }
 
@@ -567,7 +583,8 @@ extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dt
     if (!a.p || !y.p || (C % 8) != 0 || (a.cs % 8) || (a.coff % 8) || (y.cs % 8) || (y.coff % 8) ||
         (b.p && ((b.cs % 8) || (b.coff % 8))))
         return SSR_EINVAL;
-    const long total = (long)N * H * W * 4 * C / 4;
+    const long total = (long)N * H * W * C / (dtype == SSR_F32 ? 4 : 8);   // one thread per input pixel x 16 bytes
+    if (total >= (1L << 31)) return SSR_EINVAL;
     if (dtype == SSR_F32)
         hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
                            b, y, N, H, W, C);

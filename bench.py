@@ -251,7 +251,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(dom)
+                detail = json.load(open(tp)).get(dom)
+                traffic = detail["bytes_per_launch"] if isinstance(detail, dict) else detail
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n,

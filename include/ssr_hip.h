@@ -247,6 +247,13 @@ typedef struct ssr_sn_bwd_item {
 int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n_items, int32_t max_elems, void* stream);
 
 /* ---- losses (BasicSR L1Loss / GANLoss('vanilla'); call sites ssr_esrgan_model.py:148,182,218,224) ---- */
+/* USMSharp of BasicSR (img_process_util.USMSharp(radius=50, sigma=0), built at ssr_esrgan_model.py:31, applied to the
+ * ground truth at :109): 51x51 Gaussian (sigma 8) blur with reflect padding, thresholded residual mask, soft blend.
+ * src/dst: `planes` contiguous fp32 H x W planes (NCHW tensors: planes = N*C); src is multiplied by in_scale first
+ * (1/255 for uint8-valued input), dst is in [0,1].  H*W <= 16384 (SSR_EUNSUP beyond), H, W > 25. */
+int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, float in_scale, float weight,
+                  float threshold, void* stream);
+
 /* loss_out[0] += weight * mean|a-b| over (N,H,W,C valid); grad (optional) = weight*sign(a-b)/numel */
 int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
                 float* loss_out, void* stream);

@@ -273,6 +273,40 @@ D_PARAM_KEYS = (["conv0.weight", "conv0.bias"] + [f"{n}.weight_orig" for n in SN
 # ----------------------------------------------------------------------------
 # Losses / optimizer pieces executed inside optimize_parameters (BasicSR 1.4.2 semantics)
 # ----------------------------------------------------------------------------
+def usm_gaussian_kernel1d(radius: int = 50, sigma: float = 0.0) -> torch.Tensor:
+    """cv2.getGaussianKernel(ksize, sigma) as BasicSR's USMSharp.__init__ calls it (basicsr==1.4.2,
+    basicsr/utils/img_process_util.py; not on disk: restated from the published source and anchored on the call site
+    /root/reference/ssr/models/ssr_esrgan_model.py:31 `USMSharp().cuda()` -> radius 50 -> ksize 51, sigma 0 -> OpenCV's
+    rule sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8 = 8.0; coefficients exp(-(i-c)^2 / (2 sigma^2)) normalised to sum 1)."""
+    if radius % 2 == 0:
+        radius += 1
+    if sigma <= 0:
+        sigma = 0.3 * ((radius - 1) * 0.5 - 1) + 0.8
+    i = torch.arange(radius, dtype=torch.float64) - (radius - 1) / 2
+    k = torch.exp(-(i * i) / (2 * sigma * sigma))
+    return k / k.sum()
+
+
+def filter2d(img: torch.Tensor, kernel2d: torch.Tensor) -> torch.Tensor:
+    """basicsr filter2D: reflect-pad k//2 and correlate every channel of every image with the same kernel."""
+    k = kernel2d.shape[-1]
+    b, c, h, w = img.shape
+    x = F.pad(img, (k // 2,) * 4, mode="reflect").view(b * c, 1, h + k - 1, w + k - 1)
+    return F.conv2d(x, kernel2d.view(1, 1, k, k).to(img.dtype)).view(b, c, h, w)
+
+
+def usm_sharp(img: torch.Tensor, weight: float = 0.5, threshold: float = 10.0, radius: int = 50, sigma: float = 0.0):
+    """USMSharp.forward (applied to self.gt at ssr_esrgan_model.py:109; parity unpinned by the reference: BasicSR piece)."""
+    k1 = usm_gaussian_kernel1d(radius, sigma)
+    k2 = torch.outer(k1, k1).to(torch.float32)          # FloatTensor(np.dot(kernel, kernel.T))
+    blur = filter2d(img, k2)
+    residual = img - blur
+    mask = (residual.abs() * 255 > threshold).to(img.dtype)
+    soft = filter2d(mask, k2)
+    sharp = torch.clip(img + weight * residual, 0, 1)
+    return soft * sharp + (1 - soft) * img
+
+
 def l1_loss(pred, target, weight=1.0):
     """basicsr L1Loss(loss_weight, reduction='mean'); call site ssr_esrgan_model.py:148."""
     return weight * F.l1_loss(pred, target, reduction="mean")

@@ -646,6 +646,84 @@ extern "C" int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n
     return SSR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// USMSharp (BasicSR 1.4.2 basicsr/utils/img_process_util.py, constructed with its defaults at
+// /root/reference/ssr/models/ssr_esrgan_model.py:31 and applied to the ground truth at :109):
+//   blur = filter2D(img, G51)   (reflect pad 25, G51 = outer product of cv2.getGaussianKernel(51, 0): sigma = 8)
+//   residual = img - blur;  mask = |residual| * 255 > threshold;  soft = filter2D(mask, G51)
+//   sharp = clip(img + weight * residual, 0, 1);  out = soft * sharp + (1 - soft) * img
+// One workgroup per (image, channel) plane held in LDS: the Gaussian is separable and so is reflect padding, so each
+// filter2D is a row pass and a column pass over the plane (2 x 51 taps instead of 2601).
+// ------------------------------------------------------------------------------------------------
+constexpr int USM_R = 25, USM_K = 2 * USM_R + 1;
+__device__ __forceinline__ int usm_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void usm_sharp_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                        float in_scale, float weight, float threshold) {
+    extern __shared__ float usm_lds[];
+    float* p0 = usm_lds;
+    float* p1 = usm_lds + H * W;
+    float* gk = usm_lds + 2 * H * W;
+    const int tid = threadIdx.x, np = H * W;
+    const float* __restrict__ sp = src + (size_t)blockIdx.x * np;
+    float* __restrict__ dp = dst + (size_t)blockIdx.x * np;
+    if (tid < USM_K) {   // cv2.getGaussianKernel(51, sigma <= 0): sigma = 0.3 * ((51 - 1) * 0.5 - 1) + 0.8 = 8
+        const float d = (float)(tid - USM_R);
+        gk[tid] = __expf(-d * d / 128.f);
+    }
+    for (int e = tid; e < np; e += 256) p0[e] = sp[e] * in_scale;
+    __syncthreads();
+    float gsum = 0.f;
+    for (int k = 0; k < USM_K; ++k) gsum += gk[k];
+    const float ginv = 1.f / gsum;
+    auto row_pass = [&]() {   // p0 -> p1
+        for (int e = tid; e < np; e += 256) {
+            const int y = e / W, x = e - y * W;
+            float s = 0.f;
+            for (int k = 0; k < USM_K; ++k) s += gk[k] * p0[y * W + usm_reflect(x + k - USM_R, W)];
+            p1[e] = s * ginv;
+        }
+    };
+    auto col_at = [&](int e) {   // column pass of p1 at pixel e
+        const int y = e / W, x = e - y * W;
+        float s = 0.f;
+        for (int k = 0; k < USM_K; ++k) s += gk[k] * p1[usm_reflect(y + k - USM_R, H) * W + x];
+        return s * ginv;
+    };
+    row_pass();
+    __syncthreads();
+    // this thread's pixels e = tid + 256 j: the sharpened value is parked in dst (same thread re-reads it below)
+    for (int e = tid; e < np; e += 256) {
+        const float v = p0[e], res = v - col_at(e);
+        dp[e] = fminf(fmaxf(v + weight * res, 0.f), 1.f);
+        p0[e] = (fabsf(res) * 255.f > threshold) ? 1.f : 0.f;   // own pixel only: nobody else reads p0 in this phase
+    }
+    __syncthreads();
+    row_pass();
+    __syncthreads();
+    for (int e = tid; e < np; e += 256) {
+        const float soft = col_at(e), v = sp[e] * in_scale;
+        dp[e] = soft * dp[e] + (1.f - soft) * v;
+    }
+}
+
+extern "C" int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, float in_scale, float weight,
+                             float threshold, void* stream) {
+    if (!src || !dst || planes <= 0 || H <= USM_R || W <= USM_R) return SSR_EINVAL;   // reflect padding needs pad < size
+    if ((long)H * W > 16384) return SSR_EUNSUP;               // plane must fit LDS twice (128 x 128 ground-truth tiles do)
+    const size_t lds = ((size_t)2 * H * W + 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(usm_sharp_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 16384 + 64) * sizeof(float)));
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(usm_sharp_kernel, dim3(planes), dim3(256), lds, ST(stream), src, dst, H, W, in_scale, weight, threshold);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
 extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
                            float* loss_out, void* stream) {
     if (!a.p || !b.p || npix <= 0 || C <= 0) return SSR_EINVAL;

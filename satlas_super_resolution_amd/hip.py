@@ -105,7 +105,7 @@ class AdamArgs(C.Structure):
 ABI_SYMBOLS = [
     "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
-    "ssr_spectral_norm_bwd", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
+    "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
 ]
 
@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
     l.ssr_spectral_norm.argtypes = [vp, i32, i32, i32, i32, vp]
     l.ssr_spectral_norm_bwd.argtypes = [vp, i32, i32, vp]
     l.ssr_l1_loss.argtypes = [View, View, View, i32, i64, i32, f32, vp, vp]
+    l.ssr_usm_sharp.argtypes = [vp, vp, i32, i32, i32, f32, f32, f32, vp]
     l.ssr_bce_logits_loss.argtypes = [View, View, i32, i64, f32, f32, vp, vp, vp]
     l.ssr_adam_step.argtypes = [C.POINTER(AdamArgs), vp]
     l.ssr_axpby_f32.argtypes = [f32, vp, f32, vp, i64, vp]

@@ -8,7 +8,8 @@
 Same registry name and the same `opt` dictionary (YAML) keys.  Instead of autograd over ~41k ATen ops per
 step, optimize_parameters() replays the fused HIP-graph step of train_step.ESRGANTrainStep.
 Scope: L1 + vanilla-GAN losses.  Options that need components outside the hot path
-(perceptual/VGG, CLIP, SSIM losses, USM-sharpened ground truth, old_hr) raise NotImplementedError
+(perceptual/VGG, CLIP, SSIM losses, old_hr) raise NotImplementedError; USM-sharpened ground truth (l1_gt_usm /
+gan_gt_usm, the shipped YAML's setting) runs on the GPU (csrc/misc.hip usm_sharp_kernel)
 instead of being silently ignored."""
 from __future__ import annotations
 
@@ -58,7 +59,10 @@ class SSRESRGANModel:
             lr_g=float(og.get("lr", 1e-4)), lr_d=float(od.get("lr", 1e-4)),
             betas=tuple(og.get("betas", (0.9, 0.99))), ema_decay=float(train_opt.get("ema_decay", 0)),
             net_d_iters=int(train_opt.get("net_d_iters", 1)), net_d_init_iters=int(train_opt.get("net_d_init_iters", 0)),
-            feed_disc_lr=self.feed_disc_lr, real_label=float(gan.get("real_label_val", 1.0)),
+            feed_disc_lr=self.feed_disc_lr,
+            # `if self.opt['l1_gt_usm'] is False: l1_gt = self.gt` (ssr_esrgan_model.py:121-129): sharpened unless exactly False
+            l1_gt_usm=opt.get("l1_gt_usm", False) is not False, gan_gt_usm=opt.get("gan_gt_usm", False) is not False,
+            real_label=float(gan.get("real_label_val", 1.0)),
             fake_label=float(gan.get("fake_label_val", 0.0)))
         sch = train_opt.get("scheduler", {})
         self.milestones = list(sch.get("milestones", []))
@@ -120,10 +124,7 @@ class SSRESRGANModel:
 
     def optimize_parameters(self, current_iter: int):
         # the reference indexes these keys directly (KeyError when absent): ssr_esrgan_model.py:124-129
-        usm = [self.opt["l1_gt_usm"], self.opt["percep_gt_usm"], self.opt["gan_gt_usm"]]
-        if usm[0] or usm[2]:
-            raise NotImplementedError("USM-sharpened ground truth (l1_gt_usm/gan_gt_usm) is a 'next' row "
-                                      "(SURVEY.md §8f rank 1); set them to False")
+        _ = [self.opt["l1_gt_usm"], self.opt["percep_gt_usm"], self.opt["gan_gt_usm"]]   # applied in feed_data (StepConfig)
         self.ts.step(current_iter)
         self.output = None  # materialised lazily by get_current_visuals()
 

@@ -31,6 +31,8 @@ class StepConfig:
     net_d_iters: int = 1           # (:146)
     net_d_init_iters: int = 0      # (:147)
     feed_disc_lr: bool = False     # top-level feed_disc_lr          (:14)
+    l1_gt_usm: bool = False        # L1 target = USM-sharpened gt    (ssr_esrgan_model.py:121-125; yml :9)
+    gan_gt_usm: bool = False       # D real input = USM-sharpened gt (:127-129; yml :11)
     real_label: float = 1.0
     fake_label: float = 0.0
 
@@ -90,6 +92,9 @@ class ESRGANTrainStep:
         self.fake_in = z(B, H, W, cdp)      # [G output | lr_resized]   (ssr_esrgan_model.py:171-178)
         self.real_in = z(B, H, W, cdp)      # [gt       | lr_resized]   (:202-213)
         self.grad_l1 = z(B, H, W, cdp)
+        # L1 target: the D-real buffer unless exactly one of the two is USM-sharpened (ssr_esrgan_model.py:121-129)
+        self.l1_tgt = self.real_in if cfg.l1_gt_usm == cfg.gan_gt_usm else z(B, H, W, cdp)
+        self._gt_usm = None   # fp32 NCHW scratch for ssr_usm_sharp
         self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
         self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
                                                num_feat=d_kwargs.get("num_feat", 64),
@@ -131,8 +136,20 @@ class ESRGANTrainStep:
         lr = lr.contiguous()
         gt = gt.contiguous()
         self.g_plan.load_input(lr, scale)
-        hip.check(L.ssr_nchw_to_nhwc(gt.data_ptr(), self.B, self.cout, self.H, self.W, view(self.real_in), self.dt, 1,
-                                     1, scale, st), "gt->nhwc")
+        gt_usm = None
+        if self.cfg.l1_gt_usm or self.cfg.gan_gt_usm:   # self.gt_usm = self.usm_sharpener(self.gt)  (:109)
+            if self._gt_usm is None:
+                self._gt_usm = torch.empty(self.B, self.cout, self.H, self.W, dtype=torch.float32, device=gt.device)
+            hip.check(L.ssr_usm_sharp(gt.data_ptr(), self._gt_usm.data_ptr(), self.B * self.cout, self.H, self.W, scale,
+                                      0.5, 10.0, st), "ssr_usm_sharp")
+            gt_usm = self._gt_usm
+        gan_src, gan_scale = (gt_usm, 1.0) if self.cfg.gan_gt_usm else (gt, scale)
+        hip.check(L.ssr_nchw_to_nhwc(gan_src.data_ptr(), self.B, self.cout, self.H, self.W, view(self.real_in), self.dt, 1,
+                                     1, gan_scale, st), "gt->nhwc")
+        if self.l1_tgt is not self.real_in:
+            l1_src, l1_scale = (gt_usm, 1.0) if self.cfg.l1_gt_usm else (gt, scale)
+            hip.check(L.ssr_nchw_to_nhwc(l1_src.data_ptr(), self.B, self.cout, self.H, self.W, view(self.l1_tgt), self.dt, 1,
+                                         1, l1_scale, st), "l1 target->nhwc")
         if self.cfg.feed_disc_lr:   # lr_resized = F.interpolate(lr, scale_factor=4) (nearest), :133
             for buf in (self.real_in, self.fake_in):
                 hip.check(L.ssr_nchw_to_nhwc(lr.data_ptr(), self.B, self.cin, self.h, self.w,
@@ -159,7 +176,7 @@ class ESRGANTrainStep:
         self.losses.zero_()
         self.g_store.pack()
         self.g_plan.fwd.run()                                              # :140
-        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.real_in), view(self.grad_l1), self.dt,
+        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.dt,
                                         self.B * self.H * self.W, self.cout, cfg.l1_weight, self.losses.data_ptr(),
                                         hip.stream_ptr()), "ssr_l1_loss")   # :147-150
         self._d_forward(self.fake_in)                                      # :181

@@ -9,6 +9,8 @@ Tolerance (north_star / SURVEY.md D5): |a - ref| <= 1e-3*max|ref| + 1e-3*|ref| i
 from collections import OrderedDict
 
 import pytest
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -626,3 +628,48 @@ def test_big_tile_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
         outs[impl] = (y.float().cpu(), y0.float().cpu())
     for a, b, nm in zip(outs[4], outs[3], ("y", "y0")):
         assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 128), (1, 40, 52)])
+def test_usm_sharp_matches_oracle(B, H, W):
+    """ssr_usm_sharp (separable 51-tap Gaussian in LDS, reflect padding) vs the oracle's 2-D restatement of BasicSR's
+    USMSharp on uint8-valued images (feed_data: ssr_esrgan_model.py:108-109).  The residual mask is a threshold, so a
+    pixel exactly at |residual|*255 == 10 could flip: allow a handful of outliers, everything else to 2e-5."""
+    from oracle import esrgan_oracle as O
+    _, hip = _mods()
+    torch.manual_seed(B + H)
+    base = torch.rand(B, 3, H // 4 + 1, W // 4 + 1)
+    img = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear") + 0.08 * torch.randn(B, 3, H, W)
+    u8 = (img.clamp(0, 1) * 255).round()
+    src = u8.cuda().contiguous()
+    dst = torch.empty_like(src)
+    hip.check(hip.lib().ssr_usm_sharp(src.data_ptr(), dst.data_ptr(), B * 3, H, W, 1.0 / 255, 0.5, 10.0, hip.stream_ptr()), "usm")
+    torch.cuda.synchronize()
+    ref = O.usm_sharp(u8 / 255)
+    diff = (dst.cpu() - ref).abs()
+    assert float((diff > 2e-5).float().mean()) < 1e-3, float(diff.max())
+    assert float(diff.max()) < 0.05
+
+
+def test_train_step_feeds_usm_sharpened_l1_target():
+    """l1_gt_usm=True, gan_gt_usm=False (the shipped esrgan_s2naip_urban.yml:9-11): the L1 target is the sharpened
+    ground truth, the discriminator's real input is the plain one (ssr_esrgan_model.py:121-129,202-213)."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd import train_step as T
+    torch.manual_seed(3)
+    cfg = T.StepConfig(l1_gt_usm=True, gan_gt_usm=False)
+    g_kw = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
+    ts = T.ESRGANTrainStep(g_kw, dict(num_in_ch=3, num_feat=64, skip_connection=True), 1, 32, 32, dtype="fp32", cfg=cfg,
+                           use_graph=False)
+    ts.load_state(O.generator_init(seed=1, **g_kw), O.discriminator_init(3, 64, seed=2))
+    lr = torch.randint(0, 256, (1, 3, 32, 32)).float().cuda()
+    gt = (torch.rand(1, 3, 33, 33)[..., :32, :32].repeat_interleave(4, 2).repeat_interleave(4, 3) * 255).round().cuda()
+    ts.feed_data(lr, gt, scale=1.0 / 255)
+    torch.cuda.synchronize()
+    assert ts.l1_tgt is not ts.real_in
+    l1 = ts.l1_tgt[..., :3].float().cpu().permute(0, 3, 1, 2)
+    real = ts.real_in[..., :3].float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(real, gt.cpu() / 255, atol=1e-6)
+    assert float((l1 - O.usm_sharp(gt.cpu() / 255)).abs().max()) < 1e-3
+    ts.step(1)
+    assert all(math.isfinite(v) for v in ts.log().values())

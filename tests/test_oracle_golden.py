@@ -4,6 +4,8 @@ import copy
 from collections import OrderedDict
 
 import pytest
+import math
+
 import torch
 
 from conftest import load_golden, rel_err
@@ -107,3 +109,23 @@ def test_flop_model_matches_baseline_md():
     assert abs(O.step_gflop_per_image(24, 27) - 216.48) < 0.02
     assert abs(2 * sum(O.generator_conv_macs(3).values()) / 1e9 - 36.714) < 0.005
     assert abs(2 * sum(O.discriminator_conv_macs(3).values()) / 1e9 - 12.960) < 0.005
+
+
+def test_usm_sharp_oracle_properties():
+    """BasicSR's USMSharp restated in oracle/esrgan_oracle.py (parity unpinned by the reference: the class lives in the
+    absent basicsr package; anchored on ssr_esrgan_model.py:31,109).  Known answers: OpenCV's sigma rule for ksize 51,
+    normalisation, identity on flat images, clipping and the soft blend on a step edge."""
+    from oracle import esrgan_oracle as O
+    k = O.usm_gaussian_kernel1d(50, 0)
+    assert k.numel() == 51 and abs(float(k.sum()) - 1.0) < 1e-12
+    assert torch.allclose(k, k.flip(0))
+    assert abs(float(k[25] / k[24]) - math.exp(1.0 / 128.0)) < 1e-12          # sigma = 8
+    flat = torch.full((1, 3, 64, 64), 0.37)
+    assert torch.allclose(O.usm_sharp(flat), flat, atol=1e-6)
+    edge = torch.zeros(1, 1, 64, 64)
+    edge[..., 32:] = 0.8
+    out = O.usm_sharp(edge)
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    assert float(out[0, 0, 32, 33]) > 0.8 + 0.05            # overshoot on the bright side of the edge
+    assert float(out[0, 0, 32, 30]) == 0.0                  # dark side: sharp value clipped at 0
+    assert torch.allclose(out[0, 0, :, 0], edge[0, 0, :, 0])   # far from the edge: residual below threshold

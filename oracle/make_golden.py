@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from oracle.ref_shim import load_reference_archs  # noqa: E402
+from oracle.ref_shim import load_reference_archs, REFERENCE_ROOT  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
@@ -146,6 +146,35 @@ def gen_index_maps():
     print("index_maps", list(fx))
 
 
+def gen_infer_utils():
+    """Golden vectors of the UNMODIFIED /root/reference/ssr/utils/infer_utils.py:format_s2naip_data (frame selection with
+    `random.sample`, black-pixel rejection, /255).  The module imports skimage.io (absent here) only for `stitch`'s PNG
+    I/O, so an empty stand-in module is enough to import it."""
+    import importlib.util
+    import random
+    import sys
+    import types
+    import numpy as np
+    sk, skio = types.ModuleType("skimage"), types.ModuleType("skimage.io")
+    sk.io = skio
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.io", skio)
+    spec = importlib.util.spec_from_file_location("ref_infer_utils", os.path.join(REFERENCE_ROOT, "ssr/utils/infer_utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.RandomState(7)
+    cases = []
+    for T, n, nblack in [(8, 8, 0), (12, 8, 3), (10, 8, 5), (6, 1, 2)]:
+        data = rng.randint(1, 256, size=(T * 32, 32, 3)).astype(np.uint8)
+        for f in rng.choice(T, nblack, replace=False):
+            data[f * 32 + 5, 7, rng.randint(3)] = 0            # a single zero channel value marks the frame "bad" (:17)
+        random.seed(1234 + T)
+        t, img = m.format_s2naip_data(data, n, "cpu")
+        cases.append({"data": torch.from_numpy(data), "n": n, "seed": 1234 + T, "tensor": t.clone(),
+                      "image": torch.from_numpy(img.copy())})
+    torch.save({"format_s2naip_data": cases}, os.path.join(OUT, "infer_utils.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -168,3 +197,4 @@ if __name__ == "__main__":
              g_kw=dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8),
              d_kw=dict(num_in_ch=9, num_feat=8, skip_connection=True), feed_disc_lr=True)
     gen_index_maps()
+    gen_infer_utils()

@@ -512,13 +512,16 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     int st = 0, target = 4;
     for (int k = 0; k < ntile; ++k) {
+        GPROBE_K(2);
         while (wg_ld(ctl + WGC_READY + st) < target) {}
+        GPROBE_K(3);
         const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
         int* dw_ = ctl + WGC_DONE + wave;
         if (nu == 5) wg3_contract<5>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
         else if (nu == 4) wg3_contract<4>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
         else if (nu == 3) wg3_contract<3>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
         else wg3_contract<2>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
+        GPROBE_K(4);
         if (st == 1) target += 4;
         st ^= 1;
     }

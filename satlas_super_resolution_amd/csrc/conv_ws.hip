@@ -32,6 +32,11 @@ constexpr int WS_TH = 8, WS_TW = 16, WS_PH = WS_TH + 2, WS_PW = WS_TW + 2, WS_PI
 constexpr int WS_AROW = 80;                                   // bytes per patch row: 32 bf16 + 16 pad
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 
+// lane-slot s (0..31) of a wave's 2 x 16 pixel tile -> column: the second row is rotated by 14 so that with the patch
+// pitch of 18 pixels the 16 lanes the LDS serves together read rows that are distinct mod 16 (80-byte rows: bank = 20 r mod 64)
+// -> conflict-free ds_read_b128 for every tap (same map as conv_big.hip)
+__device__ __forceinline__ int ws_col(int s) { return s < 16 ? s : ((s + 14) & 15); }
+
 #define WS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Epilogue variants.  The epilogue is VALU / issue bound (tools/ws_probe.hip: with every feature a run-time
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
     const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
     const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
-    const int a_off = ((2 * wave + (i >> 4)) * WS_PW + (i & 15)) * WS_AROW + g * 16;   // this lane's pixel
+    const int a_off = ((2 * wave + (i >> 4)) * WS_PW + ws_col(i)) * WS_AROW + g * 16;   // this lane's pixel
     __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * 32 * NT);   // [32 px][32*NT co]
     __bf16* slab1 = slab + 4 * (32 * 32 * NT);                // second output (lean Y1 variants)
 
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
 #endif
         WPROBE(1);
         // ---- this lane's output pixel ----
-        const int gy = gy0 + 2 * wave + (i >> 4), gx = gx0 + (i & 15);
+        const int gy = gy0 + 2 * wave + (i >> 4), gx = gx0 + ws_col(i);
         const bool pvalid = gy < d.Gh && gx < d.Gw;
         const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
         const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
             for (int h = 0; h < 32 * PARTS / 64; ++h) {
                 const int v = h * 64 + lane;
                 const int pix = v / PARTS, part = v - pix * PARTS;
-                const int dy = pix >> 4, dx = pix & 15;
+                const int dy = pix >> 4, dx = ws_col(pix);
                 const int c = co0 + part * 8;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(sl + pix * (32 * NT) + part * 8);
 #ifdef WS_NO_STORE
@@ -381,7 +386,6 @@ bool ssr_conv_ws_shape_ok(const ssr_conv_desc& d) {
     if (d.dtype != SSR_BF16) return false;
     if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p) return false;
     if (d.Cin > 64 || (d.Cout % 8) != 0) return false;
-    if (d.Cin > 32 && (d.CoutPad % 64) != 0) return false;
     if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
     if (d.r1.p && d.r1_nc < d.Cout) return false;
     if (d.r2.p && d.r2_nc < d.Cout) return false;
@@ -394,8 +398,15 @@ bool ssr_conv_ws_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force
     if (force ? !ssr_conv_ws_shape_ok(d) : !ssr_conv_ws_qualifies(d)) return false;
     // Cin <= 32: 32-channel output tiles, 2 workgroups per CU; Cin <= 64: 64-channel tiles held by one wave per SIMD
     // (288 weight registers) when the padded output width allows it
+    // Cin <= 64: 32-channel tiles with TWO workgroups per CU (one's epilogue overlaps the other's MFMAs: 27.7 vs 36.0 us on
+    // a 64->64 128x128 layer) for the epilogue variants that fit 256 registers without spilling (plain / LeakyReLU);
+    // the others keep 64-channel tiles on one wave per SIMD.  SSR_CONV_WS21=0 / 2: never / always 32-channel tiles.
+    static const int v21 = [] { const char* e = getenv("SSR_CONV_WS21"); return e ? atoi(e) : 1; }();
+    const bool light = !d.y0.p && !d.y1.p && !d.r2.p && !d.r1.p && !d.m.p && !d.accumulate && d.alpha == 1.f;
     if (d.Cin <= 32) *rc = launch_ws<1, 1>(d, st);
+    else if (v21 == 2 || (v21 == 1 && light)) *rc = launch_ws<2, 1>(d, st);
     else if (d.CoutPad % 64 == 0) *rc = launch_ws<2, 2>(d, st);
+    else if (force) *rc = launch_ws<2, 1>(d, st);             // spills with the heavier epilogues: only on request
     else return false;
     return true;
 }

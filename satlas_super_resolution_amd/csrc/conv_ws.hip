@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     // ---- patch staging: everything that does not depend on the tile is computed once ----
     // vector v = tid + 256 q of the patch: consecutive lanes read consecutive 16-B parts of one pixel (all planes)
     // and then the next pixel: a 64-channel NHWC row is one 128-B line -> a wave instruction touches 8 full lines
-    int p_rel[NPV], p_yx[NPV], p_lds[NPV];
+    int p_rel[NPV], p_yx[NPV];
 #pragma unroll
     for (int q = 0; q < NPV; ++q) {
         const int v = tid + q * 256;
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
         const bool ok = v < NV && c < d.Cin;
         p_rel[q] = ((((py - 1) >> upshift) * d.Wi + ((px - 1) >> upshift)) * d.x.cs + c);
         p_yx[q] = ok ? ((py - 1) & 0xffff) | ((px - 1) << 16) : 0x7fff7fff;   // never inside
-        p_lds[q] = pl * PLANE + pix * WS_AROW + part * 16;
     }
     u32x4 rp[NPV];
     auto load_patch = [&](int n, int gy0, int gx0) {
@@ -116,8 +115,11 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     auto store_patch = [&](int buf) {
         char* base = smem + buf * BUF;
 #pragma unroll
-        for (int q = 0; q < NPV; ++q)
-            if (tid + q * 256 < NV) *reinterpret_cast<u32x4*>(base + p_lds[q]) = rp[q];
+        for (int q = 0; q < NPV; ++q) {
+            const int v = tid + q * 256;
+            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
+            if (v < NV) *reinterpret_cast<u32x4*>(base + (pp8 >> 2) * PLANE + pix * WS_AROW + (pp8 & 3) * 16) = rp[q];
+        }
     };
     auto decode = [&](int tile, int& n, int& gy0, int& gx0) {
         int b = tile;
@@ -162,24 +164,28 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
         const bool pvalid = gy < d.Gh && gx < d.Gw;
         const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
         const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
-        // lean variants: the epilogue operands of this lane's pixel are requested now and land under the MFMAs
+        // lean variants: the epilogue operands of this lane's pixel.  With one wave per SIMD (64-channel tiles) they are
+        // requested now and land under the MFMAs; the two-workgroups-per-CU variants request them after the MFMA loop to
+        // stay inside 256 registers (the other workgroup covers the latency).
+        constexpr bool EARLY_OPS = NPL * NT > 2;
         u32x2 q1[EP >= 0 && (EP & WS_R1) ? NT * 4 : 1], qa[EP >= 0 && (EP & WS_ACC) ? NT * 4 : 1],
             qm[EP >= 0 && (EP & WS_MASK) ? NT * 4 : 1];
-        if constexpr (EP >= 0) {
+        auto load_ops = [&]() {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int c = co0 + t * 32 + 8 * q4 + co_l;
                     const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
-                    if constexpr ((EP & WS_R1) != 0)
+                    if constexpr (EP >= 0 && (EP & WS_R1) != 0)
                         q1[t * 4 + q4] = *reinterpret_cast<const u32x2*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
-                    if constexpr ((EP & WS_ACC) != 0)
+                    if constexpr (EP >= 0 && (EP & WS_ACC) != 0)
                         qa[t * 4 + q4] = *reinterpret_cast<const u32x2*>(yp + pp * d.y.cs + d.y.coff + cc);
-                    if constexpr ((EP & WS_MASK) != 0)
+                    if constexpr (EP >= 0 && (EP & WS_MASK) != 0)
                         qm[t * 4 + q4] = *reinterpret_cast<const u32x2*>(mp + pp * d.m.cs + d.m.coff + cc);
                 }
-        }
+        };
+        if constexpr (EP >= 0 && EARLY_OPS) load_ops();
         // ---- 9 taps x NPL planes x 2 k-substeps; accumulators start at the bias ----
         WPROBE(2);
         f32x16 acc[NT];
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
         __builtin_amdgcn_sched_barrier(0);
         WPROBE(3);
         if constexpr (EP >= 0) {
+            if constexpr (!EARLY_OPS) load_ops();
             // ---- lean epilogue: this lane = one pixel x 16*NT channels (rows 8*q4 + 4*g + e of the C fragments) ----
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -403,8 +410,10 @@ bool ssr_conv_ws_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force
     // the others keep 64-channel tiles on one wave per SIMD.  SSR_CONV_WS21=0 / 2: never / always 32-channel tiles.
     static const int v21 = [] { const char* e = getenv("SSR_CONV_WS21"); return e ? atoi(e) : 1; }();
     const bool light = !d.y0.p && !d.y1.p && !d.r2.p && !d.r1.p && !d.m.p && !d.accumulate && d.alpha == 1.f;
+    const bool mask_only = !d.y0.p && !d.y1.p && !d.r2.p && !d.r1.p && d.m.p && !d.accumulate && d.alpha == 1.f &&
+                           d.act != SSR_ACT_LRELU;
     if (d.Cin <= 32) *rc = launch_ws<1, 1>(d, st);
-    else if (v21 == 2 || (v21 == 1 && light)) *rc = launch_ws<2, 1>(d, st);
+    else if (v21 == 2 || (v21 >= 1 && light) || (v21 == 3 && mask_only)) *rc = launch_ws<2, 1>(d, st);
     else if (d.CoutPad % 64 == 0) *rc = launch_ws<2, 2>(d, st);
     else if (force) *rc = launch_ws<2, 1>(d, st);             // spills with the heavier epilogues: only on request
     else return false;

@@ -324,12 +324,16 @@ bool ssr_conv_res_qualifies(const ssr_conv_desc& d);
 // weight-stationary persistent kernel for the large-spatial layers (conv_ws.hip)
 bool ssr_conv_ws_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
 bool ssr_conv_ws_qualifies(const ssr_conv_desc& d);
+// thin-output VALU kernel for the logit / RGB heads (conv_thin.hip)
+bool ssr_conv_thin_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
+bool ssr_conv_thin_qualifies(const ssr_conv_desc& d);
 // big-tile kernel for the wide discriminator layers (conv_big.hip)
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
 bool ssr_conv_big_qualifies(const ssr_conv_desc& d);
 
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
+    if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
     if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
     if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
     if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
@@ -357,6 +361,8 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     int rc = 0;
     if (impl == 1) return ssr_conv_ws_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
     if (impl == 4) return ssr_conv_big_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+    if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+    if (impl == 0 && ssr_conv_thin_try(d, st, &rc, false)) return rc;
     if (impl == 0 && ssr_conv_ws_try(d, st, &rc, false)) return rc;
     if (impl == 0 && ssr_conv_big_try(d, st, &rc, false)) return rc;
     if (impl != 3 && ssr_conv_res_try(d, st, &rc)) return rc;

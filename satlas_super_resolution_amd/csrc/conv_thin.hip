@@ -1,0 +1,139 @@
+// Thin-output 3x3 convolution (bf16, Cout <= 8, Cin <= 64): the logit / RGB heads and the dgrad into a 3-channel input.
+//
+// conv9 (64 -> 1), conv_last (64 -> 3) and conv0's dgrad (64 -> 3) at 128x128 cost 38..67 us each on the MFMA kernels
+// (r01 rocprofv3): a 32-wide MFMA tile is 97 % / 91 % padding there and the launch is all staging and epilogue.  The work
+// is 576 MACs per pixel per output channel — one v_dot2c_f32_bf16 per channel pair — and the layer is bound by reading
+// its input once (33.5 MB at B = 16).  So: no matrix core.  One thread = one pixel; an 8 x 32 pixel tile's halo patch sits
+// in LDS (144-byte rows: consecutive lanes 36 banks apart -> conflict-free ds_read_b128), the weights arrive through
+// scalar loads (wave-uniform addresses) as SGPR operands of the dot instructions, fp32 accumulation, full ssr_conv_desc epilogue on <= 8 values per lane.
+//
+// Replaces nn.Conv2d forward at /root/reference/ssr/archs/discriminator_arch.py:40,69 (conv9), rrdbnet_arch.py:113,136
+// (conv_last) and autograd's input gradient of discriminator_arch.py:28,44 (conv0) in the generator phase.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int CT_TH = 8, CT_TW = 32, CT_PH = CT_TH + 2, CT_PW = CT_TW + 2, CT_NPIX = CT_PH * CT_PW;   // 340
+typedef __bf16 bf16x2t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float ct_dot8(const u32x4& a, const u32x4& b, float acc) {
+    // written out: with a loop-indexed subscript of the vector references hipcc 7.2 folded all four to element 0
+    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2t, a0), __builtin_bit_cast(bf16x2t, b0), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2t, a1), __builtin_bit_cast(bf16x2t, b1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2t, a2), __builtin_bit_cast(bf16x2t, b2), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2t, a3), __builtin_bit_cast(bf16x2t, b3), acc, false);
+    return acc;
+}
+
+template <int NCO>   // accumulators per thread: 1, 4 or 8 (Cout rounded up)
+__global__ __launch_bounds__(256) void conv_thin_kernel(const ssr_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int cin = d.Cin, nvec = cin >> 3;                   // 16-byte vectors per pixel
+    const int rowb = cin * 2 + 16;                            // padded LDS row
+    const int tiles_x = (d.Gw + CT_TW - 1) / CT_TW, tiles_y = (d.Gh + CT_TH - 1) / CT_TH;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * CT_TH, gx0 = tx_i * CT_TW;
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
+    // ---- stage the halo patch: vector v = pixel * nvec + part ----
+    for (int v = tid; v < CT_NPIX * nvec; v += 256) {
+        const int pix = v / nvec, part = v - pix * nvec;
+        const int py = pix / CT_PW, px = pix - py * CT_PW;
+        const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi)
+            val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + part * 8);
+        *reinterpret_cast<u32x4*>(smem + pix * rowb + part * 16) = val;
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    float acc[NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) acc[c] = 0.f;
+    const char* pb = smem + (ty * CT_PW + tx) * rowb;
+    // weights come straight from the packed global array: the address is uniform across the wave, so hipcc emits scalar
+    // loads and v_dot2c takes them from SGPRs — one LDS read (the pixel) per 4 * NCO dot instructions
+    for (int tap = 0; tap < 9; ++tap) {
+        const char* pr = pb + ((tap / 3) * CT_PW + tap % 3) * rowb;
+        for (int k = 0; k < nvec; ++k) {
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(pr + k * 16);
+            const __bf16* wk = wg + ((size_t)((k >> 2) * 9 + tap) * d.CoutPad) * 32 + (k & 3) * 8;
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) {
+                const u32x4 wv = *reinterpret_cast<const u32x4*>(wk + c * 32);
+                acc[c] = ct_dot8(xv, wv, acc[c]);
+            }
+        }
+    }
+    // ---- epilogue (ssr_conv_desc contract) on this pixel's Cout values ----
+    const int gy = gy0 + ty, gx = gx0 + tx;
+    if (gy >= d.Gh || gx >= d.Gw) return;
+    const size_t pp = (size_t)(n * d.Ho + gy * d.oys + d.oyo) * d.Wo + gx * d.oxs + d.oxo;
+    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
+    __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
+    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
+    const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
+    const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        if (c >= d.Cout) break;
+        float v = acc[c] + (d.bias ? d.bias[c] : 0.f);
+        if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+        v *= d.alpha;
+        if (y0p) y0p[pp * d.y0.cs + d.y0.coff + c] = (__bf16)v;
+        if (r1p && c < d.r1_nc) v += d.beta1 * (float)r1p[pp * d.r1.cs + d.r1.coff + c];
+        if (r2p && c < d.r2_nc) v += d.beta2 * (float)r2p[pp * d.r2.cs + d.r2.coff + c];
+        if (d.accumulate) v += (float)yp[pp * d.y.cs + d.y.coff + c];
+        if (y1p) y1p[pp * d.y1.cs + d.y1.coff + c] = (__bf16)v;
+        if (mp && c >= d.m_c0 && c < d.m_c1) v *= lrelu_grad_from_out((float)mp[pp * d.m.cs + d.m.coff + c]);
+        yp[pp * d.y.cs + d.y.coff + c] = (__bf16)v;
+    }
+}
+
+template <int NCO>
+int launch_thin(const ssr_conv_desc& d, hipStream_t st) {
+    const size_t lds = (size_t)CT_NPIX * (d.Cin * 2 + 16);
+    auto kern = conv_thin_kernel<NCO>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           CT_NPIX * (64 * 2 + 16) + 9 * 8 * 64 * 2);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = d.N * ((d.Gh + CT_TH - 1) / CT_TH) * ((d.Gw + CT_TW - 1) / CT_TW);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+}  // namespace
+
+bool ssr_conv_thin_shape_ok(const ssr_conv_desc& d) {
+    if (d.dtype != SSR_BF16) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p || d.up != 1) return false;
+    if (d.Cin > 64 || (d.Cin % 8) != 0 || d.Cout > 8 || d.Cout < 1) return false;
+    if (d.Gh != d.Hi || d.Gw != d.Wi) return false;
+    return (d.x.cs % 8) == 0 && (d.x.coff % 8) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0;
+}
+
+bool ssr_conv_thin_qualifies(const ssr_conv_desc& d) {
+    static const bool off = [] { const char* e = getenv("SSR_CONV_THIN"); return e && e[0] == '0'; }();
+    if (off || !ssr_conv_thin_shape_ok(d)) return false;
+    return (long)d.N * d.Gh * d.Gw >= 65536;                  // enough 256-pixel tiles to fill the chip
+}
+
+bool ssr_conv_thin_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
+    if (force ? !ssr_conv_thin_shape_ok(d) : !ssr_conv_thin_qualifies(d)) return false;
+    if (d.Cout == 1) *rc = launch_thin<1>(d, st);
+    else if (d.Cout <= 4) *rc = launch_thin<4>(d, st);
+    else *rc = launch_thin<8>(d, st);
+    return true;
+}

@@ -673,3 +673,42 @@ def test_train_step_feeds_usm_sharpened_l1_target():
     assert float((l1 - O.usm_sharp(gt.cpu() / 255)).abs().max()) < 1e-3
     ts.step(1)
     assert all(math.isfinite(v) for v in ts.log().values())
+
+
+@pytest.mark.parametrize("variant", ["bias", "lrelu_r1", "mask_acc", "dual"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 1, 16, 40, 2), (64, 3, 9, 33, 1), (24, 3, 8, 32, 1), (64, 8, 16, 32, 1)])
+def test_thin_output_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
+    """csrc/conv_thin.hip (v_dot2c_f32_bf16 dot products, one pixel per thread; the conv9 / conv_last / conv0-dgrad shapes)
+    forced through ssr_conv2d_impl(impl=5) against the pipelined MFMA kernel (impl=3), epilogue features included."""
+    import ctypes as C
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cin + cout + H + len(variant))
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    cp = 8                                                     # outputs live in 8-channel padded buffers
+    mk = lambda c: (torch.randn(B, H, W, c, device="cuda") * 0.5).to(tdt).contiguous()
+    xb, r1, m, y_init = mk(cin), mk(cp), mk(cp), mk(cp)
+    outs = {}
+    for impl in (5, 3):
+        y, y0, y1 = y_init.clone(), torch.zeros_like(y_init), torch.zeros_like(y_init)
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        kw = dict(act=hip.ACT_LRELU if variant in ("lrelu_r1", "dual") else hip.ACT_NONE, cin=cin)
+        if variant in ("lrelu_r1", "dual"):
+            kw.update(r1=hip.view(r1), r1_nc=cout, beta1=0.5)
+        if variant == "dual":
+            kw.update(alpha=0.7, y0=hip.view(y0))
+        d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), **kw)
+        if variant in ("mask_acc", "dual"):
+            d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        if variant == "mask_acc":
+            d.accumulate = 1
+        if variant == "dual":
+            d.y1 = hip.view(y1)
+        hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+        torch.cuda.synchronize()
+        outs[impl] = tuple(t[..., :cout].float().cpu() for t in (y, y0, y1))
+    for a, b, nm in zip(outs[5], outs[3], ("y", "y0", "y1")):
+        assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))

@@ -47,8 +47,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed oracle steps after one warm-up (~8 s of CPU work at the default)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="oracle threads (PyTorch CPU does not scale past ~16 on this network at batch 2)")
     return ap.parse_args()

@@ -330,6 +330,7 @@ bool ssr_conv_thin_qualifies(const ssr_conv_desc& d);
 // big-tile kernel for the wide discriminator layers (conv_big.hip)
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
 bool ssr_conv_big_qualifies(const ssr_conv_desc& d);
+bool ssr_conv_big_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int* rc);
 
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
@@ -392,6 +393,8 @@ extern "C" int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream
                 return SSR_EINVAL;
         }
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        int rcb = 0;
+        if (ssr_conv_big_batch_try(ds, n, st, &rcb)) return rcb;   // 512-pixel tiles (conv_big.hip) when the grid is large enough
         bool nt2, small;
         pick_tile(ds[0], nt2, small);
         // the class launches together fill the chip: use the tile shape the 4x larger grid would get

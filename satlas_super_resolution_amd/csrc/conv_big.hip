@@ -31,17 +31,22 @@
 
 namespace {
 
-constexpr int CB_TH = 32, CB_TW = 16, CB_PH = CB_TH + 2, CB_PW = CB_TW + 2, CB_NPIX = CB_PH * CB_PW;   // 612
+constexpr int CB_TH = 32, CB_TW = 16;
 constexpr int CB_AROW = 80;                                  // bytes per LDS row: 32 bf16 + 16 pad
-constexpr int CB_PATCH = CB_NPIX * CB_AROW;                  // 48,960
-constexpr int CB_WROWS = 9 * 64;
-constexpr int CB_WBYTES = CB_WROWS * CB_AROW;                // 46,080
-constexpr int CB_BIAS = CB_PATCH + CB_WBYTES;                // 64 floats
-constexpr int CB_LDS = CB_BIAS + 256;
-constexpr int CB_NPV = (CB_NPIX * 4 + 255) / 256;            // 10 patch vectors per thread
-constexpr int CB_NWV = CB_WROWS * 4 / 256;                   // 9 weight vectors per thread
-static_assert(CB_NPV + CB_NWV == 19, "19 staging vectors per thread: one per k-step + one");
-static_assert(CB_LDS <= 160 * 1024 && 2 * 4 * 32 * 64 * 2 <= CB_PATCH, "LDS budget / output slabs fit in the patch area");
+// KT x KT taps: 3 (the 3x3 layers) or 2 (one output-parity class of a 4x4 stride-2 transposed conv: conv1..conv3 dgrad)
+template <int KT> struct CbT {
+    static constexpr int PH = CB_TH + KT - 1, PW = CB_TW + KT - 1, NPIX = PH * PW;     // 612 / 561
+    static constexpr int PATCH = NPIX * CB_AROW;               // 48,960 / 44,880
+    static constexpr int WROWS = KT * KT * 64;
+    static constexpr int WBYTES = WROWS * CB_AROW;             // 46,080 / 20,480
+    static constexpr int BIAS = PATCH + WBYTES;                // 64 floats
+    static constexpr int LDS = BIAS + 256;
+    static constexpr int NPV = (NPIX * 4 + 255) / 256;         // patch vectors per thread: 10 / 9
+    static constexpr int NWV = WROWS * 4 / 256;                // weight vectors per thread: 9 / 4
+    static constexpr int NSTEP = KT * KT * 2;                  // k-steps per 32-channel chunk: 18 / 8
+    static constexpr int LPS = (NPV + NWV + NSTEP - 1) / NSTEP;   // staging loads sprinkled per k-step: 2 / 2
+    static_assert(LDS <= 160 * 1024 && 2 * 4 * 32 * 64 * 2 <= PATCH, "LDS budget / output slabs fit in the patch area");
+};
 
 constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_Y0 = 16, CB_GENERIC = -1;   // Y0: second output = activation before the residual
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
@@ -49,14 +54,18 @@ typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float cb_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float cb_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
-// pixel of lane-slot s (0..31) of pixel tile m of wave w: tile rows 8w + 2m, 8w + 2m + 1
+// pixel of lane-slot s (0..31) of pixel tile m of wave w: tile rows 8w + 2m, 8w + 2m + 1; the second row is rotated by
+// 32 - PW so that the rows the 16-lane read groups touch are distinct mod 16 for every tap
+template <int KT>
 __device__ __forceinline__ void cb_pixel(int w, int m, int s, int& row, int& col) {
     row = 8 * w + 2 * m + (s >> 4);
-    col = s < 16 ? s : ((s + 14) & 15);
+    col = s < 16 ? s : ((s + 32 - CbT<KT>::PW) & 15);
 }
 
-template <int EP>
-__global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d) {
+template <int EP, int KT>
+__device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
+    using T = CbT<KT>;
+    constexpr int CB_PW = T::PW, CB_NPIX = T::NPIX, CB_PATCH = T::PATCH, CB_BIAS = T::BIAS, CB_NPV = T::NPV, CB_NWV = T::NWV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
     const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
     const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
     const int nchunks = (d.Cin + 31) / 32;
-    const size_t wchunk = (size_t)9 * d.CoutPad * 32;
+    const size_t wchunk = (size_t)KT * KT * d.CoutPad * 32;
 
     float* bias_lds = reinterpret_cast<float*>(smem + CB_BIAS);
     if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
         const int v = tid + q * 256;
         const int pix = v >> 2, part = v & 3;
         const int py = pix / CB_PW, px = pix - py * CB_PW;
-        const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+        const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
         const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
         pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
         plo[q] = v < CB_NPIX * 4 ? pix * CB_AROW + part * 16 : -1;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         int row, col;
-        cb_pixel(wave, m, i, row, col);
+        cb_pixel<KT>(wave, m, i, row, col);
         a_off[m] = (row * CB_PW + col) * CB_AROW + g * 16;
     }
     const int b_off = CB_PATCH + i * CB_AROW + g * 16;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
         const bool has_next = c + 1 < nchunks;
         // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
         // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
-        constexpr int NSTEP = 18, CB_PF = 2;
+        constexpr int NSTEP = T::NSTEP, CB_PF = 2;
         u32x4 wq[NSTEP][2], pq[NSTEP][4];
         auto issue = [&](auto sc) {
             constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
                 wq[s_][t] = *reinterpret_cast<const u32x4*>(smem + b_off + (tap * 64 + t * 32) * CB_AROW + kk * 32);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                pq[s_][m] = *reinterpret_cast<const u32x4*>(smem + a_off[m] + ((tap / 3) * CB_PW + tap % 3) * CB_AROW + kk * 32);
+                pq[s_][m] = *reinterpret_cast<const u32x4*>(smem + a_off[m] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
         };
         static_for<0, CB_PF>([&](auto sc) { issue(sc); });
         static_for<0, NSTEP>([&](auto sc) {
@@ -178,8 +187,10 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (s_ + CB_PF < NSTEP) issue(std::integral_constant<int, s_ + CB_PF>{});
             if (has_next) {
-                load_one(c + 1, std::integral_constant<int, s_>{});
-                if constexpr (s_ == NSTEP - 1) load_one(c + 1, std::integral_constant<int, NSTEP>{});
+                static_for<0, T::LPS>([&](auto lc) {
+                    constexpr int j = s_ * T::LPS + decltype(lc)::value;
+                    if constexpr (j < CB_NPV + CB_NWV) load_one(c + 1, std::integral_constant<int, j>{});
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         int row, col;
-        cb_pixel(wave, m, i, row, col);
+        cb_pixel<KT>(wave, m, i, row, col);
         const int gy = gy0 + row, gx = gx0 + col;
         const bool pvalid = gy < d.Gh && gx < d.Gw;
         const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
                 const int v = h * 64 + lane;
                 const int s_ = v >> 3, part = v & 7;
                 int prow, pcol;
-                cb_pixel(wave, m, s_, prow, pcol);
+                cb_pixel<KT>(wave, m, s_, prow, pcol);
                 const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * 64 + part * 8);
                 if (oy < d.Gh && ox < d.Gw && c < d.Cout)
@@ -318,19 +329,54 @@ __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d)
     BPROBE(8);
 }
 
-template <int EP>
-int launch_big(const ssr_conv_desc& d, hipStream_t st) {
-    auto kern = conv_big_kernel<EP>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+template <int EP, int KT>
+__global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d) {
+    conv_big_body<EP, KT>(d);
+}
+// up to four descriptors of identical geometry (the output-parity classes of a stride-2 transposed conv), blockIdx.z selects
+struct ssr_conv_desc4b { ssr_conv_desc d[4]; };
+template <int EP, int KT>
+__global__ __launch_bounds__(256, 1) void conv_big_kernel4(const ssr_conv_desc4b p) {
+    conv_big_body<EP, KT>(p.d[blockIdx.z]);
+}
+
+template <int EP, int KT>
+int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
+    constexpr int lds = CbT<KT>::LDS;
+    const ssr_conv_desc& d = ds[0];
     const int tiles = d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW);
-    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, 1), dim3(256), CB_LDS, st, d);
+    if (n == 1) {
+        auto kern = conv_big_kernel<EP, KT>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, 1), dim3(256), lds, st, d);
+    } else {
+        auto kern = conv_big_kernel4<EP, KT>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        ssr_conv_desc4b p;
+        for (int k = 0; k < 4; ++k) p.d[k] = ds[k < n ? k : 0];
+        hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, n), dim3(256), lds, st, p);
+    }
     SSR_LAUNCH_CHECK();
     return SSR_OK;
+}
+
+// feature set of the branch-free epilogue instantiation that fits `d`, or CB_GENERIC
+int cb_epilogue_of(const ssr_conv_desc& d) {
+    auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
+    if ((!d.y0.p || al16(d.y0)) && !d.y1.p && !d.r2.p && d.alpha == 1.f)
+        return (d.act == SSR_ACT_LRELU ? CB_LRELU : 0) | (d.m.p ? CB_MASK : 0) | (d.r1.p ? CB_R1 : 0) |
+               (d.accumulate ? CB_ACC : 0) | (d.y0.p ? CB_Y0 : 0);
+    return CB_GENERIC;
 }
 
 }  // namespace
@@ -338,7 +384,9 @@ int launch_big(const ssr_conv_desc& d, hipStream_t st) {
 // everything except the grid-size heuristic (ssr_conv2d_impl(impl = 4) forces this kernel on small shapes)
 bool ssr_conv_big_shape_ok(const ssr_conv_desc& d) {
     if (d.dtype != SSR_BF16) return false;
-    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p) return false;
+    const bool k3 = d.KH == 3 && d.KW == 3 && d.pad_y == 1 && d.pad_x == 1;
+    const bool k2 = d.KH == 2 && d.KW == 2 && (d.pad_y == 0 || d.pad_y == 1) && (d.pad_x == 0 || d.pad_x == 1);
+    if (!(k3 || k2) || d.stride != 1 || d.x2.p) return false;
     if (d.Cin < 32 || (d.CoutPad % 64) != 0 || (d.Cout % 8) != 0) return false;
     if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
     if (d.r1.p && d.r1_nc < d.Cout) return false;
@@ -351,29 +399,43 @@ bool ssr_conv_big_shape_ok(const ssr_conv_desc& d) {
 
 bool ssr_conv_big_qualifies(const ssr_conv_desc& d) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_BIGTILE"); return e && e[0] == '0'; }();
-    if (off || !ssr_conv_big_shape_ok(d)) return false;
+    if (off || !ssr_conv_big_shape_ok(d) || d.KH != 3) return false;
     if (d.Cin <= 64) return false;                            // weight-stationary kernel (conv_ws.hip) territory
     const long wgs = (long)d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW) * (d.CoutPad / 64);
     return wgs >= 128;                                        // at least half the CUs get a 512-pixel tile
 }
 
+template <int KT>
+static int cb_dispatch(const ssr_conv_desc* ds, int n, hipStream_t st) {
+    switch (cb_epilogue_of(ds[0])) {
+        case 0: return launch_big<0, KT>(ds, n, st);
+        case CB_LRELU: return launch_big<CB_LRELU, KT>(ds, n, st);
+        case CB_LRELU | CB_R1: return launch_big<CB_LRELU | CB_R1, KT>(ds, n, st);
+        case CB_LRELU | CB_R1 | CB_Y0: return launch_big<CB_LRELU | CB_R1 | CB_Y0, KT>(ds, n, st);
+        case CB_MASK: return launch_big<CB_MASK, KT>(ds, n, st);
+        case CB_MASK | CB_ACC: return launch_big<CB_MASK | CB_ACC, KT>(ds, n, st);
+        case CB_MASK | CB_R1: return launch_big<CB_MASK | CB_R1, KT>(ds, n, st);
+        default: return launch_big<CB_GENERIC, KT>(ds, n, st);
+    }
+}
+
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_big_shape_ok(d) : !ssr_conv_big_qualifies(d)) return false;
-    auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
-    if ((!d.y0.p || al16(d.y0)) && !d.y1.p && !d.r2.p && d.alpha == 1.f) {
-        const int ep = (d.act == SSR_ACT_LRELU ? CB_LRELU : 0) | (d.m.p ? CB_MASK : 0) | (d.r1.p ? CB_R1 : 0) |
-                       (d.accumulate ? CB_ACC : 0) | (d.y0.p ? CB_Y0 : 0);
-        switch (ep) {
-            case 0: *rc = launch_big<0>(d, st); return true;
-            case CB_LRELU: *rc = launch_big<CB_LRELU>(d, st); return true;
-            case CB_LRELU | CB_R1: *rc = launch_big<CB_LRELU | CB_R1>(d, st); return true;
-            case CB_LRELU | CB_R1 | CB_Y0: *rc = launch_big<CB_LRELU | CB_R1 | CB_Y0>(d, st); return true;
-            case CB_MASK: *rc = launch_big<CB_MASK>(d, st); return true;
-            case CB_MASK | CB_ACC: *rc = launch_big<CB_MASK | CB_ACC>(d, st); return true;
-            case CB_MASK | CB_R1: *rc = launch_big<CB_MASK | CB_R1>(d, st); return true;
-            default: break;
-        }
-    }
-    *rc = launch_big<CB_GENERIC>(d, st);
+    *rc = d.KH == 3 ? cb_dispatch<3>(&d, 1, st) : cb_dispatch<2>(&d, 1, st);
+    return true;
+}
+
+// n <= 4 parity-class descriptors (2x2 stride 1, identical geometry and epilogue features) in one launch
+bool ssr_conv_big_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int* rc) {
+    const char* e = getenv("SSR_CONV_BIGTILE2");             // 0: never, 2: always (tests), default: by grid size
+    const bool off = e && e[0] == '0', always = e && e[0] == '2';
+    if (off || n < 1 || n > 4) return false;
+    const int ep = cb_epilogue_of(ds[0]);
+    for (int k = 0; k < n; ++k)
+        if (!ssr_conv_big_shape_ok(ds[k]) || ds[k].KH != 2 || cb_epilogue_of(ds[k]) != ep) return false;
+    const ssr_conv_desc& d = ds[0];
+    const long wgs = (long)d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW) * (d.CoutPad / 64) * n;
+    if (!always && (wgs < 192 || d.Gh < 24)) return false;   // small grids / half-empty 32-row tiles: pipelined kernel
+    *rc = cb_dispatch<2>(ds, n, st);
     return true;
 }

@@ -712,3 +712,41 @@ def test_thin_output_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
         outs[impl] = tuple(t[..., :cout].float().cpu() for t in (y, y0, y1))
     for a, b, nm in zip(outs[5], outs[3], ("y", "y0", "y1")):
         assert rel_err(a, b) < 1e-2, (nm, rel_err(a, b))
+
+
+@pytest.mark.parametrize("cout,cin,gh,gw,B", [(128, 64, 32, 32, 2), (64, 64, 20, 24, 1), (256, 128, 16, 16, 1)])
+def test_stride2_dgrad_big_tile_parity_classes(cout, cin, gh, gw, B, monkeypatch):
+    """dgrad of a 4x4 stride-2 conv (discriminator_arch.py:31-33 conv1..conv3) = four 2x2 parity-class convs.  The
+    big-tile 2x2 instantiation of csrc/conv_big.hip — each class forced through impl=4, and all four in ONE launch through
+    ssr_conv2d_batch — against the pipelined kernel (impl=3) on the same descriptors, with the step's epilogue
+    (residual + LeakyReLU-backward mask)."""
+    import ctypes as C
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cout + cin + gh)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 4, 2, False, True)], dt)
+    st.load_state_dict({"c.weight_orig": torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5),
+                        "c.weight_u": torch.randn(cout), "c.weight_v": torch.randn(cin * 16)})
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    mk = lambda h, w, c: (torch.randn(B, h, w, c, device="cuda") * 0.5).to(tdt).contiguous()
+    dy, r1, m = mk(gh, gw, cout), mk(2 * gh, 2 * gw, cin), mk(2 * gh, 2 * gw, cin)
+    outs = {}
+    for mode in ("pipelined", "big_each", "big_batch"):
+        y = torch.zeros(B, 2 * gh, 2 * gw, cin, device="cuda", dtype=tdt)
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        cb.dgrad(L, "c", hip.view(dy), gh, gw, hip.view(y), r1=hip.view(r1), r1_nc=cin, beta1=1.0, m=hip.view(m), m_c0=0, m_c1=cin)
+        fn, args, _ = L.calls[0]
+        arr, n = args[0], args[1]
+        if mode == "big_batch":
+            monkeypatch.setenv("SSR_CONV_BIGTILE2", "2")
+            hip.check(hip.lib().ssr_conv2d_batch(arr, n, hip.stream_ptr()), "batch")
+            monkeypatch.delenv("SSR_CONV_BIGTILE2")
+        else:
+            for k in range(n):
+                hip.check(hip.lib().ssr_conv2d_impl(C.byref(arr[k]), hip.stream_ptr(), 3 if mode == "pipelined" else 4), mode)
+        torch.cuda.synchronize()
+        outs[mode] = y.float().cpu()
+    assert rel_err(outs["big_each"], outs["pipelined"]) < 1e-2
+    assert rel_err(outs["big_batch"], outs["pipelined"]) < 1e-2

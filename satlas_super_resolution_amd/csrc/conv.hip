@@ -293,12 +293,6 @@ template <typename T, int KH, int KW, int S>
 int dispatch_tile(const ssr_conv_desc& d, hipStream_t st) {
     bool nt2, small;
     pick_tile(d, nt2, small);
-    // experiment knob (SSR_CONV_BIG): tile variant for large grids. 0 = (NT2, MW4, KS2: 512 thr, 1 block/CU),
-    // 1 = (NT1, MW4, KS1: 256 thr, ~75 KB LDS -> 2 blocks/CU), 2 = (NT2, MW4, KS1), 3 = (NT1, MW4, KS2)
-    static const int big = [] { const char* e = getenv("SSR_CONV_BIG"); return e ? atoi(e) : 0; }();
-    if (!small && big == 1) { ssr_conv_desc e = d; return launch_conv<T, KH, KW, S, 1, 4, 1>(e, st); }
-    if (!small && big == 2 && nt2) return launch_conv<T, KH, KW, S, 2, 4, 1>(d, st);
-    if (!small && big == 3) return launch_conv<T, KH, KW, S, 1, 4, 2>(d, st);
     if (nt2) return small ? launch_conv<T, KH, KW, S, 2, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 2, 4, 2>(d, st);
     return small ? launch_conv<T, KH, KW, S, 1, 2, 2>(d, st) : launch_conv<T, KH, KW, S, 1, 4, 2>(d, st);
 }

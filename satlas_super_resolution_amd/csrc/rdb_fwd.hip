@@ -427,12 +427,6 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
         if (tid < 192) bias_lds[tid] = d.bias[k] ? d.bias[k][c] : 0.f;
         if (tid >= 192 && tid < 208) ctl[tid - 192] = 0;
     }
-    // producers: a queue of RB_RQ slabs (this wave's 3 KiB of each) in registers.  The ring has only two stages (LDS is
-    // full), so run-ahead lives here: conv5 needs a slab per ~300 cycles, the six producers fetch one per ~480; the
-    // queue fills during stages 1..4, which consume a slab per 576..1152 cycles.
-    constexpr int RB_RQ = 8;
-    u32x4 wq[RB_RQ][RB_PV];
-    if (producer) static_for<0, RB_RQ>([&](auto uc) { rb_load_slab<BWD>(d, decltype(uc)::value, lane, pw, wq[decltype(uc)::value]); });
     // MFMA waves: this lane's pixels (rb_map) for every stage, requested now
     const int w4 = wave & 3;
     const int e1a = rb_map.e[0][w4][i], e1b = rb_map.e[0][w4 + 4][i];
@@ -441,11 +435,12 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
     const int e4 = rb_map.e[3][w4][i], e5 = rb_map.e[4][w4 & 1][i];
     const int e5s0 = rb_map.e[4][w4 & 1][lane >> 2], e5s1 = rb_map.e[4][w4 & 1][16 + (lane >> 2)];
     // ---- 64-channel input halo region (x / d_out): 18x18 pixels -> X0 (2 planes of 32 channels, padded rows),
-    //      staged through registers so that the rows can be padded ----
+    //      staged through registers so that the rows can be padded.  The halo is what the first MFMA needs, so its loads
+    //      are issued BEFORE the producers fill their weight queue (a wave's loads return in order). ----
+    constexpr int NQ = (2592 + RB_NTHREADS - 1) / RB_NTHREADS;
+    u32x4 rx[NQ];
     {
         const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.in.p);
-        constexpr int NQ = (2592 + RB_NTHREADS - 1) / RB_NTHREADS;
-        u32x4 rx[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int v = tid + q * RB_NTHREADS;             // (plane, pixel, part): 2 x 324 x 4 = 2592 vectors
@@ -459,6 +454,14 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
                                                       plane * 32 + part * 8);
             rx[q] = val;
         }
+    }
+    // producers: a queue of RB_RQ slabs (this wave's 3 KiB of each) in registers.  The ring has only two stages (LDS is
+    // full), so run-ahead lives here: conv5 needs a slab per ~300 cycles, the six producers fetch one per ~480; the
+    // queue fills during stages 1..4, which consume a slab per 576..1152 cycles.
+    constexpr int RB_RQ = 8;
+    u32x4 wq[RB_RQ][RB_PV];
+    if (producer) static_for<0, RB_RQ>([&](auto uc) { rb_load_slab<BWD>(d, decltype(uc)::value, lane, pw, wq[decltype(uc)::value]); });
+    {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int v = tid + q * RB_NTHREADS;

@@ -35,6 +35,18 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLO
 // derivative recovered from the *output* of LeakyReLU (sign is preserved for slope > 0);
 // at exactly 0 torch's leaky_relu_backward uses (x > 0 ? 1 : slope).
 __device__ __forceinline__ float lrelu_grad_from_out(float out) { return out > 0.f ? 1.f : LRELU_SLOPE; }
+// lrelu(v) == max(v, 0.2 v) as ONE v_max_f32: fmaxf() makes hipcc canonicalise the accumulator first (a second v_max per
+// value; the branch-free epilogues are VALU-bound at 4 cycles per instruction).  NaNs propagate (0.2 * NaN = NaN).
+__device__ __forceinline__ float lrelu_max(float v) {
+    float r;
+    const float s = LRELU_SLOPE * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(s));
+    return r;
+}
+// v * lrelu_grad_from_out(m) for the two bf16 masks packed in one dword: integer compares on the raw bits (bf16 m > 0
+// <=> its 16 bits, read as a signed integer, are > 0), no unpacking
+__device__ __forceinline__ float lrelu_mask_lo(float v, unsigned m2) { return (int)(m2 << 16) > 0 ? v : LRELU_SLOPE * v; }
+__device__ __forceinline__ float lrelu_mask_hi(float v, unsigned m2) { return (int)m2 > 0xFFFF ? v : LRELU_SLOPE * v; }
 
 // One 16-byte LDS/global operand read feeds the matrix core:
 //   fp32 : 4 x v_mfma_f32_32x32x2_f32  (lane (i,g) holds channels g*4+s, s = 0..3  -> 8 channels / read)

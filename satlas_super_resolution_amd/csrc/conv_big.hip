@@ -34,6 +34,9 @@ namespace {
 constexpr int CB_TH = 32, CB_TW = 16;
 constexpr int CB_AROW = 80;                                  // bytes per LDS row: 32 bf16 + 16 pad
 // KT x KT taps: 3 (the 3x3 layers) or 2 (one output-parity class of a 4x4 stride-2 transposed conv: conv1..conv3 dgrad)
+// output transpose slabs: [32 px][64 co] with 144-byte rows (a 128-byte pitch puts the 32 lanes of a ds_write_b64 on two
+// bank pairs: a 16-way conflict that cost 8k of the 11k epilogue cycles, tools/big_probe.hip)
+constexpr int CB_SROW = 72, CB_SLAB = 32 * CB_SROW;
 template <int KT> struct CbT {
     static constexpr int PH = CB_TH + KT - 1, PW = CB_TW + KT - 1, NPIX = PH * PW;     // 612 / 561
     static constexpr int PATCH = NPIX * CB_AROW;               // 48,960 / 44,880
@@ -45,7 +48,7 @@ template <int KT> struct CbT {
     static constexpr int NWV = WROWS * 4 / 256;                // weight vectors per thread: 9 / 4
     static constexpr int NSTEP = KT * KT * 2;                  // k-steps per 32-channel chunk: 18 / 8
     static constexpr int LPS = (NPV + NWV + NSTEP - 1) / NSTEP;   // staging loads sprinkled per k-step: 2 / 2
-    static_assert(LDS <= 160 * 1024 && 2 * 4 * 32 * 64 * 2 <= PATCH, "LDS budget / output slabs fit in the patch area");
+    static_assert(LDS <= 160 * 1024 && 2 * 4 * 32 * 72 * 2 <= PATCH, "LDS budget / output slabs fit in the patch area");
 };
 
 constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_Y0 = 16, CB_GENERIC = -1;   // Y0: second output = activation before the residual
@@ -159,6 +162,40 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             }
         }
 
+    // ---- lean epilogues: this lane's pixel of every pixel tile and its epilogue operands (residual / old value / mask).
+    //      They are requested when the LAST chunk starts, so their latency hides under its MFMAs (fetched inside the
+    //      epilogue they cost a global round trip per pixel tile: ~5 of the 11k epilogue cycles, tools/big_probe.hip). ----
+    const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
+    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
+    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
+    size_t ppx[4];
+    bool pval[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        int row, col;
+        cb_pixel<KT>(wave, m, i, row, col);
+        const int gy = gy0 + row, gx = gx0 + col;
+        pval[m] = gy < d.Gh && gx < d.Gw;
+        const int cy = pval[m] ? gy : d.Gh - 1, cx = pval[m] ? gx : d.Gw - 1;
+        ppx[m] = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
+    }
+    constexpr bool HAS_R1 = EP >= 0 && (EP & CB_R1), HAS_ACC = EP >= 0 && (EP & CB_ACC), HAS_MASK = EP >= 0 && (EP & CB_MASK);
+    u32x2c q1[HAS_R1 ? 4 : 1][8], qa[HAS_ACC ? 4 : 1][8], qm[HAS_MASK ? 4 : 1][8];
+    auto load_epi_ops = [&]() {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int c = co0 + t * 32 + 8 * q4 + co_l;
+                    const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
+                    if constexpr (HAS_R1) q1[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(r1p + ppx[m] * d.r1.cs + d.r1.coff + cc);
+                    if constexpr (HAS_ACC) qa[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(yp + ppx[m] * d.y.cs + d.y.coff + cc);
+                    if constexpr (HAS_MASK) qm[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(mp + ppx[m] * d.m.cs + d.m.coff + cc);
+                }
+    };
+
     for (int c = 0; c < nchunks; ++c) {
         BPROBE_C(2);
         if (c > 0) __syncthreads();                           // everyone is finished reading the previous chunk
@@ -168,6 +205,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         __syncthreads();
         BPROBE_C(5);
         const bool has_next = c + 1 < nchunks;
+        if (!has_next) load_epi_ops();
         // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
         // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
         constexpr int NSTEP = T::NSTEP, CB_PF = 2;
@@ -205,71 +243,91 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     __syncthreads();                                          // patch area becomes the output transpose slabs
 
     // ---- epilogue: per pixel tile m this lane = one pixel x (2 x 16) channels ----
-    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
     __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
     __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
-    const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
     const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
-    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
-    __bf16* slab = reinterpret_cast<__bf16*>(smem) + wave * (32 * 64);   // [32 lane-slots][64 co]
-    __bf16* slab0 = slab + 4 * (32 * 64);                                // second output (lean Y0 variants)
+    // the wave's [32 px][64 co] slab of pixel tile m -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
+    auto flush = [&](int m, const __bf16* sl, __bf16* __restrict__ out, const ssr_view& vw) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        int row, col;
-        cb_pixel<KT>(wave, m, i, row, col);
-        const int gy = gy0 + row, gx = gx0 + col;
-        const bool pvalid = gy < d.Gh && gx < d.Gw;
-        const int cy = pvalid ? gy : d.Gh - 1, cx = pvalid ? gx : d.Gw - 1;
-        const size_t pp = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
-        if constexpr (EP >= 0) {
-            u32x2c q1[8], qa[8], qm[8];
+        for (int h = 0; h < 4; ++h) {
+            const int v = h * 64 + lane;
+            const int s_ = v >> 3, part = v & 7;
+            int prow, pcol;
+            cb_pixel<KT>(wave, m, s_, prow, pcol);
+            const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * CB_SROW + part * 8);
+#ifdef CB_X_NOSTORE
+            if (val.x == 0x12345678u && oy < d.Gh && ox < d.Gw && c < d.Cout)
+#else
+            if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+#endif
+                *reinterpret_cast<u32x4*>(out + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * vw.cs +
+                                          vw.coff + c) = val;
+        }
+    };
+    if constexpr (EP >= 0) {
+        // branch-free variants: the slabs of MB pixel tiles are written back to back, then read and stored back to back
+        // (wave-private slabs, LDS executes a wave's operations in order: no barrier, one LDS round trip per round)
+        constexpr int NSL = (EP & CB_Y0) ? 2 : 1;
+        constexpr int MB_ = (T::PATCH + T::WBYTES) / (4 * CB_SLAB * 2 * NSL);
+        constexpr int MB = MB_ >= 4 ? 4 : MB_ >= 2 ? 2 : 1;
+        __bf16* wslab = reinterpret_cast<__bf16*>(smem) + wave * (MB * NSL * CB_SLAB);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int r0 = 0; r0 < 4; r0 += MB) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
-                    if constexpr ((EP & CB_R1) != 0) q1[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
-                    if constexpr ((EP & CB_ACC) != 0) qa[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(yp + pp * d.y.cs + d.y.coff + cc);
-                    if constexpr ((EP & CB_MASK) != 0) qm[t * 4 + q4] = *reinterpret_cast<const u32x2c*>(mp + pp * d.m.cs + d.m.coff + cc);
-                }
+            for (int mm = 0; mm < MB; ++mm) {
+                const int m = r0 + mm;
+                __bf16* slab = wslab + mm * NSL * CB_SLAB;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float v[4];
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[m][t][4 * q4 + e];
-                        if constexpr ((EP & CB_LRELU) != 0) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu()
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[m][t][4 * q4 + e];
+                            if constexpr ((EP & CB_LRELU) != 0) v[e] = lrelu_max(v[e]);   // == lrelu()
+                        }
+                        if constexpr ((EP & CB_Y0) != 0) {   // y0 = act(conv + bias), before the residual
+                            bf16x4c o0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o0[e] = (__bf16)v[e];
+                            *reinterpret_cast<bf16x4c*>(slab + CB_SLAB + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o0;
+                        }
+                        if constexpr (HAS_R1) {
+                            const u32x2c r = q1[m][t * 4 + q4];
+                            v[0] += d.beta1 * cb_lo(r[0]); v[1] += d.beta1 * cb_hi(r[0]);
+                            v[2] += d.beta1 * cb_lo(r[1]); v[3] += d.beta1 * cb_hi(r[1]);
+                        }
+                        if constexpr (HAS_ACC) {
+                            const u32x2c r = qa[m][t * 4 + q4];
+                            v[0] += cb_lo(r[0]); v[1] += cb_hi(r[0]); v[2] += cb_lo(r[1]); v[3] += cb_hi(r[1]);
+                        }
+                        if constexpr (HAS_MASK) {
+                            const u32x2c r = qm[m][t * 4 + q4];
+                            v[0] = lrelu_mask_lo(v[0], r[0]); v[1] = lrelu_mask_hi(v[1], r[0]);
+                            v[2] = lrelu_mask_lo(v[2], r[1]); v[3] = lrelu_mask_hi(v[3], r[1]);
+                        }
+                        bf16x4c o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o;
                     }
-                    if constexpr ((EP & CB_Y0) != 0) {   // y0 = act(conv + bias), before the residual
-                        bf16x4c o0;
+            }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o0[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4c*>(slab0 + i * 64 + t * 32 + 8 * q4 + co_l) = o0;
-                    }
-                    if constexpr ((EP & CB_R1) != 0) {
-                        const u32x2c r = q1[t * 4 + q4];
-                        v[0] += d.beta1 * cb_lo(r[0]); v[1] += d.beta1 * cb_hi(r[0]);
-                        v[2] += d.beta1 * cb_lo(r[1]); v[3] += d.beta1 * cb_hi(r[1]);
-                    }
-                    if constexpr ((EP & CB_ACC) != 0) {
-                        const u32x2c r = qa[t * 4 + q4];
-                        v[0] += cb_lo(r[0]); v[1] += cb_hi(r[0]); v[2] += cb_lo(r[1]); v[3] += cb_hi(r[1]);
-                    }
-                    if constexpr ((EP & CB_MASK) != 0) {
-                        const u32x2c r = qm[t * 4 + q4];
-                        v[0] *= lrelu_grad_from_out(cb_lo(r[0])); v[1] *= lrelu_grad_from_out(cb_hi(r[0]));
-                        v[2] *= lrelu_grad_from_out(cb_lo(r[1])); v[3] *= lrelu_grad_from_out(cb_hi(r[1]));
-                    }
-                    bf16x4c o;
+            for (int mm = 0; mm < MB; ++mm) {
+                const __bf16* slab = wslab + mm * NSL * CB_SLAB;
+                flush(r0 + mm, slab, yp, d.y);
+                if constexpr ((EP & CB_Y0) != 0) flush(r0 + mm, slab + CB_SLAB, y0p, d.y0);
+            }
+        }
+    } else {
+        // generic epilogue: the full ssr_conv_desc contract with run-time flags, one pixel tile at a time
+        __bf16* slab = reinterpret_cast<__bf16*>(smem) + wave * CB_SLAB;   // [32 lane-slots][64 co]
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                    *reinterpret_cast<bf16x4c*>(slab + i * 64 + t * 32 + 8 * q4 + co_l) = o;
-                }
-        } else {
-            // generic epilogue: the full ssr_conv_desc contract with run-time flags
+        for (int m = 0; m < 4; ++m) {
+            const size_t pp = ppx[m];
+            const bool pvalid = pval[m];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x4c q1g[4], q2g[4], qag[4], qmg[4];
@@ -304,27 +362,11 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                         if (y0p) *reinterpret_cast<bf16x4c*>(y0p + pp * d.y0.cs + d.y0.coff + c) = o0;
                         if (y1p) *reinterpret_cast<bf16x4c*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
                     }
-                    *reinterpret_cast<bf16x4c*>(slab + i * 64 + t * 32 + 8 * q4 + co_l) = o2;
+                    *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o2;
                 }
             }
+            flush(m, slab, yp, d.y);
         }
-        // the wave's [32 px][64 co] slab -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
-        auto flush = [&](const __bf16* sl, __bf16* __restrict__ out, const ssr_view& vw) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int v = h * 64 + lane;
-                const int s_ = v >> 3, part = v & 7;
-                int prow, pcol;
-                cb_pixel<KT>(wave, m, s_, prow, pcol);
-                const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * 64 + part * 8);
-                if (oy < d.Gh && ox < d.Gw && c < d.Cout)
-                    *reinterpret_cast<u32x4*>(out + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * vw.cs +
-                                              vw.coff + c) = val;
-            }
-        };
-        flush(slab, yp, d.y);
-        if constexpr (EP >= 0 && (EP & CB_Y0) != 0) flush(slab0, y0p, d.y0);
     }
     BPROBE(8);
 }

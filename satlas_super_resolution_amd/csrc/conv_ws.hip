@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
     const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
     const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
+    constexpr int SROW = 32 * NT + 8;                         // slab row pitch in elements
     const int a_off = ((2 * wave + (i >> 4)) * WS_PW + ws_col(i)) * WS_AROW + g * 16;   // this lane's pixel
-    __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * 32 * NT);   // [32 px][32*NT co]
-    __bf16* slab1 = slab + 4 * (32 * 32 * NT);                // second output (lean Y1 variants)
+    __bf16* slab = reinterpret_cast<__bf16*>(smem + 2 * BUF + 256) + wave * (32 * SROW);   // [32 px][32*NT co], rows padded by 16 B (bank spread)
+    __bf16* slab1 = slab + 4 * (32 * SROW);                // second output (lean Y1 variants)
 
     int tile = blockIdx.x;
     int n, gy0, gx0;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[t][4 * q4 + e];
-                        if constexpr ((EP & WS_LRELU) != 0) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu()
+                        if constexpr ((EP & WS_LRELU) != 0) v[e] = lrelu_max(v[e]);   // == lrelu()
                     }
                     if constexpr ((EP & WS_R1) != 0) {
                         const u32x2 r = q1[t * 4 + q4];
@@ -246,17 +247,17 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                         bf16x4w o1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o1[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4w*>(slab1 + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o1;
+                        *reinterpret_cast<bf16x4w*>(slab1 + i * SROW + t * 32 + 8 * q4 + co_l) = o1;
                     }
                     if constexpr ((EP & WS_MASK) != 0) {
                         const u32x2 r = qm[t * 4 + q4];
-                        v[0] *= lrelu_grad_from_out(bf16_lo(r[0])); v[1] *= lrelu_grad_from_out(bf16_hi(r[0]));
-                        v[2] *= lrelu_grad_from_out(bf16_lo(r[1])); v[3] *= lrelu_grad_from_out(bf16_hi(r[1]));
+                        v[0] = lrelu_mask_lo(v[0], r[0]); v[1] = lrelu_mask_hi(v[1], r[0]);
+                        v[2] = lrelu_mask_lo(v[2], r[1]); v[3] = lrelu_mask_hi(v[3], r[1]);
                     }
                     bf16x4w o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                    *reinterpret_cast<bf16x4w*>(slab + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o;
+                    *reinterpret_cast<bf16x4w*>(slab + i * SROW + t * 32 + 8 * q4 + co_l) = o;
                 }
         } else {
         // ---- generic epilogue (full ssr_conv_desc contract); its operands are loaded after the MFMA loop to stay
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                     if (y1p) *reinterpret_cast<bf16x4w*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
                 }
                 // final output: transposed through the wave's slab so that a store instruction writes whole lines
-                *reinterpret_cast<bf16x4w*>(slab + i * (32 * NT) + t * 32 + 8 * q4 + co_l) = o2;
+                *reinterpret_cast<bf16x4w*>(slab + i * SROW + t * 32 + 8 * q4 + co_l) = o2;
             }
         }
         }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
                 const int pix = v / PARTS, part = v - pix * PARTS;
                 const int dy = pix >> 4, dx = ws_col(pix);
                 const int c = co0 + part * 8;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(sl + pix * (32 * NT) + part * 8);
+                const u32x4 val = *reinterpret_cast<const u32x4*>(sl + pix * SROW + part * 8);
 #ifdef WS_NO_STORE
                 if (val[0] == 0x12345678u)
 #else
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
 
 template <int NPL, int NT, int EP>
 int launch_ws_ep(const ssr_conv_desc& d, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + (EP >= 0 && (EP & WS_Y1) ? 2 : 1) * 4 * 32 * 32 * NT * 2;
+    constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + (EP >= 0 && (EP & WS_Y1) ? 2 : 1) * 4 * 32 * (32 * NT + 8) * 2;
     auto kern = conv_ws_kernel<NPL, NT, EP>;
     static bool attr_done = false;
     if (!attr_done) {

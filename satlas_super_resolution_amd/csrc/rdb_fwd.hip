@@ -301,11 +301,11 @@ __device__ __forceinline__ void rb_store_slice(const f32x16& acc, const RbPix& p
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * q4 + e];
         if (BWD) {
-            v[0] *= lrelu_grad_from_out(bf_lo(mk[q4][0])); v[1] *= lrelu_grad_from_out(bf_hi(mk[q4][0]));
-            v[2] *= lrelu_grad_from_out(bf_lo(mk[q4][1])); v[3] *= lrelu_grad_from_out(bf_hi(mk[q4][1]));
+            v[0] = lrelu_mask_lo(v[0], mk[q4][0]); v[1] = lrelu_mask_hi(v[1], mk[q4][0]);
+            v[2] = lrelu_mask_lo(v[2], mk[q4][1]); v[3] = lrelu_mask_hi(v[3], mk[q4][1]);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], LRELU_SLOPE * v[e]);   // == lrelu(v)
+            for (int e = 0; e < 4; ++e) v[e] = lrelu_max(v[e]);   // == lrelu(v)
         }
         bf16x4v o;
 #pragma unroll

@@ -8,12 +8,13 @@ __device__ unsigned long long* g_probe;
 #include "../satlas_super_resolution_amd/csrc/conv_big.hip"
 int main(int argc, char** argv) {
     const int N = 16, H = argc > 1 ? atoi(argv[1]) : 128, W = H, Cin = argc > 2 ? atoi(argv[2]) : 128, Cout = argc > 3 ? atoi(argv[3]) : 64;
+    const int KT = argc > 4 ? atoi(argv[4]) : 3;
     __bf16 *x, *w, *y; const size_t nx = (size_t)N * H * W * Cin * 2, ny = (size_t)N * H * W * Cout * 2, nw = (size_t)Cin * 9 * Cout * 2;
     hipMalloc(&x, nx); hipMalloc(&y, ny); hipMalloc(&w, nw);
     hipMemset(x, 0x3c, nx); hipMemset(w, 0x3c, nw);
     ssr_conv_desc d{};
     d.dtype = SSR_BF16; d.x = {x, Cin, 0}; d.N = N; d.Hi = H; d.Wi = W; d.up = 1; d.Cin = Cin; d.w = w; d.CoutPad = Cout;
-    d.KH = d.KW = 3; d.stride = 1; d.pad_y = d.pad_x = 1; d.Gh = H; d.Gw = W; d.Ho = H; d.Wo = W; d.oys = d.oxs = 1;
+    d.KH = d.KW = KT; d.stride = 1; d.pad_y = d.pad_x = KT == 3 ? 1 : 0; d.Gh = H; d.Gw = W; d.Ho = H; d.Wo = W; d.oys = d.oxs = 1;
     d.Cout = Cout; d.y = {y, Cout, 0}; d.alpha = 1.f; d.act = 1;
     const int nb = N * ((H + 31) / 32) * ((W + 15) / 16) * (Cout / 64);
     unsigned long long* probe; hipMalloc(&probe, (size_t)nb * 16 * 8); hipMemset(probe, 0, (size_t)nb * 16 * 8);
@@ -24,7 +25,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 10; ++it) ssr_conv_big_try(d, 0, &rc, true);
     hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h((size_t)nb * 16); hipMemcpy(h.data(), probe, h.size() * 8, hipMemcpyDeviceToHost);
-    const double gf = 2.0 * N * H * W * Cin * Cout * 9 / 1e9;
+    const double gf = 2.0 * N * H * W * Cin * Cout * KT * KT / 1e9;
     printf("rc=%d blocks=%d launch %.1f us  %.1f GFLOP -> %.0f TFLOP/s\n", rc, nb, ms * 100, gf, gf / (ms / 10 * 1e-3) / 1e3);
     const char* nm[] = {"", "prologue (chunk 0 loads + barrier)", "", "barrier A (chunk 1)", "store chunk", "barrier B", "MFMA phase", "", "epilogue"};
     double ph[16] = {0};

@@ -85,6 +85,12 @@ typedef struct ssr_conv_desc {
     ssr_view r2; int32_t r2_nc; float beta2;
     int32_t accumulate;
     ssr_view m; int32_t m_c0, m_c1;   /* mask source: m[p, m.coff + c] for output channel c */
+    /* 0, or 1 = space-to-depth evaluation of a 4x4 stride-2 pad-1 layer (KH = KW = 4, stride = 2, pad = 1, up = 1, even
+     * Hi / Wi, Cin a power-of-two multiple of 32; see ssr_conv2d_s2d_ok): the layer is computed as a 2x2 stride-1
+     * convolution over the view  x'[Y, X, q*Cin + c] = x[2Y-1 + (q>>1), 2X-1 + (q&1), c]  (zero outside), which the
+     * big-tile kernel gathers while staging — nothing is materialised.  `w` must then be packed with
+     * ssr_pack_item.fwd_s2d = 1: [q*Cin/32 + chunk][2x2 taps (dy,dx)][CoutPad][32], tap (ky,kx) = (2dy + (q>>1), 2dx + (q&1)). */
+    int32_t s2d;
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
@@ -102,6 +108,8 @@ int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
 int ssr_conv2d_variant(const ssr_conv_desc* d);
 /* input channels per packed weight chunk for a KHxKH kernel in `dtype` */
 int ssr_conv2d_ck(int32_t dtype, int32_t KH);
+/* 1 if a 4x4 stride-2 layer of this shape can run through the space-to-depth path (ssr_conv_desc.s2d), else 0 */
+int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad);
 
 /*
  * Fused ResidualDenseBlock (rrdbnet_arch.py:37-44, and :68 for the third block of an RRDB), bf16,
@@ -179,6 +187,7 @@ typedef struct ssr_pack_item {
     int32_t CoutPad, CinPad;      /* fwd padding */
     int32_t CinPadO, CoutPadI;    /* dgrad: "output" channels (=Cin) padded to 32, "input" (=Cout) padded to ck_dgrad */
     int32_t ck_fwd, ck_dgrad;     /* channels per chunk of the consuming kernels (ssr_conv2d_ck) */
+    int32_t fwd_s2d;              /* 1: dst_fwd in the space-to-depth order of ssr_conv_desc.s2d (4x4 stride 2, ck_fwd = 32) */
 } ssr_pack_item;
 
 int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream);

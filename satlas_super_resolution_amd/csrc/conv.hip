@@ -326,8 +326,15 @@ bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool forc
 bool ssr_conv_big_qualifies(const ssr_conv_desc& d);
 bool ssr_conv_big_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int* rc);
 
+extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad) {
+    static const bool off = [] { const char* e = getenv("SSR_CONV_S2D"); return e && e[0] == '0'; }();
+    const int cpc = Cin / 32;
+    return !off && dtype == SSR_BF16 && Cin >= 32 && (Cin % 32) == 0 && (cpc & (cpc - 1)) == 0 && (CoutPad % 64) == 0 && (Cout % 8) == 0;
+}
+
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
+    if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
     if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
     if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
     if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
@@ -354,6 +361,14 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     if (!d.x2.p && d.Cin2 != 0) return SSR_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = 0;
+    if (d.s2d) {   // 4x4 stride 2 through the space-to-depth view: a 2x2 stride-1 layer of 4*Cin channels on the big-tile kernel
+        if (!(d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad_y == 1 && d.pad_x == 1 && d.up == 1 && !d.x2.p)) return SSR_EINVAL;
+        if (!ssr_conv2d_s2d_ok(d.dtype, d.Cin, d.Cout, d.CoutPad) || (d.Hi % 2) || (d.Wi % 2) || d.Gh != d.Hi / 2 || d.Gw != d.Wi / 2)
+            return SSR_EINVAL;
+        ssr_conv_desc e = d;
+        e.KH = e.KW = 2; e.stride = 1; e.pad_y = e.pad_x = 0; e.Cin = 4 * d.Cin;
+        return ssr_conv_big_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
+    }
     if (impl == 1) return ssr_conv_ws_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
     if (impl == 4) return ssr_conv_big_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
     if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;

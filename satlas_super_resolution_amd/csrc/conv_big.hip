@@ -42,7 +42,9 @@ template <int KT> struct CbT {
     static constexpr int PATCH = NPIX * CB_AROW;               // 48,960 / 44,880
     static constexpr int WROWS = KT * KT * 64;
     static constexpr int WBYTES = WROWS * CB_AROW;             // 46,080 / 20,480
-    static constexpr int BIAS = PATCH + WBYTES;                // 64 floats
+    static constexpr int BUF = PATCH + WBYTES;                 // one chunk: 95,040 / 65,360
+    static constexpr int NBUF = KT == 2 ? 2 : 1;               // the 2x2 chunks are double-buffered (see the chunk loops)
+    static constexpr int BIAS = NBUF * BUF;                    // 64 floats
     static constexpr int LDS = BIAS + 256;
     static constexpr int NPV = (NPIX * 4 + 255) / 256;         // patch vectors per thread: 10 / 9
     static constexpr int NWV = WROWS * 4 / 256;                // weight vectors per thread: 9 / 4
@@ -51,6 +53,7 @@ template <int KT> struct CbT {
     static_assert(LDS <= 160 * 1024 && 2 * 4 * 32 * 72 * 2 <= PATCH, "LDS budget / output slabs fit in the patch area");
 };
 
+#define CB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_Y0 = 16, CB_GENERIC = -1;   // Y0: second output = activation before the residual
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
@@ -90,15 +93,36 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
 
     // ---- staging descriptors (independent of the chunk) ----
+    // 2x2 kernels can read x through a space-to-depth view (ssr_conv_desc.s2d: the 4x4 stride-2 forward layers): chunk c
+    // is parity class q = c / (C/32) of source channels [32 (c mod C/32), +32), patch pixel (Y, X) reads source pixel
+    // (2Y-1 + (q>>1), 2X-1 + (q&1)).  pgo = offset of the q = 0 pixel, pmk = one validity bit per class (bit 0 only
+    // without s2d), soff(c) = the chunk's uniform offset.
+    const bool s2d = KT == 2 && d.s2d != 0;
+    const int cpc_shift = s2d ? 31 - __builtin_clz((unsigned)(d.Cin >> 7)) : 0;   // log2(source channels / 32)
     int pgo[CB_NPV], plo[CB_NPV], wgo[CB_NWV], wlo[CB_NWV];
+    unsigned pmk[KT == 2 ? CB_NPV : 1];
 #pragma unroll
     for (int q = 0; q < CB_NPV; ++q) {
         const int v = tid + q * 256;
         const int pix = v >> 2, part = v & 3;
         const int py = pix / CB_PW, px = pix - py * CB_PW;
         const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
-        const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-        pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
+        if constexpr (KT == 2) {
+            if (s2d) {
+                const int sy = 2 * ly - 1, sx = 2 * lx - 1;
+                const bool y0 = sy >= 0 && sy < d.Hi, y1 = sy + 1 >= 0 && sy + 1 < d.Hi;
+                const bool x0 = sx >= 0 && sx < d.Wi, x1 = sx + 1 >= 0 && sx + 1 < d.Wi;
+                pmk[q] = v < CB_NPIX * 4 ? (unsigned)(y0 && x0) | (unsigned)(y0 && x1) << 1 | (unsigned)(y1 && x0) << 2 | (unsigned)(y1 && x1) << 3 : 0u;
+                pgo[q] = ((n * d.Hi + sy) * d.Wi + sx) * d.x.cs + d.x.coff + part * 8;
+            } else {
+                const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+                pmk[q] = ok ? 1u : 0u;
+                pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : 0;
+            }
+        } else {
+            const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+            pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
+        }
         plo[q] = v < CB_NPIX * 4 ? pix * CB_AROW + part * 16 : -1;
     }
 #pragma unroll
@@ -112,13 +136,23 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     // one staging load (vector j of the 19 per thread).  A wave that issues its loads back to back sits in the issue
     // of each one until the previous has drained (~170 cycles per 1-KiB instruction: the ~6.4 B/clk per-wave limit of
     // tools/l2_probe.hip) and cannot issue MFMAs meanwhile, so the loads of chunk c+1 are sprinkled over the k-steps
-    // of chunk c, one per step.
+    // of chunk c.
     auto load_one = [&](int c, auto jc) {
         constexpr int j = decltype(jc)::value;
         const int c0 = c * 32;
+#ifdef CB_X_NOLOAD
+        if (c > 1) return;                                     // probe: chunks after the first two reuse stale registers
+#endif
         if constexpr (j < CB_NPV) {
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[j] + c0);
+            if constexpr (KT == 2) {
+                const int q = s2d ? c >> cpc_shift : 0;        // wave-uniform
+                const int soff = s2d ? ((q >> 1) * d.Wi + (q & 1)) * d.x.cs + ((c - (q << cpc_shift)) << 5) : c0;
+                if (((pmk[j] >> q) & 1u) && (s2d || c0 + (int)(tid & 3) * 8 < d.Cin))
+                    val = *reinterpret_cast<const u32x4*>(xg + (ptrdiff_t)pgo[j] + soff);
+            } else {
+                if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[j] + c0);
+            }
             rp[j] = val;
         } else {
             rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
@@ -196,48 +230,128 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 }
     };
 
-    for (int c = 0; c < nchunks; ++c) {
-        BPROBE_C(2);
-        if (c > 0) __syncthreads();                           // everyone is finished reading the previous chunk
-        BPROBE_C(3);
-        store_chunk();
-        BPROBE_C(4);
-        __syncthreads();
-        BPROBE_C(5);
-        const bool has_next = c + 1 < nchunks;
-        if (!has_next) load_epi_ops();
-        // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
-        // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
-        constexpr int NSTEP = T::NSTEP, CB_PF = 2;
-        u32x4 wq[NSTEP][2], pq[NSTEP][4];
-        auto issue = [&](auto sc) {
-            constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                wq[s_][t] = *reinterpret_cast<const u32x4*>(smem + b_off + (tap * 64 + t * 32) * CB_AROW + kk * 32);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                pq[s_][m] = *reinterpret_cast<const u32x4*>(smem + a_off[m] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
-        };
-        static_for<0, CB_PF>([&](auto sc) { issue(sc); });
-        static_for<0, NSTEP>([&](auto sc) {
-            constexpr int s_ = decltype(sc)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (s_ + CB_PF < NSTEP) issue(std::integral_constant<int, s_ + CB_PF>{});
-            if (has_next) {
-                static_for<0, T::LPS>([&](auto lc) {
-                    constexpr int j = s_ * T::LPS + decltype(lc)::value;
-                    if constexpr (j < CB_NPV + CB_NWV) load_one(c + 1, std::integral_constant<int, j>{});
-                });
+    if constexpr (KT == 2) {
+        // ---- 2x2 taps: only 8 k-steps (64 MFMAs per wave) per chunk, so a store -> barrier -> MFMA sequence per chunk left
+        //      the matrix cores idle for half of the loop (tools/big_probe.hip: 1500 of 5600 cycles in barriers and the
+        //      chunk store, 4100 for 2048 cycles of MFMAs).  Two chunk buffers and ONE continuous stream of k-steps instead:
+        //      during chunk c   steps 0..3  store chunk c+1 (registers -> the other buffer), after barrier X (everyone is
+        //                                   finished reading that buffer: chunk c-1)
+        //                       step  4     barrier Y (chunk c+1 visible)
+        //                       steps 4..7  request chunk c+2 (global -> the same registers)
+        //                       steps 6..7  already read the first fragments of chunk c+1
+        //      The barriers are bare s_barrier + lgkmcnt(0): global loads stay in flight across them. ----
+        constexpr int NSTEP = T::NSTEP, CB_PF = 2, NV = CB_NPV + CB_NWV;
+        static_assert(NSTEP == 8 && NV <= 13, "store / load slots of the step schedule");
+        auto store_one = [&](int base, auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < CB_NPV) {
+                if (plo[j] >= 0) *reinterpret_cast<u32x4*>(smem + base + plo[j]) = rp[j];
+            } else {
+                *reinterpret_cast<u32x4*>(smem + base + wlo[j - CB_NPV]) = rw[j - CB_NPV];
             }
+        };
+        u32x4 wq[NSTEP][2], pq[NSTEP][4];
+        // memory operation k (0..5) of k-step s_: the two weight fragments, then pixel fragments 0..3
+        auto issue1 = [&](int base, auto sc, auto kc) {
+            constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1, k = decltype(kc)::value;
+            if constexpr (k >= 2)
+                pq[s_][k - 2] = *reinterpret_cast<const u32x4*>(smem + base + a_off[k - 2] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
+            else
+                wq[s_][k] = *reinterpret_cast<const u32x4*>(smem + base + b_off + (tap * 64 + k * 32) * CB_AROW + kk * 32);
+        };
+        static_for<0, NV>([&](auto jc) { store_one(0, jc); });
+        if (nchunks > 1) load_chunk(1);
+        CB_BAR();
+        static_for<0, CB_PF>([&](auto sc) { static_for<0, 6>([&](auto kc) { issue1(0, sc, kc); }); });
+        // the last chunk is a separate instantiation: the staging registers are dead there and hold the epilogue operands
+        auto chunk = [&](int c, auto h1c) {
+            constexpr bool has1 = decltype(h1c)::value;
+            BPROBE_C(2);
+            const int cur = (c & 1) * T::BUF, nxt = T::BUF - cur;
+            const bool has2 = c + 2 < nchunks;
+            if constexpr (!has1) load_epi_ops();
+            static_for<0, NSTEP>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                if constexpr (s_ == 0 || s_ == 4) {
+                    if constexpr (has1) CB_BAR();                 // X / Y
+                }
+                // memory instructions go between the MFMAs (see the 3x3 loop): a fragment read after each of the first
+                // six, a staging store (steps 0..3) or load (steps 4..7) after MFMAs 1, 3, 6 and 7
+                static_for<0, 8>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    mma16<__bf16>(acc[k >> 1][k & 1], wq[s_][k & 1], pq[s_][k >> 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (k < 6) {
+                        if constexpr (s_ + CB_PF < NSTEP) issue1(cur, std::integral_constant<int, s_ + CB_PF>{}, kc);
+                        else if constexpr (has1) issue1(nxt, std::integral_constant<int, s_ + CB_PF - NSTEP>{}, kc);
+                    }
+                    constexpr int e = k == 1 ? 0 : k == 3 ? 1 : k == 6 ? 2 : k == 7 ? 3 : -1;
+                    if constexpr (has1 && e >= 0) {
+                        constexpr int j = (s_ & 3) * 4 + e;       // 13 vectors over 4 steps: 4, 4, 4, 1
+                        if constexpr (j < NV) {
+                            if constexpr (s_ < 4) store_one(nxt, std::integral_constant<int, j>{});
+                            else if (has2) load_one(c + 2, std::integral_constant<int, j>{});
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) mma16<__bf16>(acc[m][t], wq[s_][t], pq[s_][m]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        BPROBE_C(6);
+            BPROBE_C(6);
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
+        chunk(nchunks - 1, std::false_type{});
+    } else {
+        auto chunk = [&](int c, auto hnc) {                       // last chunk peeled: see above
+            constexpr bool has_next = decltype(hnc)::value;
+            BPROBE_C(2);
+            if (c > 0) __syncthreads();                           // everyone is finished reading the previous chunk
+            BPROBE_C(3);
+            store_chunk();
+            BPROBE_C(4);
+            __syncthreads();
+            BPROBE_C(5);
+            if constexpr (!has_next) load_epi_ops();
+            // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
+            // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
+            constexpr int NSTEP = T::NSTEP, CB_PF = 2;
+            u32x4 wq[NSTEP][2], pq[NSTEP][4];
+            // memory operation k (0..5) of k-step s_: the two weight fragments, then pixel fragments 0..3 (the order the
+            // MFMAs of that step need them in)
+            auto issue1 = [&](auto sc, auto kc) {
+                constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1, k = decltype(kc)::value;
+                if constexpr (k >= 2)
+                    pq[s_][k - 2] = *reinterpret_cast<const u32x4*>(smem + a_off[k - 2] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
+                else
+                    wq[s_][k] = *reinterpret_cast<const u32x4*>(smem + b_off + (tap * 64 + k * 32) * CB_AROW + kk * 32);
+            };
+            static_for<0, CB_PF>([&](auto sc) { static_for<0, 6>([&](auto kc) { issue1(sc, kc); }); });
+            // Inside a step the memory instructions go BETWEEN the MFMAs, one per MFMA: bunched at the step boundary
+            // (6 LDS reads + up to 2 global loads, ~100 cycles of issue) they left the matrix pipe idle at every one of
+            // the 18 boundaries (tools/big_probe.hip: 6600 cycles for 4608 of MFMAs).
+            static_for<0, NSTEP>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                static_for<0, 8>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    mma16<__bf16>(acc[k >> 1][k & 1], wq[s_][k & 1], pq[s_][k >> 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (k < 6) {
+                        if constexpr (s_ + CB_PF < NSTEP) issue1(std::integral_constant<int, s_ + CB_PF>{}, kc);
+                    } else if constexpr (has_next) {
+                        // staging loads of the next chunk: two in each of the first CB_L2 steps, then one per step; the
+                        // last one four steps before the end so that the chunk store does not wait for it
+                        constexpr int NV = CB_NPV + CB_NWV, SPAN = NSTEP - 4, CB_L2 = NV > SPAN ? NV - SPAN : 0;
+                        constexpr int j = s_ < CB_L2 ? 2 * s_ + (k - 6) : (k == 6 ? CB_L2 + s_ : NV);
+                        if constexpr (j < NV) load_one(c + 1, std::integral_constant<int, j>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            BPROBE_C(6);
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
+        chunk(nchunks - 1, std::false_type{});
     }
     BPROBE(7);
     __syncthreads();                                          // patch area becomes the output transpose slabs
@@ -269,7 +383,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         // branch-free variants: the slabs of MB pixel tiles are written back to back, then read and stored back to back
         // (wave-private slabs, LDS executes a wave's operations in order: no barrier, one LDS round trip per round)
         constexpr int NSL = (EP & CB_Y0) ? 2 : 1;
-        constexpr int MB_ = (T::PATCH + T::WBYTES) / (4 * CB_SLAB * 2 * NSL);
+        constexpr int MB_ = T::BIAS / (4 * CB_SLAB * 2 * NSL);
         constexpr int MB = MB_ >= 4 ? 4 : MB_ >= 2 ? 2 : 1;
         __bf16* wslab = reinterpret_cast<__bf16*>(smem) + wave * (MB * NSL * CB_SLAB);
 #pragma unroll
@@ -430,7 +544,11 @@ bool ssr_conv_big_shape_ok(const ssr_conv_desc& d) {
     const bool k2 = d.KH == 2 && d.KW == 2 && (d.pad_y == 0 || d.pad_y == 1) && (d.pad_x == 0 || d.pad_x == 1);
     if (!(k3 || k2) || d.stride != 1 || d.x2.p) return false;
     if (d.Cin < 32 || (d.CoutPad % 64) != 0 || (d.Cout % 8) != 0) return false;
-    if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
+    if (d.s2d) {   // internal form of a 4x4 stride-2 layer (conv.hip): 2x2, pad 0, Cin = 4 x source channels
+        const int cpc = d.Cin / 128;
+        if (!k2 || d.pad_y != 0 || d.pad_x != 0 || d.up != 1 || (d.Cin % 128) != 0 || (cpc & (cpc - 1)) != 0) return false;
+        if ((d.Hi % 2) != 0 || (d.Wi % 2) != 0 || d.Gh != d.Hi / 2 || d.Gw != d.Wi / 2) return false;
+    } else if (d.Gh != (d.Hi << (d.up == 2)) || d.Gw != (d.Wi << (d.up == 2))) return false;
     if (d.r1.p && d.r1_nc < d.Cout) return false;
     if (d.r2.p && d.r2_nc < d.Cout) return false;
     if (d.m.p && !(d.m_c0 == 0 && d.m_c1 >= d.Cout)) return false;

@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
             const int ci = chunk * ck + cc;
             const bool ok = co < it.Cout && ci < it.Cin;
             const float* __restrict__ sp = it.src + ((size_t)co * it.Cin + ci) * KK;
+            if (it.fwd_s2d) {
+                // space-to-depth order (ssr_conv_desc.s2d): tap (ky,kx) -> parity q = (ky&1, kx&1), 2x2 tap (ky>>1, kx>>1);
+                // [q * nchunks + chunk][2x2 tap][CoutPad][ck]
+                const int nch = it.CinPad / ck;
+                for (int tap = 0; tap < 16; ++tap) {
+                    const int ky = tap >> 2, kx = tap & 3, q = (ky & 1) * 2 + (kx & 1), tt = (ky >> 1) * 2 + (kx >> 1);
+                    dst[((((size_t)q * nch + chunk) * 4 + tt) * it.CoutPad + co) * ck + cc] = from_f32<T>(ok ? sp[tap] * inv : 0.f);
+                }
+                continue;
+            }
             T* dp = dst + ((size_t)chunk * KK * it.CoutPad + co) * ck + cc;
             for (int tap = 0; tap < KK; ++tap) dp[(size_t)tap * it.CoutPad * ck] = from_f32<T>(ok ? sp[tap] * inv : 0.f);
         }

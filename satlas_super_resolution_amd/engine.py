@@ -90,11 +90,18 @@ class ParamStore:
         self.packed_fwd: Dict[str, torch.Tensor] = {}
         self.packed_dgrad: Dict[str, torch.Tensor] = {}
         self.pad: Dict[str, Tuple[int, int, int, int]] = {}
+        self.s2d: Dict[str, bool] = {}
         items = []
         for i, s in enumerate(specs):
             kk = s.k * s.k
             ck_f = L.ssr_conv2d_ck(dtype, s.k)                       # kernel consuming the forward weights
             ck_d = L.ssr_conv2d_ck(dtype, s.k if s.stride == 1 else 2)   # dgrad kernel (2x2 parity classes for s2)
+            # 4x4 stride-2 layers (discriminator_arch.py:31-35) run as 2x2 layers over a space-to-depth view of their
+            # input when the shape allows (ssr_conv_desc.s2d): the forward weights are packed in that order
+            s2d = bool(s.k == 4 and s.stride == 2 and L.ssr_conv2d_s2d_ok(dtype, s.cin, s.cout, rup(s.cout, 32)))
+            self.s2d[s.name] = s2d
+            if s2d:
+                ck_f = 32
             cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck_f)
             cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck_d)
             self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)
@@ -106,7 +113,8 @@ class ParamStore:
             inv = (self.sigma.data_ptr() + 4 * self.sn_names.index(s.name)) if s.sn else None
             items.append(PackItem(self.data.data_ptr() + 4 * woff, inv, pf.data_ptr(),
                                   pd.data_ptr() if s.dgrad_packed else None,
-                                  s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d))
+                                  s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d,
+                                  1 if s2d else 0))
         self._pack_items = items
         self.repacked: Dict[Tuple[str, int], torch.Tensor] = {}
         # gathered dense-block dgrad weights (filled by add_rdb_gather)
@@ -302,6 +310,7 @@ class _ConvBuilder:
         d.r2, d.r2_nc, d.beta2 = r2, r2_nc, beta2
         d.accumulate = 0
         d.m, d.m_c0, d.m_c1 = hip.NULL_VIEW, 0, 0
+        d.s2d = 1 if self.store.s2d.get(name) else 0
         self.keep.append(d)
         L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv fwd {name}")
         return d

@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
         ("r2", View), ("r2_nc", C.c_int32), ("beta2", C.c_float),
         ("accumulate", C.c_int32),
         ("m", View), ("m_c0", C.c_int32), ("m_c1", C.c_int32),
+        ("s2d", C.c_int32),
     ]
 
 
@@ -75,7 +76,7 @@ class PackItem(C.Structure):
         ("src", C.c_void_p), ("inv_scale", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
         ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
         ("CoutPad", C.c_int32), ("CinPad", C.c_int32), ("CinPadO", C.c_int32), ("CoutPadI", C.c_int32),
-        ("ck_fwd", C.c_int32), ("ck_dgrad", C.c_int32),
+        ("ck_fwd", C.c_int32), ("ck_dgrad", C.c_int32), ("fwd_s2d", C.c_int32),
     ]
 
 
@@ -103,7 +104,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_device_info", "ssr_abi_version",
@@ -132,6 +133,7 @@ def lib() -> C.CDLL:
     l.ssr_conv2d_batch.argtypes = [C.POINTER(ConvDesc), i32, vp]
     l.ssr_conv2d_variant.argtypes = [C.POINTER(ConvDesc)]
     l.ssr_conv2d_ck.argtypes = [i32, i32]
+    l.ssr_conv2d_s2d_ok.argtypes = [i32, i32, i32, i32]
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]

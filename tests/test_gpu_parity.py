@@ -750,3 +750,32 @@ def test_stride2_dgrad_big_tile_parity_classes(cout, cin, gh, gw, B, monkeypatch
         outs[mode] = y.float().cpu()
     assert rel_err(outs["big_each"], outs["pipelined"]) < 1e-2
     assert rel_err(outs["big_batch"], outs["pipelined"]) < 1e-2
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 32, 32, 2), (128, 256, 24, 40, 1), (256, 512, 16, 16, 2), (32, 64, 66, 34, 1)])
+def test_stride2_forward_space_to_depth(cin, cout, H, W, B):
+    """4x4 stride-2 spectral-norm conv + LeakyReLU (discriminator_arch.py:31-33,45-47) through ssr_conv_desc.s2d — a 2x2
+    conv over a space-to-depth view gathered by the big-tile kernel's staging loads, weights packed in that order
+    (ssr_pack_item.fwd_s2d) — against torch on the bf16-rounded operands."""
+    engine, hip = _mods()
+    dt, tdt = hip.BF16, torch.bfloat16
+    torch.manual_seed(cin + cout + H)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 4, 2, False, True)], dt)
+    assert st.s2d["c"], "shape should qualify for the space-to-depth path"
+    w = torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5)
+    st.load_state_dict({"c.weight_orig": w, "c.weight_u": torch.randn(cout), "c.weight_v": torch.randn(cin * 16)})
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    sigma = float(st.sigma[0])
+    x = torch.randn(B, cin, H, W)
+    xb = torch.zeros(B, H, W, cin, dtype=tdt, device="cuda")
+    yb = torch.zeros(B, H // 2, W // 2, cout, dtype=tdt, device="cuda")
+    _nchw_to_buf(hip, x, xb, dt)
+    cb = engine._ConvBuilder(st, B)
+    L = engine.Launcher()
+    d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(yb), act=hip.ACT_LRELU)
+    assert d.s2d == 1 and hip.lib().ssr_conv2d_variant(d) % 10 == 9
+    L.run()
+    y = _buf_to_nchw(hip, yb, cout, dt).cpu()
+    yr = F.leaky_relu(F.conv2d(x.bfloat16().float(), (w / sigma).bfloat16().float(), None, stride=2, padding=1), 0.2)
+    assert rel_err(y, yr) < 1.5e-2, rel_err(y, yr)

@@ -42,6 +42,7 @@ class ConvSpec:
     bias: bool = True
     sn: bool = False  # spectral-normalised (weight stored as weight_orig)
     dgrad_packed: bool = True  # keep a rotated/transposed copy for the per-conv (scatter) dgrad
+    s2d: Optional[bool] = None  # 4x4 stride-2 layers: None = space-to-depth path when the shape allows, False = never
 
 
 class ParamStore:
@@ -98,7 +99,7 @@ class ParamStore:
             ck_d = L.ssr_conv2d_ck(dtype, s.k if s.stride == 1 else 2)   # dgrad kernel (2x2 parity classes for s2)
             # 4x4 stride-2 layers (discriminator_arch.py:31-35) run as 2x2 layers over a space-to-depth view of their
             # input when the shape allows (ssr_conv_desc.s2d): the forward weights are packed in that order
-            s2d = bool(s.k == 4 and s.stride == 2 and L.ssr_conv2d_s2d_ok(dtype, s.cin, s.cout, rup(s.cout, 32)))
+            s2d = bool(s.k == 4 and s.stride == 2 and s.s2d is not False and L.ssr_conv2d_s2d_ok(dtype, s.cin, s.cout, rup(s.cout, 32)))
             self.s2d[s.name] = s2d
             if s2d:
                 ck_f = 32
@@ -687,14 +688,21 @@ class GeneratorPlan:
 # =====================================================================================================
 # Discriminator
 # =====================================================================================================
-def discriminator_specs(num_in_ch, num_feat=64) -> List[ConvSpec]:
-    """discriminator_arch.py:28-40."""
+def discriminator_specs(num_in_ch, num_feat=64, in_hw: Optional[Tuple[int, int]] = None) -> List[ConvSpec]:
+    """discriminator_arch.py:28-40.  `in_hw` (input size the store will serve, if known) only steers kernel choice: the
+    space-to-depth form of a stride-2 layer works on 32x16-pixel tiles and loses to the pipelined kernel on output grids
+    below 24 rows (r01 per-layer times at B=32: conv3, 16x16 grid, 82 vs 66 us; conv1/conv2 67/51 vs 99/87 us)."""
     nf = num_feat
+    grid = lambda k: None if in_hw is None or min(in_hw[0] >> k, in_hw[1] >> k) >= 24 else False
+    return _disc_specs(num_in_ch, nf, grid)
+
+
+def _disc_specs(num_in_ch, nf, grid) -> List[ConvSpec]:
     return [
         ConvSpec("conv0", nf, num_in_ch, 3, 1, True, False),
-        ConvSpec("conv1", nf * 2, nf, 4, 2, False, True),
-        ConvSpec("conv2", nf * 4, nf * 2, 4, 2, False, True),
-        ConvSpec("conv3", nf * 8, nf * 4, 4, 2, False, True),
+        ConvSpec("conv1", nf * 2, nf, 4, 2, False, True, s2d=grid(1)),
+        ConvSpec("conv2", nf * 4, nf * 2, 4, 2, False, True, s2d=grid(2)),
+        ConvSpec("conv3", nf * 8, nf * 4, 4, 2, False, True, s2d=grid(3)),
         ConvSpec("conv4", nf * 4, nf * 8, 3, 1, False, True),
         ConvSpec("conv5", nf * 2, nf * 4, 3, 1, False, True),
         ConvSpec("conv6", nf, nf * 2, 3, 1, False, True),

@@ -8,7 +8,7 @@ MI355X-first re-design:
     (chunked so RCCL can pipeline them over the 7 xGMI links) issued on a SIDE stream;
   * the generator exchange is launched as soon as G's backward retires and overlaps the whole
     discriminator phase (D real+fake forward/backward do not depend on the updated G weights);
-    both Adam updates run after the exchanges complete;
+    G's Adam update waits only for G's exchange (an event behind it on the side stream) and runs under D's;
   * D grads are reduced ONCE after both backward passes (avg_real+avg_fake == avg(real+fake));
   * u/v stay bit-identical across ranks without any broadcast: every rank applies the same
     deterministic power iteration to the same (all-reduced) weights;
@@ -63,22 +63,37 @@ class DPContext:
 
     def all_reduce_async(self, flat: torch.Tensor):
         """Sum-all-reduce a flat arena in chunks.  On GPU the collectives are enqueued on a side stream
-        that first waits for the producer (current) stream; call wait() before consuming."""
+        that first waits for the producer (current) stream.  Returns a handle for wait(handle): an event
+        recorded behind this arena's collectives (GPU) / its work objects (CPU), so that the consumer of
+        an earlier exchange does not have to wait for a later one."""
         if not self.active:
-            return
+            return None
         if flat.is_cuda:
             cs = self._stream()
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
                 for off in range(0, flat.numel(), self.chunk_elems):
                     dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            for off in range(0, flat.numel(), self.chunk_elems):
-                self._pending.append(dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM,
-                                                     group=self.group, async_op=True))
+                ev = torch.cuda.Event()
+                ev.record(cs)
+            return ev
+        works = [dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for off in range(0, flat.numel(), self.chunk_elems)]
+        self._pending.extend(works)
+        return works
 
-    def wait(self):
+    def wait(self, handle=None):
+        """Make the current stream (GPU) / the caller (CPU) wait for one exchange (`handle` from
+        all_reduce_async) or, without a handle, for everything issued so far."""
         if not self.active:
+            return
+        if handle is not None:
+            if isinstance(handle, list):
+                for w in handle:
+                    w.wait()
+                self._pending = [w for w in self._pending if all(w is not h for h in handle)]
+            else:
+                torch.cuda.current_stream().wait_event(handle)
             return
         for w in self._pending:
             w.wait()

@@ -233,16 +233,18 @@ class ESRGANTrainStep:
         cfg = self.cfg
         g_on = (self.iter % cfg.net_d_iters == 0) and (self.iter > cfg.net_d_init_iters)
         if self.dp.active:
+            hg = None
             if g_on:
                 self._run("g", self._phase_g)
-                self.dp.all_reduce_async(self.g_store.grad)
+                hg = self.dp.all_reduce_async(self.g_store.grad)
             else:
                 self._run("g_skip", self._phase_g_skipped)
             self._run("d", self._phase_d)
-            self.dp.all_reduce_async(self.d_store.grad)
-            self.dp.wait()
+            hd = self.dp.all_reduce_async(self.d_store.grad)
             if g_on:
+                self.dp.wait(hg)                                   # G's Adam runs under D's exchange
                 self._run("opt_g", self._phase_opt_g)
+            self.dp.wait(hd)
             self._run("opt_d", self._phase_opt_d)
         else:
             def whole():

@@ -52,9 +52,12 @@ def _worker(rank, world, port, q):
     keys_g, keys_d = list(part.g_grads), list(part.d_grads)
     flat_g = torch.cat([part.g_grads[k].reshape(-1) for k in keys_g])
     flat_d = torch.cat([part.d_grads[k].reshape(-1) for k in keys_d])     # real+fake already summed: ONE exchange
-    ctx.all_reduce_async(flat_g)
-    ctx.all_reduce_async(flat_d)
-    ctx.wait()
+    hg = ctx.all_reduce_async(flat_g)
+    hd = ctx.all_reduce_async(flat_d)
+    ctx.wait(hg)                                                         # per-exchange handles, as train_step.step() uses them
+    assert len(ctx._pending) == len(hd)
+    ctx.wait(hd)
+    assert not ctx._pending
     flat_g *= ctx.grad_scale
     flat_d *= ctx.grad_scale
     ref_g = torch.cat([full.g_grads[k].reshape(-1) for k in keys_g])

@@ -247,8 +247,9 @@ def main():
         "frac_of_mfma_peak_whole_step": value * gflop_img / 1e3 / (PEAK_TFLOPS[args.dtype] * ctx.world),
         "losses_finite": finite,
     }
-    if ctx.rank == 0 and not args.no_roofline:
-        agg = instrumented_step(ts, args)
+    # the instrumented step contains the gradient exchanges: every rank runs it (collectives must match), rank 0 reports
+    agg = instrumented_step(ts, args) if not args.no_roofline else None
+    if ctx.rank == 0 and agg is not None:
         conv = {k: v for k, v in agg.items() if v[2] > 0}      # MFMA kernels (algorithmic FLOPs known)
         dom = max(conv, key=lambda k: conv[k][1])
         n, secs, fl = conv[dom]

@@ -31,8 +31,8 @@ def init_distributed(backend: Optional[str] = None) -> "DPContext":
         return DPContext(None, 0, 1)
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:   # SSR_DIST_BACKEND=gloo: test hook (two ranks sharing one GPU, tests/test_dp_gpu.py; RCCL needs one device per rank)
+        backend = os.environ.get("SSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():

@@ -1,0 +1,129 @@
+"""GPU, world_size 2 on ONE device: the data-parallel branch of ESRGANTrainStep.step() — phase graphs ("g", "d", "opt_g",
+"opt_d") with the gradient exchanges between them on the side stream, per-exchange wait events, 1/world folded into
+Adam — exercised end to end on the HIP path.  Two processes share cuda:0, so the collective backend is gloo (RCCL refuses
+two ranks on one device); everything else is the code path `bench.py --gpus N` runs over RCCL.
+
+Checks: both ranks end bit-identical; per-rank batch 1 + exchange == the CPU oracle's full-batch (B = 2) step, two
+iterations (losses through reduce_scalars, parameters on the update, EMA)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import rel_err
+
+G_KW = dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
+D_KW = dict(num_in_ch=3, num_feat=8, skip_connection=True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    torch.manual_seed(11)
+    return [(torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32)) for _ in range(2)]
+
+
+def _worker(rank, world, port, q, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.dp import init_distributed
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    ctx = init_distributed(backend="gloo")
+    assert ctx.active and ctx.world == world
+    ts = ESRGANTrainStep(G_KW, D_KW, 1, 8, 8, "fp32", StepConfig(), dp=ctx, use_graph=True)
+    ts.load_state(O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6))
+    ts.sync_params_from_rank0()
+    logs = []
+    for it, (lr, gt) in enumerate(_data(), start=1):
+        ts.feed_data(lr[rank:rank + 1].cuda(), gt[rank:rank + 1].cuda())
+        ts.step(it)
+        logs.append(dict(ts.log()))
+    torch.cuda.synchronize()
+    g = {k: ts.g_store.tensor(k).cpu().clone() for k in ts.g_store.state_dict()}
+    d = {k: v.cpu().clone() for k, v in ts.d_store.state_dict().items()}
+    ema = {k: v.cpu().clone() for k, v in ts.ema_state_dict().items()}
+    path = os.path.join(outdir, f"rank{rank}.pt")   # tensors go through a file: the worker may exit before the parent reads
+    torch.save((rank, logs, g, d, ema), path)
+    q.put(path)
+    ctx.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_world2_shared_gpu_matches_full_batch_oracle(tmp_path):
+    from oracle import esrgan_oracle as O
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    paths = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = sorted((torch.load(pth, weights_only=False) for pth in paths), key=lambda r: r[0])
+    (_, logs0, g0r, d0r, ema0), (_, logs1, g1r, d1r, _) = res
+    # identical replicas after two steps (same reduced gradients, same deterministic updates)
+    for k in g0r:
+        assert torch.equal(g0r[k], g1r[k]), ("G replica mismatch", k)
+    for k in d0r:
+        assert torch.equal(d0r[k], d1r[k]), ("D replica mismatch", k)
+    assert logs0 == logs1
+    # == the oracle's full-batch step
+    g_init, d_init = O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6)
+    orc = O.ESRGANOracle(g_init, d_init, O.StepConfig())
+    lr_steps = 1e-4 * 2
+    for it, (lr, gt) in enumerate(_data(), start=1):
+        ref_log = orc.step(lr, gt, it)
+        for k, v in ref_log.items():
+            assert abs(logs0[it - 1][k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, logs0[it - 1][k], v)
+
+    def update_close(got, ref, p0, steps, what, upd_tol=2e-2):   # as tests/test_gpu_parity.py::_update_close
+        err = ((got - p0) - (ref - p0)).abs()
+        tight = upd_tol * (ref - p0).abs().max() + 3e-7 * ref.abs().max() + 1e-9
+        assert (err > tight).float().mean().item() <= 1e-3, what
+        assert err.max() <= 2.1 * steps + tight, (what, float(err.max()))
+
+    for k, v in orc.g.items():
+        update_close(g0r[k], v, g_init[k], lr_steps, ("G", k))
+    for k, v in orc.d.items():
+        if k.endswith("_u") or k.endswith("_v"):
+            assert rel_err(d0r[k], v) < 1e-3, ("D buffer", k)
+        else:
+            update_close(d0r[k], v, d_init[k], lr_steps, ("D", k))
+    for k, v in orc.g_ema.items():
+        update_close(ema0[k], v, g_init[k], lr_steps * 1e-3 * 2, ("EMA", k))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+    cuda:0 and gloo standing in for RCCL: every rank must take part in every collective — the timed steps, the max-over-
+    ranks reduction AND the instrumented roofline step — and rank 0 alone prints the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSR_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+           "--batch", "2", "--blocks", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["losses_finite"]
+    assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out

@@ -45,18 +45,31 @@ template <int KT> struct CbT {
     static constexpr int BUF = PATCH + WBYTES;                 // one chunk: 95,040 / 65,360
     static constexpr int NBUF = KT == 2 ? 2 : 1;               // the 2x2 chunks are double-buffered (see the chunk loops)
     static constexpr int BIAS = NBUF * BUF;                    // 64 floats
-    static constexpr int LDS = BIAS + 256;
+    // output transpose slabs: 3x3 kernels have a dedicated area behind the bias table (the chunk area already holds the
+    // NEXT image's first chunk when an epilogue runs, see conv_big_body); the double-buffered 2x2 kernels reuse the
+    // buffer of the chunk just consumed
+    static constexpr int SLABS = KT == 3 ? BIAS + 256 : 0, SLABB = KT == 3 ? 4 * 2 * 32 * 72 * 2 : BUF;
+    static constexpr int LDS = BIAS + 256 + (KT == 3 ? SLABB : 0);
     static constexpr int NPV = (NPIX * 4 + 255) / 256;         // patch vectors per thread: 10 / 9
     static constexpr int NWV = WROWS * 4 / 256;                // weight vectors per thread: 9 / 4
     static constexpr int NSTEP = KT * KT * 2;                  // k-steps per 32-channel chunk: 18 / 8
     static constexpr int LPS = (NPV + NWV + NSTEP - 1) / NSTEP;   // staging loads sprinkled per k-step: 2 / 2
-    static_assert(LDS <= 160 * 1024 && 2 * 4 * 32 * 72 * 2 <= PATCH, "LDS budget / output slabs fit in the patch area");
+    static_assert(LDS <= 160 * 1024 && 4 * 2 * 32 * 72 * 2 <= SLABB, "LDS budget / two slabs per wave fit");
 };
 
+#ifndef CB_TAIL
+#define CB_TAIL 4
+#endif
 #define CB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int CB_LRELU = 1, CB_MASK = 2, CB_R1 = 4, CB_ACC = 8, CB_Y0 = 16, CB_GENERIC = -1;   // Y0: second output = activation before the residual
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+// Buffer addressing: SGPR resource + 32-bit per-lane byte offset + uniform (SGPR) byte offset.  With 64-bit global pointers
+// hipcc keeps a loop-invariant pointer PAIR per staging vector / epilogue operand (38 + registers; the persistent 3x3
+// kernel spilled them to scratch); here the per-lane part stays one register and the image / chunk offset is scalar.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cb_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
 __device__ __forceinline__ float cb_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float cb_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
@@ -76,10 +89,15 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int tiles_x = (d.Gw + CB_TW - 1) / CB_TW, tiles_y = (d.Gh + CB_TH - 1) / CB_TH;
-    int b = blockIdx.x;
-    const int tx_i = b % tiles_x; b /= tiles_x;
-    const int ty_i = b % tiles_y;
-    const int n = b / tiles_y;
+    // A workgroup is PERSISTENT over images: it owns tile position (ty_i, tx_i) of images n0, n0 + G, n0 + 2G, ... and
+    // runs their chunks as one stream — while the last chunk of one image is contracted the first chunk of the next is
+    // already on its way, and the epilogue's stores drain under the next image's MFMAs.  (One tile per workgroup paid
+    // the first chunk's HBM latency and the epilogue with idle matrix cores: the 128x128 layers measured at compute time
+    // PLUS memory time.)  Staging descriptors and output coordinates are image-relative; the image is a uniform offset.
+    const int tpi = tiles_x * tiles_y, G = gridDim.x / tpi;
+    const int tp = blockIdx.x % tpi, n0 = blockIdx.x / tpi;
+    const int tx_i = tp % tiles_x, ty_i = tp / tiles_x;
+    const int nimg = KT == 3 ? (d.N - n0 + G - 1) / G : 1;   // (the 2x2 kernels are launched with G = N: one image each)
     const int gy0 = ty_i * CB_TH, gx0 = tx_i * CB_TW;
     const int co0 = blockIdx.y * 64;
     const int upshift = d.up == 2 ? 1 : 0;
@@ -88,6 +106,8 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
     const int nchunks = (d.Cin + 31) / 32;
     const size_t wchunk = (size_t)KT * KT * d.CoutPad * 32;
+    const int T_ = nimg * nchunks;                             // length of this workgroup's chunk stream
+    const size_t ximg = (size_t)d.Hi * d.Wi * d.x.cs, oimg = (size_t)d.Ho * d.Wo;   // per-image strides (elements / pixels)
 
     float* bias_lds = reinterpret_cast<float*>(smem + CB_BIAS);
     if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
@@ -113,15 +133,15 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 const bool y0 = sy >= 0 && sy < d.Hi, y1 = sy + 1 >= 0 && sy + 1 < d.Hi;
                 const bool x0 = sx >= 0 && sx < d.Wi, x1 = sx + 1 >= 0 && sx + 1 < d.Wi;
                 pmk[q] = v < CB_NPIX * 4 ? (unsigned)(y0 && x0) | (unsigned)(y0 && x1) << 1 | (unsigned)(y1 && x0) << 2 | (unsigned)(y1 && x1) << 3 : 0u;
-                pgo[q] = ((n * d.Hi + sy) * d.Wi + sx) * d.x.cs + d.x.coff + part * 8;
+                pgo[q] = (sy * d.Wi + sx) * d.x.cs + d.x.coff + part * 8;
             } else {
                 const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
                 pmk[q] = ok ? 1u : 0u;
-                pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : 0;
+                pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : 0;
             }
         } else {
             const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-            pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
+            pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
         }
         plo[q] = v < CB_NPIX * 4 ? pix * CB_AROW + part * 16 : -1;
     }
@@ -132,16 +152,17 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         wgo[q] = ((row >> 6) * d.CoutPad + co0 + (row & 63)) * 32 + part * 8;
         wlo[q] = CB_PATCH + row * CB_AROW + part * 16;
     }
+    const __amdgpu_buffer_rsrc_t rsx = cb_rsrc(d.x.p, (long)d.N * ximg * 2), rsw = cb_rsrc(d.w, (long)nchunks * wchunk * 2);
     u32x4 rp[CB_NPV], rw[CB_NWV];
     // one staging load (vector j of the 19 per thread).  A wave that issues its loads back to back sits in the issue
     // of each one until the previous has drained (~170 cycles per 1-KiB instruction: the ~6.4 B/clk per-wave limit of
     // tools/l2_probe.hip) and cannot issue MFMAs meanwhile, so the loads of chunk c+1 are sprinkled over the k-steps
     // of chunk c.
-    auto load_one = [&](int c, auto jc) {
+    auto load_one = [&](int nn, int c, auto jc) {          // vector j of chunk c of image nn
         constexpr int j = decltype(jc)::value;
         const int c0 = c * 32;
 #ifdef CB_X_NOLOAD
-        if (c > 1) return;                                     // probe: chunks after the first two reuse stale registers
+        if (c > 1 || nn != n0) return;                         // probe: chunks after the first two reuse stale registers
 #endif
         if constexpr (j < CB_NPV) {
             u32x4 val = {0u, 0u, 0u, 0u};
@@ -149,16 +170,18 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 const int q = s2d ? c >> cpc_shift : 0;        // wave-uniform
                 const int soff = s2d ? ((q >> 1) * d.Wi + (q & 1)) * d.x.cs + ((c - (q << cpc_shift)) << 5) : c0;
                 if (((pmk[j] >> q) & 1u) && (s2d || c0 + (int)(tid & 3) * 8 < d.Cin))
-                    val = *reinterpret_cast<const u32x4*>(xg + (ptrdiff_t)pgo[j] + soff);
+                    val = *reinterpret_cast<const u32x4*>(xg + nn * ximg + (ptrdiff_t)pgo[j] + soff);
             } else {
-                if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[j] + c0);
+                if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin)
+                    val = __builtin_amdgcn_raw_buffer_load_b128(rsx, pgo[j] * 2, (int)((nn * ximg + c0) * 2), 0);
             }
             rp[j] = val;
         } else {
-            rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
+            if constexpr (KT == 3) rw[j - CB_NPV] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wgo[j - CB_NPV] * 2, (int)(c * wchunk * 2), 0);
+            else rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
         }
     };
-    auto load_chunk = [&](int c) { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(c, jc); }); };
+    auto load_chunk = [&](int nn, int c) { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(nn, c, jc); }); };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int q = 0; q < CB_NPV; ++q)
@@ -179,22 +202,24 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const int co_l = 4 * g;                                   // + 8*q4 + e: this lane's 16 channels of a channel tile
 
     BPROBE(0);
-    load_chunk(0);
+    load_chunk(n0, 0);
     __syncthreads();                                          // bias table
     BPROBE(1);
     f32x16 acc[4][2];
+    auto acc_init = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v0 = EP >= 0 ? bq[e] : 0.f;       // lean variants: accumulators start at the bias
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = EP >= 0 ? bq[e] : 0.f;   // lean variants: accumulators start at the bias
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m][t][4 * q4 + e] = v0;
+                    for (int m = 0; m < 4; ++m) acc[m][t][4 * q4 + e] = v0;
+                }
             }
-        }
+    };
 
     // ---- lean epilogues: this lane's pixel of every pixel tile and its epilogue operands (residual / old value / mask).
     //      They are requested when the LAST chunk starts, so their latency hides under its MFMAs (fetched inside the
@@ -202,7 +227,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const __bf16* __restrict__ r1p = reinterpret_cast<const __bf16*>(d.r1.p);
     const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(d.m.p);
     __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
-    size_t ppx[4];
+    int ppx[4];                                               // image-relative output pixel of this lane per pixel tile
     bool pval[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -211,23 +236,187 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         const int gy = gy0 + row, gx = gx0 + col;
         pval[m] = gy < d.Gh && gx < d.Gw;
         const int cy = pval[m] ? gy : d.Gh - 1, cx = pval[m] ? gx : d.Gw - 1;
-        ppx[m] = (size_t)(n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
+        ppx[m] = (cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;   // + nn * oimg
     }
     constexpr bool HAS_R1 = EP >= 0 && (EP & CB_R1), HAS_ACC = EP >= 0 && (EP & CB_ACC), HAS_MASK = EP >= 0 && (EP & CB_MASK);
-    u32x2c q1[HAS_R1 ? 4 : 1][8], qa[HAS_ACC ? 4 : 1][8], qm[HAS_MASK ? 4 : 1][8];
-    auto load_epi_ops = [&]() {
+    typedef u32x2c OpsR1[HAS_R1 ? 4 : 1][8];
+    typedef u32x2c OpsAcc[HAS_ACC ? 4 : 1][8];
+    typedef u32x2c OpsMask[HAS_MASK ? 4 : 1][8];
+    OpsR1 q1;
+    OpsAcc qa;
+    OpsMask qm;                                               // prefetched under the stream's last chunk
+    const long obytes = (long)d.N * oimg * 2;                 // x view.cs = bytes of an output-side tensor (exact: out-of-range reads return 0)
+    const __amdgpu_buffer_rsrc_t rs_r1 = cb_rsrc(d.r1.p, obytes * d.r1.cs), rs_m = cb_rsrc(d.m.p, obytes * d.m.cs),
+                                 rs_y = cb_rsrc(d.y.p, obytes * d.y.cs), rs_y0 = cb_rsrc(d.y0.p, obytes * d.y0.cs);
+    auto load_epi_ops_to = [&](int nn, OpsR1& q1, OpsAcc& qa, OpsMask& qm, int m0 = 0, int m1 = 4) {
+        const int s1 = (int)(nn * oimg * d.r1.cs * 2), sa = (int)(nn * oimg * d.y.cs * 2), sm = (int)(nn * oimg * d.m.cs * 2);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) {
+            if (m < m0 || m >= m1) continue;                      // (compile-time after unrolling)
+            const int c = co0 + co_l;                             // + t * 32 + 8 * q4: constant offsets of the load instructions
+            const int v1 = (ppx[m] * d.r1.cs + d.r1.coff + c) * 2, va = (ppx[m] * d.y.cs + d.y.coff + c) * 2,
+                      vm = (ppx[m] * d.m.cs + d.m.coff + c) * 2;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const int cc = c < d.Cout ? c : 0;            // clamped: always addressable
-                    if constexpr (HAS_R1) q1[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(r1p + ppx[m] * d.r1.cs + d.r1.coff + cc);
-                    if constexpr (HAS_ACC) qa[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(yp + ppx[m] * d.y.cs + d.y.coff + cc);
-                    if constexpr (HAS_MASK) qm[m][t * 4 + q4] = *reinterpret_cast<const u32x2c*>(mp + ppx[m] * d.m.cs + d.m.coff + cc);
+                    const int o = (t * 32 + 8 * q4) * 2;
+                    if constexpr (HAS_R1) q1[m][t * 4 + q4] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, v1 + o, s1, 0);
+                    if constexpr (HAS_ACC) qa[m][t * 4 + q4] = __builtin_amdgcn_raw_buffer_load_b64(rs_y, va + o, sa, 0);
+                    if constexpr (HAS_MASK) qm[m][t * 4 + q4] = __builtin_amdgcn_raw_buffer_load_b64(rs_m, vm + o, sm, 0);
                 }
+        }
+    };
+    auto load_epi_ops = [&](int nn) { load_epi_ops_to(nn, q1, qa, qm); };
+
+    // ---- epilogue: per pixel tile m this lane = one pixel x (2 x 16) channels ----
+    __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
+    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
+    const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+    // the wave's [32 px][64 co] slab of pixel tile m -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
+    auto flush = [&](int nn, int m, const __bf16* sl, const __amdgpu_buffer_rsrc_t& rs, const ssr_view& vw) {
+        const int so = (int)(nn * oimg * vw.cs * 2);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int v = h * 64 + lane;
+            const int s_ = v >> 3, part = v & 7;
+            int prow, pcol;
+            cb_pixel<KT>(wave, m, s_, prow, pcol);
+            const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * CB_SROW + part * 8);
+#ifdef CB_X_NOSTORE
+            if (val.x == 0x12345678u && oy < d.Gh && ox < d.Gw && c < d.Cout)
+#else
+            if (oy < d.Gh && ox < d.Gw && c < d.Cout)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(val, rs, (((oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * vw.cs + vw.coff + c) * 2, so, 0);
+        }
+    };
+    // Epilogue of image nn.  The (now idle) chunk area at byte offset sbase becomes the waves' output transpose slabs.  PRE: the
+    // operands were requested under the last chunk's MFMAs (final image of the stream, where the staging registers are
+    // free); otherwise they are requested here, with the next image's first chunk still waiting in the staging registers.
+    auto epilogue_with = [&](int nn, int sbase, OpsR1& q1, OpsAcc& qa, OpsMask& qm, auto lazyc) {
+        constexpr bool LAZY = decltype(lazyc)::value;         // request the operands of each round of pixel tiles at its start
+        if constexpr (EP >= 0) {
+            // branch-free variants: the slabs of MB pixel tiles are written back to back, then read and stored back to back
+            // (wave-private slabs, LDS executes a wave's operations in order: no barrier, one LDS round trip per round)
+            constexpr int NSL = (EP & CB_Y0) ? 2 : 1;
+            constexpr int MB_ = T::SLABB / (4 * CB_SLAB * 2 * NSL);
+            constexpr int MB = MB_ >= 4 ? 4 : MB_ >= 2 ? 2 : 1;
+            __bf16* wslab = reinterpret_cast<__bf16*>(smem + sbase) + wave * (MB * NSL * CB_SLAB);
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += MB) {
+                if constexpr (LAZY) load_epi_ops_to(nn, q1, qa, qm, r0, r0 + MB);
+#pragma unroll
+                for (int mm = 0; mm < MB; ++mm) {
+                    const int m = r0 + mm;
+                    __bf16* slab = wslab + mm * NSL * CB_SLAB;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[m][t][4 * q4 + e];
+                                if constexpr ((EP & CB_LRELU) != 0) v[e] = lrelu_max(v[e]);   // == lrelu()
+                            }
+                            if constexpr ((EP & CB_Y0) != 0) {   // y0 = act(conv + bias), before the residual
+                                bf16x4c o0;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o0[e] = (__bf16)v[e];
+                                *reinterpret_cast<bf16x4c*>(slab + CB_SLAB + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o0;
+                            }
+                            if constexpr (HAS_R1) {
+                                const u32x2c r = q1[m][t * 4 + q4];
+                                v[0] += d.beta1 * cb_lo(r[0]); v[1] += d.beta1 * cb_hi(r[0]);
+                                v[2] += d.beta1 * cb_lo(r[1]); v[3] += d.beta1 * cb_hi(r[1]);
+                            }
+                            if constexpr (HAS_ACC) {
+                                const u32x2c r = qa[m][t * 4 + q4];
+                                v[0] += cb_lo(r[0]); v[1] += cb_hi(r[0]); v[2] += cb_lo(r[1]); v[3] += cb_hi(r[1]);
+                            }
+                            if constexpr (HAS_MASK) {
+                                const u32x2c r = qm[m][t * 4 + q4];
+                                v[0] = lrelu_mask_lo(v[0], r[0]); v[1] = lrelu_mask_hi(v[1], r[0]);
+                                v[2] = lrelu_mask_lo(v[2], r[1]); v[3] = lrelu_mask_hi(v[3], r[1]);
+                            }
+                            bf16x4c o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                            *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o;
+                        }
+                }
+#pragma unroll
+                for (int mm = 0; mm < MB; ++mm) {
+                    const __bf16* slab = wslab + mm * NSL * CB_SLAB;
+                    flush(nn, r0 + mm, slab, rs_y, d.y);
+                    if constexpr ((EP & CB_Y0) != 0) flush(nn, r0 + mm, slab + CB_SLAB, rs_y0, d.y0);
+                }
+            }
+        } else {
+            // generic epilogue: the full ssr_conv_desc contract with run-time flags, one pixel tile at a time
+            __bf16* slab = reinterpret_cast<__bf16*>(smem + sbase) + wave * CB_SLAB;   // [32 lane-slots][64 co]
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const size_t pp = nn * oimg + ppx[m];
+                const bool pvalid = pval[m];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bf16x4c q1g[4], q2g[4], qag[4], qmg[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int c = co0 + t * 32 + 8 * q4 + co_l;
+                        const int cc = c < d.Cout ? c : 0;
+                        if (r1p) q1g[q4] = *reinterpret_cast<const bf16x4c*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
+                        if (r2p) q2g[q4] = *reinterpret_cast<const bf16x4c*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
+                        if (d.accumulate) qag[q4] = *reinterpret_cast<const bf16x4c*>(yp + pp * d.y.cs + d.y.coff + cc);
+                        if (mp) qmg[q4] = *reinterpret_cast<const bf16x4c*>(mp + pp * d.m.cs + d.m.coff + cc);
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int c = co0 + t * 32 + 8 * q4 + co_l;
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
+                        bf16x4c o0, o1, o2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[m][t][4 * q4 + e] + bq[e];
+                            if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+                            v *= d.alpha;
+                            o0[e] = (__bf16)v;
+                            if (r1p) v += d.beta1 * (float)q1g[q4][e];
+                            if (r2p) v += d.beta2 * (float)q2g[q4][e];
+                            if (d.accumulate) v += (float)qag[q4][e];
+                            o1[e] = (__bf16)v;
+                            if (mp) v *= lrelu_grad_from_out((float)qmg[q4][e]);
+                            o2[e] = (__bf16)v;
+                        }
+                        if (pvalid && c < d.Cout) {
+                            if (y0p) *reinterpret_cast<bf16x4c*>(y0p + pp * d.y0.cs + d.y0.coff + c) = o0;
+                            if (y1p) *reinterpret_cast<bf16x4c*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
+                        }
+                        *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o2;
+                    }
+                }
+                flush(nn, m, slab, rs_y, d.y);
+            }
+        }
+    };
+
+    auto epilogue = [&](int nn, int sbase, auto prec) {
+        constexpr bool PRE = decltype(prec)::value;
+        if constexpr (KT == 2) CB_BAR();                      // 2x2: everyone is finished reading the buffer that becomes the slabs
+        if constexpr (EP >= 0 && !PRE) {                      // operands of an in-stream epilogue live only here
+            OpsR1 l1;
+            OpsAcc la;
+            OpsMask lm;
+            // two operand kinds: 128 registers for all four pixel tiles do not fit next to the accumulator copies
+            constexpr bool LAZY = (HAS_R1 ? 1 : 0) + (HAS_ACC ? 1 : 0) + (HAS_MASK ? 1 : 0) > 1;
+            if constexpr (!LAZY) load_epi_ops_to(nn, l1, la, lm);
+            epilogue_with(nn, sbase, l1, la, lm, std::bool_constant<LAZY>{});
+        } else {
+            epilogue_with(nn, sbase, q1, qa, qm, std::false_type{});
+        }
     };
 
     if constexpr (KT == 2) {
@@ -260,16 +449,16 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 wq[s_][k] = *reinterpret_cast<const u32x4*>(smem + base + b_off + (tap * 64 + k * 32) * CB_AROW + kk * 32);
         };
         static_for<0, NV>([&](auto jc) { store_one(0, jc); });
-        if (nchunks > 1) load_chunk(1);
+        if (T_ > 1) load_chunk(n0, 1);
         CB_BAR();
         static_for<0, CB_PF>([&](auto sc) { static_for<0, 6>([&](auto kc) { issue1(0, sc, kc); }); });
         // the last chunk is a separate instantiation: the staging registers are dead there and hold the epilogue operands
-        auto chunk = [&](int c, auto h1c) {
+        auto chunk = [&](int c, int nn, int nn2, int c2, auto h1c) {   // c = stream position; (nn2, c2) = position c + 2
             constexpr bool has1 = decltype(h1c)::value;
             BPROBE_C(2);
             const int cur = (c & 1) * T::BUF, nxt = T::BUF - cur;
-            const bool has2 = c + 2 < nchunks;
-            if constexpr (!has1) load_epi_ops();
+            const bool has2 = c + 2 < T_;
+            if constexpr (!has1) load_epi_ops(nn);
             static_for<0, NSTEP>([&](auto sc) {
                 constexpr int s_ = decltype(sc)::value;
                 if constexpr (s_ == 0 || s_ == 4) {
@@ -290,7 +479,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                         constexpr int j = (s_ & 3) * 4 + e;       // 13 vectors over 4 steps: 4, 4, 4, 1
                         if constexpr (j < NV) {
                             if constexpr (s_ < 4) store_one(nxt, std::integral_constant<int, j>{});
-                            else if (has2) load_one(c + 2, std::integral_constant<int, j>{});
+                            else if (has2) load_one(nn2, c2, std::integral_constant<int, j>{});
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -299,19 +488,24 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             __builtin_amdgcn_sched_barrier(0);
             BPROBE_C(6);
         };
-        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
-        chunk(nchunks - 1, std::false_type{});
+        acc_init();
+        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, n0, n0, c + 2, std::true_type{});
+        chunk(nchunks - 1, n0, n0, 0, std::false_type{});
+        BPROBE(7);
+        epilogue(n0, ((nchunks - 1) & 1) * T::BUF, std::true_type{});
     } else {
-        auto chunk = [&](int c, auto hnc) {                       // last chunk peeled: see above
-            constexpr bool has_next = decltype(hnc)::value;
+        auto chunk = [&](int c, bool stored, int nn, int nn1, int c1, auto hnc) {   // c = stream position; (nn1, c1) = position c + 1
+            constexpr bool has_next = decltype(hnc)::value;            // the stream's last chunk is peeled: see above
             BPROBE_C(2);
-            if (c > 0) __syncthreads();                           // everyone is finished reading the previous chunk
-            BPROBE_C(3);
-            store_chunk();
+            if (!stored) {                                        // (an image's first chunk was stored before the previous epilogue)
+                if (c > 0) CB_BAR();                              // everyone is finished reading the previous chunk
+                BPROBE_C(3);
+                store_chunk();
+            }
             BPROBE_C(4);
-            __syncthreads();
+            CB_BAR();
             BPROBE_C(5);
-            if constexpr (!has_next) load_epi_ops();
+            if constexpr (!has_next) load_epi_ops(nn);
             // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
             // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
             constexpr int NSTEP = T::NSTEP, CB_PF = 2;
@@ -340,9 +534,9 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                     } else if constexpr (has_next) {
                         // staging loads of the next chunk: two in each of the first CB_L2 steps, then one per step; the
                         // last one four steps before the end so that the chunk store does not wait for it
-                        constexpr int NV = CB_NPV + CB_NWV, SPAN = NSTEP - 4, CB_L2 = NV > SPAN ? NV - SPAN : 0;
+                        constexpr int NV = CB_NPV + CB_NWV, SPAN = NSTEP - CB_TAIL, CB_L2 = NV > SPAN ? NV - SPAN : 0;
                         constexpr int j = s_ < CB_L2 ? 2 * s_ + (k - 6) : (k == 6 ? CB_L2 + s_ : NV);
-                        if constexpr (j < NV) load_one(c + 1, std::integral_constant<int, j>{});
+                        if constexpr (j < NV) load_one(nn1, c1, std::integral_constant<int, j>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -350,137 +544,29 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             __builtin_amdgcn_sched_barrier(0);
             BPROBE_C(6);
         };
-        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
-        chunk(nchunks - 1, std::false_type{});
-    }
-    BPROBE(7);
-    __syncthreads();                                          // patch area becomes the output transpose slabs
-
-    // ---- epilogue: per pixel tile m this lane = one pixel x (2 x 16) channels ----
-    __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
-    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
-    const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
-    // the wave's [32 px][64 co] slab of pixel tile m -> 256 16-byte vectors, 4 per lane: whole 128-byte lines per pixel
-    auto flush = [&](int m, const __bf16* sl, __bf16* __restrict__ out, const ssr_view& vw) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int v = h * 64 + lane;
-            const int s_ = v >> 3, part = v & 7;
-            int prow, pcol;
-            cb_pixel<KT>(wave, m, s_, prow, pcol);
-            const int oy = gy0 + prow, ox = gx0 + pcol, c = co0 + part * 8;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(sl + s_ * CB_SROW + part * 8);
-#ifdef CB_X_NOSTORE
-            if (val.x == 0x12345678u && oy < d.Gh && ox < d.Gw && c < d.Cout)
-#else
-            if (oy < d.Gh && ox < d.Gw && c < d.Cout)
-#endif
-                *reinterpret_cast<u32x4*>(out + ((size_t)(n * d.Ho + oy * d.oys + d.oyo) * d.Wo + ox * d.oxs + d.oxo) * vw.cs +
-                                          vw.coff + c) = val;
-        }
-    };
-    if constexpr (EP >= 0) {
-        // branch-free variants: the slabs of MB pixel tiles are written back to back, then read and stored back to back
-        // (wave-private slabs, LDS executes a wave's operations in order: no barrier, one LDS round trip per round)
-        constexpr int NSL = (EP & CB_Y0) ? 2 : 1;
-        constexpr int MB_ = T::BIAS / (4 * CB_SLAB * 2 * NSL);
-        constexpr int MB = MB_ >= 4 ? 4 : MB_ >= 2 ? 2 : 1;
-        __bf16* wslab = reinterpret_cast<__bf16*>(smem) + wave * (MB * NSL * CB_SLAB);
-#pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += MB) {
-#pragma unroll
-            for (int mm = 0; mm < MB; ++mm) {
-                const int m = r0 + mm;
-                __bf16* slab = wslab + mm * NSL * CB_SLAB;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[m][t][4 * q4 + e];
-                            if constexpr ((EP & CB_LRELU) != 0) v[e] = lrelu_max(v[e]);   // == lrelu()
-                        }
-                        if constexpr ((EP & CB_Y0) != 0) {   // y0 = act(conv + bias), before the residual
-                            bf16x4c o0;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o0[e] = (__bf16)v[e];
-                            *reinterpret_cast<bf16x4c*>(slab + CB_SLAB + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o0;
-                        }
-                        if constexpr (HAS_R1) {
-                            const u32x2c r = q1[m][t * 4 + q4];
-                            v[0] += d.beta1 * cb_lo(r[0]); v[1] += d.beta1 * cb_hi(r[0]);
-                            v[2] += d.beta1 * cb_lo(r[1]); v[3] += d.beta1 * cb_hi(r[1]);
-                        }
-                        if constexpr (HAS_ACC) {
-                            const u32x2c r = qa[m][t * 4 + q4];
-                            v[0] += cb_lo(r[0]); v[1] += cb_hi(r[0]); v[2] += cb_lo(r[1]); v[3] += cb_hi(r[1]);
-                        }
-                        if constexpr (HAS_MASK) {
-                            const u32x2c r = qm[m][t * 4 + q4];
-                            v[0] = lrelu_mask_lo(v[0], r[0]); v[1] = lrelu_mask_hi(v[1], r[0]);
-                            v[2] = lrelu_mask_lo(v[2], r[1]); v[3] = lrelu_mask_hi(v[3], r[1]);
-                        }
-                        bf16x4c o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o;
-                    }
+        // every chunk but the stream's last one runs in the loops; the last chunk and its epilogue are peeled (staging
+        // registers dead: they hold the prefetched epilogue operands)
+        int gc = 0;
+        for (int k = 0; k < nimg; ++k) {
+            const int nn = n0 + k * G;
+            const bool last_img = k + 1 == nimg;
+            acc_init();
+            for (int c = 0; c < (last_img ? nchunks - 1 : nchunks); ++c, ++gc) {
+                const bool last_c = c + 1 == nchunks;
+                chunk(gc, k > 0 && c == 0, nn, last_c ? nn + G : nn, last_c ? 0 : c + 1, std::true_type{});
             }
-#pragma unroll
-            for (int mm = 0; mm < MB; ++mm) {
-                const __bf16* slab = wslab + mm * NSL * CB_SLAB;
-                flush(r0 + mm, slab, yp, d.y);
-                if constexpr ((EP & CB_Y0) != 0) flush(r0 + mm, slab + CB_SLAB, y0p, d.y0);
+            if (!last_img) {
+                // image boundary: the next image's first chunk leaves the staging registers BEFORE the epilogue (which then
+                // has the register file to itself); its stores, and the epilogue's global stores, drain under the next MFMAs
+                CB_BAR();                                         // everyone is finished reading this image's last chunk
+                store_chunk();
+                epilogue(nn, T::SLABS, std::false_type{});
             }
         }
-    } else {
-        // generic epilogue: the full ssr_conv_desc contract with run-time flags, one pixel tile at a time
-        __bf16* slab = reinterpret_cast<__bf16*>(smem) + wave * CB_SLAB;   // [32 lane-slots][64 co]
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const size_t pp = ppx[m];
-            const bool pvalid = pval[m];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bf16x4c q1g[4], q2g[4], qag[4], qmg[4];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const int cc = c < d.Cout ? c : 0;
-                    if (r1p) q1g[q4] = *reinterpret_cast<const bf16x4c*>(r1p + pp * d.r1.cs + d.r1.coff + cc);
-                    if (r2p) q2g[q4] = *reinterpret_cast<const bf16x4c*>(r2p + pp * d.r2.cs + d.r2.coff + cc);
-                    if (d.accumulate) qag[q4] = *reinterpret_cast<const bf16x4c*>(yp + pp * d.y.cs + d.y.coff + cc);
-                    if (mp) qmg[q4] = *reinterpret_cast<const bf16x4c*>(mp + pp * d.m.cs + d.m.coff + cc);
-                }
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + t * 32 + 8 * q4 + co_l);
-                    bf16x4c o0, o1, o2;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[m][t][4 * q4 + e] + bq[e];
-                        if (d.act == SSR_ACT_LRELU) v = lrelu(v);
-                        v *= d.alpha;
-                        o0[e] = (__bf16)v;
-                        if (r1p) v += d.beta1 * (float)q1g[q4][e];
-                        if (r2p) v += d.beta2 * (float)q2g[q4][e];
-                        if (d.accumulate) v += (float)qag[q4][e];
-                        o1[e] = (__bf16)v;
-                        if (mp) v *= lrelu_grad_from_out((float)qmg[q4][e]);
-                        o2[e] = (__bf16)v;
-                    }
-                    if (pvalid && c < d.Cout) {
-                        if (y0p) *reinterpret_cast<bf16x4c*>(y0p + pp * d.y0.cs + d.y0.coff + c) = o0;
-                        if (y1p) *reinterpret_cast<bf16x4c*>(y1p + pp * d.y1.cs + d.y1.coff + c) = o1;
-                    }
-                    *reinterpret_cast<bf16x4c*>(slab + i * CB_SROW + t * 32 + 8 * q4 + co_l) = o2;
-                }
-            }
-            flush(m, slab, yp, d.y);
-        }
+        const int nl = n0 + (nimg - 1) * G;
+        chunk(gc, nimg > 1 && nchunks == 1, nl, nl, 0, std::false_type{});
+        BPROBE(7);
+        epilogue(nl, T::SLABS, std::true_type{});
     }
     BPROBE(8);
 }
@@ -500,7 +586,21 @@ template <int EP, int KT>
 int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
     constexpr int lds = CbT<KT>::LDS;
     const ssr_conv_desc& d = ds[0];
-    const int tiles = d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW);
+    // grid.x = (tile positions per image) x G image groups; a workgroup walks images n0, n0 + G, ... (conv_big_body).
+    // G minimises rounds x images-per-workgroup on 256 CUs (one workgroup per CU), then rounds, then prefers more groups.
+    const int tpi = ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW);
+    static const bool persist = [] { const char* e = getenv("SSR_CONV_BIG_PERSIST"); return !(e && e[0] == '0'); }();
+    int G = d.N;
+    if (persist && KT == 3) {
+        const long per_img = (long)tpi * (d.CoutPad / 64) * n;
+        long best = -1;
+        for (int g = 1; g <= d.N; ++g) {
+            const long rounds = (per_img * g + 255) / 256, cost = rounds * ((d.N + g - 1) / g);
+            const long key = (cost << 24) | (rounds << 12) | (4095 - (g > 4095 ? 4095 : g));
+            if (best < 0 || key < best) { best = key; G = g; }
+        }
+    }
+    const int tiles = tpi * G;
     if (n == 1) {
         auto kern = conv_big_kernel<EP, KT>;
         static bool attr_done = false;

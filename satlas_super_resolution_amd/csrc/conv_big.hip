@@ -97,7 +97,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const int tpi = tiles_x * tiles_y, G = gridDim.x / tpi;
     const int tp = blockIdx.x % tpi, n0 = blockIdx.x / tpi;
     const int tx_i = tp % tiles_x, ty_i = tp / tiles_x;
-    const int nimg = KT == 3 ? (d.N - n0 + G - 1) / G : 1;   // (the 2x2 kernels are launched with G = N: one image each)
+    const int nimg = (d.N - n0 + G - 1) / G;
     const int gy0 = ty_i * CB_TH, gx0 = tx_i * CB_TW;
     const int co0 = blockIdx.y * 64;
     const int upshift = d.up == 2 ? 1 : 0;
@@ -411,7 +411,8 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             OpsAcc la;
             OpsMask lm;
             // two operand kinds: 128 registers for all four pixel tiles do not fit next to the accumulator copies
-            constexpr bool LAZY = (HAS_R1 ? 1 : 0) + (HAS_ACC ? 1 : 0) + (HAS_MASK ? 1 : 0) > 1;
+            constexpr int NOPS = (HAS_R1 ? 1 : 0) + (HAS_ACC ? 1 : 0) + (HAS_MASK ? 1 : 0);
+            constexpr bool LAZY = NOPS > 1 || (KT == 2 && NOPS > 0);   // (2x2: staging + prefetched fragments stay live here)
             if constexpr (!LAZY) load_epi_ops_to(nn, l1, la, lm);
             epilogue_with(nn, sbase, l1, la, lm, std::bool_constant<LAZY>{});
         } else {
@@ -449,7 +450,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 wq[s_][k] = *reinterpret_cast<const u32x4*>(smem + base + b_off + (tap * 64 + k * 32) * CB_AROW + kk * 32);
         };
         static_for<0, NV>([&](auto jc) { store_one(0, jc); });
-        if (T_ > 1) load_chunk(n0, 1);
+        if (T_ > 1) load_chunk(n0 + (1 / nchunks) * G, 1 % nchunks);
         CB_BAR();
         static_for<0, CB_PF>([&](auto sc) { static_for<0, 6>([&](auto kc) { issue1(0, sc, kc); }); });
         // the last chunk is a separate instantiation: the staging registers are dead there and hold the epilogue operands
@@ -488,11 +489,23 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             __builtin_amdgcn_sched_barrier(0);
             BPROBE_C(6);
         };
-        acc_init();
-        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, n0, n0, c + 2, std::true_type{});
-        chunk(nchunks - 1, n0, n0, 0, std::false_type{});
+        // stream position gc = (image k, chunk c); position gc + 2 is (image nn + ((c + 2) / nchunks) * G, chunk (c + 2) % nchunks).
+        // At an image boundary nothing in the schedule changes: the next image's first chunk is already in the other
+        // buffer, the one after it waits in the staging registers, and the epilogue's slabs use the buffer just consumed
+        // (barrier X of the next chunk orders them before its stores).  The stream's last chunk is peeled.
+        int gc = 0;
+        for (int k = 0; k < nimg; ++k) {
+            const int nn = n0 + k * G;
+            const bool last_img = k + 1 == nimg;
+            acc_init();
+            for (int c = 0; c < (last_img ? nchunks - 1 : nchunks); ++c, ++gc)
+                chunk(gc, nn, nn + ((c + 2) / nchunks) * G, (c + 2) % nchunks, std::true_type{});
+            if (!last_img) epilogue(nn, ((gc - 1) & 1) * T::BUF, std::false_type{});
+        }
+        const int nl = n0 + (nimg - 1) * G;
+        chunk(gc, nl, nl, 0, std::false_type{});
         BPROBE(7);
-        epilogue(n0, ((nchunks - 1) & 1) * T::BUF, std::true_type{});
+        epilogue(nl, (gc & 1) * T::BUF, std::true_type{});
     } else {
         auto chunk = [&](int c, bool stored, int nn, int nn1, int c1, auto hnc) {   // c = stream position; (nn1, c1) = position c + 1
             constexpr bool has_next = decltype(hnc)::value;            // the stream's last chunk is peeled: see above
@@ -589,9 +602,10 @@ int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
     // grid.x = (tile positions per image) x G image groups; a workgroup walks images n0, n0 + G, ... (conv_big_body).
     // G minimises rounds x images-per-workgroup on 256 CUs (one workgroup per CU), then rounds, then prefers more groups.
     const int tpi = ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW);
-    static const bool persist = [] { const char* e = getenv("SSR_CONV_BIG_PERSIST"); return !(e && e[0] == '0'); }();
+    // SSR_CONV_BIG_PERSIST: 0 = one image per workgroup, 2 / 3 = persistent 2x2 / 3x3 kernels only, default both
+    static const int persist = [] { const char* e = getenv("SSR_CONV_BIG_PERSIST"); return e ? atoi(e) : 1; }();
     int G = d.N;
-    if (persist && KT == 3) {
+    if (persist == 1 || persist == KT) {
         const long per_img = (long)tpi * (d.CoutPad / 64) * n;
         long best = -1;
         for (int g = 1; g <= d.N; ++g) {
@@ -599,6 +613,10 @@ int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
             const long key = (cost << 24) | (rounds << 12) | (4095 - (g > 4095 ? 4095 : g));
             if (best < 0 || key < best) { best = key; G = g; }
         }
+    }
+    if (const char* e = getenv("SSR_CONV_BIG_G")) {           // test hook: force the number of image groups (1..N)
+        const int g = atoi(e);
+        if (g >= 1) G = g < d.N ? g : d.N;
     }
     const int tiles = tpi * G;
     if (n == 1) {

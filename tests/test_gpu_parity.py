@@ -779,3 +779,19 @@ def test_stride2_forward_space_to_depth(cin, cout, H, W, B):
     y = _buf_to_nchw(hip, yb, cout, dt).cpu()
     yr = F.leaky_relu(F.conv2d(x.bfloat16().float(), (w / sigma).bfloat16().float(), None, stride=2, padding=1), 0.2)
     assert rel_err(y, yr) < 1.5e-2, rel_err(y, yr)
+
+
+@pytest.mark.parametrize("groups", ["1", "2"])
+def test_big_tile_workgroups_persistent_over_images(groups, monkeypatch):
+    """The big-tile kernels walk images n0, n0 + G, ... per workgroup, the chunk stream crossing image boundaries
+    (csrc/conv_big.hip).  G is chosen from the grid size, which the small parity shapes never push below N; the
+    SSR_CONV_BIG_G hook forces it: B = 3 with G = 1 (one workgroup per tile position, three images) and G = 2 (uneven: two
+    images / one image), for the in-stream and the final epilogue of every family — 3x3 lean and generic, the batched
+    2x2 parity classes of the stride-2 dgrad and the space-to-depth forward."""
+    monkeypatch.setenv("SSR_CONV_BIG_G", groups)
+    for variant in ("plain", "lrelu", "lrelu_r1_y0", "mask_acc", "mask_r1", "generic"):
+        test_big_tile_conv_matches_pipelined_kernel(variant, 128, 64, 32, 32, 3)
+    test_big_tile_conv_matches_pipelined_kernel("lrelu", 32, 64, 37, 21, 3)        # a single chunk per image
+    test_stride2_dgrad_big_tile_parity_classes(128, 64, 32, 32, 3, monkeypatch)
+    test_stride2_forward_space_to_depth(64, 128, 32, 32, 3)
+    test_stride2_forward_space_to_depth(32, 64, 66, 34, 3)                         # nchunks = 4 (one per parity class)

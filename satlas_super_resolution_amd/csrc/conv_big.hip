@@ -32,28 +32,31 @@
 namespace {
 
 constexpr int CB_TH = 32, CB_TW = 16;
-constexpr int CB_AROW = 80;                                  // bytes per LDS row: 32 bf16 + 16 pad
-// KT x KT taps: 3 (the 3x3 layers) or 2 (one output-parity class of a 4x4 stride-2 transposed conv: conv1..conv3 dgrad)
+// KT x KT taps: 3 (the 3x3 layers) or 2 (one output-parity class of a 4x4 stride-2 transposed conv: conv1..conv3 dgrad,
+// or a 4x4 stride-2 forward layer through the space-to-depth view).  CK = input channels per LDS chunk: 32, or 16 for the
+// double-buffered 3x3 pipeline (two 32-channel 3x3 chunks do not fit the 160 KB of LDS, two 16-channel ones do).
 // output transpose slabs: [32 px][64 co] with 144-byte rows (a 128-byte pitch puts the 32 lanes of a ds_write_b64 on two
 // bank pairs: a 16-way conflict that cost 8k of the 11k epilogue cycles, tools/big_probe.hip)
 constexpr int CB_SROW = 72, CB_SLAB = 32 * CB_SROW;
-template <int KT> struct CbT {
+template <int KT, int CK> struct CbT {
+    static constexpr int AROW = CK * 2 + 16;                   // bytes per LDS row: CK bf16 + 16 pad (80: bank = 20 r, 48: 12 r — both
+                                                               // conflict-free for rows distinct mod 16)
+    static constexpr int VPP = CK / 8, KSUB = CK / 16;         // 16-byte vectors per row; 16-channel k-substeps per tap
+    static constexpr bool DB = KT == 2 || CK == 16;            // double-buffered continuous k-step stream (see conv_big_body)
     static constexpr int PH = CB_TH + KT - 1, PW = CB_TW + KT - 1, NPIX = PH * PW;     // 612 / 561
-    static constexpr int PATCH = NPIX * CB_AROW;               // 48,960 / 44,880
+    static constexpr int PATCH = NPIX * AROW;                  // 48,960 / 44,880 (29,376 for 3x3 with CK = 16)
     static constexpr int WROWS = KT * KT * 64;
-    static constexpr int WBYTES = WROWS * CB_AROW;             // 46,080 / 20,480
-    static constexpr int BUF = PATCH + WBYTES;                 // one chunk: 95,040 / 65,360
-    static constexpr int NBUF = KT == 2 ? 2 : 1;               // the 2x2 chunks are double-buffered (see the chunk loops)
+    static constexpr int WBYTES = WROWS * AROW;                // 46,080 / 20,480 (27,648)
+    static constexpr int BUF = PATCH + WBYTES;                 // one chunk: 95,040 / 65,360 (57,024)
+    static constexpr int NBUF = DB ? 2 : 1;
     static constexpr int BIAS = NBUF * BUF;                    // 64 floats
-    // output transpose slabs: 3x3 kernels have a dedicated area behind the bias table (the chunk area already holds the
-    // NEXT image's first chunk when an epilogue runs, see conv_big_body); the double-buffered 2x2 kernels reuse the
-    // buffer of the chunk just consumed
-    static constexpr int SLABS = KT == 3 ? BIAS + 256 : 0, SLABB = KT == 3 ? 4 * 2 * 32 * 72 * 2 : BUF;
-    static constexpr int LDS = BIAS + 256 + (KT == 3 ? SLABB : 0);
-    static constexpr int NPV = (NPIX * 4 + 255) / 256;         // patch vectors per thread: 10 / 9
-    static constexpr int NWV = WROWS * 4 / 256;                // weight vectors per thread: 9 / 4
-    static constexpr int NSTEP = KT * KT * 2;                  // k-steps per 32-channel chunk: 18 / 8
-    static constexpr int LPS = (NPV + NWV + NSTEP - 1) / NSTEP;   // staging loads sprinkled per k-step: 2 / 2
+    // output transpose slabs: the single-buffered kernel has a dedicated area behind the bias table (the chunk area already
+    // holds the NEXT image's first chunk when an epilogue runs); the double-buffered ones reuse the buffer just consumed
+    static constexpr int SLABS = DB ? 0 : BIAS + 256, SLABB = DB ? BUF : 4 * 2 * 32 * 72 * 2;
+    static constexpr int LDS = BIAS + 256 + (DB ? 0 : SLABB);
+    static constexpr int NPV = (NPIX * VPP + 255) / 256;       // patch vectors per thread: 10 / 9 (5)
+    static constexpr int NWV = (WROWS * VPP + 255) / 256;      // weight vectors per thread: 9 / 4 (5)
+    static constexpr int NSTEP = KT * KT * KSUB;               // k-steps per chunk: 18 / 8 (9)
     static_assert(LDS <= 160 * 1024 && 4 * 2 * 32 * 72 * 2 <= SLABB, "LDS budget / two slabs per wave fit");
 };
 
@@ -78,12 +81,13 @@ __device__ __forceinline__ float cb_hi(unsigned w) { return __builtin_bit_cast(f
 template <int KT>
 __device__ __forceinline__ void cb_pixel(int w, int m, int s, int& row, int& col) {
     row = 8 * w + 2 * m + (s >> 4);
-    col = s < 16 ? s : ((s + 32 - CbT<KT>::PW) & 15);
+    col = s < 16 ? s : ((s + 32 - (CB_TW + KT - 1)) & 15);
 }
 
-template <int EP, int KT>
+template <int EP, int KT, int CK>
 __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
-    using T = CbT<KT>;
+    using T = CbT<KT, CK>;
+    constexpr int CB_AROW = T::AROW, VPP = T::VPP;
     constexpr int CB_PW = T::PW, CB_NPIX = T::NPIX, CB_PATCH = T::PATCH, CB_BIAS = T::BIAS, CB_NPV = T::NPV, CB_NWV = T::NWV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,8 +108,9 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     const int LH = d.Hi << upshift, LW = d.Wi << upshift;
     const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
     const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
-    const int nchunks = (d.Cin + 31) / 32;
-    const size_t wchunk = (size_t)KT * KT * d.CoutPad * 32;
+    const int nchunks = (d.Cin + CK - 1) / CK;
+    const size_t wchunk = (size_t)KT * KT * d.CoutPad * 32;   // the packed weights stay in 32-channel chunks: a 16-channel
+    constexpr int WSUB = 32 / CK;                              // LDS chunk reads half of each 64-byte row
     const int T_ = nimg * nchunks;                             // length of this workgroup's chunk stream
     const size_t ximg = (size_t)d.Hi * d.Wi * d.x.cs, oimg = (size_t)d.Ho * d.Wo;   // per-image strides (elements / pixels)
 
@@ -124,7 +129,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
 #pragma unroll
     for (int q = 0; q < CB_NPV; ++q) {
         const int v = tid + q * 256;
-        const int pix = v >> 2, part = v & 3;
+        const int pix = v / VPP, part = v % VPP;
         const int py = pix / CB_PW, px = pix - py * CB_PW;
         const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
         if constexpr (KT == 2) {
@@ -132,27 +137,27 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 const int sy = 2 * ly - 1, sx = 2 * lx - 1;
                 const bool y0 = sy >= 0 && sy < d.Hi, y1 = sy + 1 >= 0 && sy + 1 < d.Hi;
                 const bool x0 = sx >= 0 && sx < d.Wi, x1 = sx + 1 >= 0 && sx + 1 < d.Wi;
-                pmk[q] = v < CB_NPIX * 4 ? (unsigned)(y0 && x0) | (unsigned)(y0 && x1) << 1 | (unsigned)(y1 && x0) << 2 | (unsigned)(y1 && x1) << 3 : 0u;
+                pmk[q] = v < CB_NPIX * VPP ? (unsigned)(y0 && x0) | (unsigned)(y0 && x1) << 1 | (unsigned)(y1 && x0) << 2 | (unsigned)(y1 && x1) << 3 : 0u;
                 pgo[q] = (sy * d.Wi + sx) * d.x.cs + d.x.coff + part * 8;
             } else {
-                const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+                const bool ok = v < CB_NPIX * VPP && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
                 pmk[q] = ok ? 1u : 0u;
                 pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : 0;
             }
         } else {
-            const bool ok = v < CB_NPIX * 4 && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+            const bool ok = v < CB_NPIX * VPP && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
             pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
         }
-        plo[q] = v < CB_NPIX * 4 ? pix * CB_AROW + part * 16 : -1;
+        plo[q] = v < CB_NPIX * VPP ? pix * CB_AROW + part * 16 : -1;
     }
 #pragma unroll
     for (int q = 0; q < CB_NWV; ++q) {
         const int v = tid + q * 256;
-        const int row = v >> 2, part = v & 3;                  // row = tap*64 + co
+        const int row = v / VPP, part = v % VPP;               // row = tap*64 + co
         wgo[q] = ((row >> 6) * d.CoutPad + co0 + (row & 63)) * 32 + part * 8;
-        wlo[q] = CB_PATCH + row * CB_AROW + part * 16;
+        wlo[q] = v < T::WROWS * VPP ? CB_PATCH + row * CB_AROW + part * 16 : -1;
     }
-    const __amdgpu_buffer_rsrc_t rsx = cb_rsrc(d.x.p, (long)d.N * ximg * 2), rsw = cb_rsrc(d.w, (long)nchunks * wchunk * 2);
+    const __amdgpu_buffer_rsrc_t rsx = cb_rsrc(d.x.p, (long)d.N * ximg * 2), rsw = cb_rsrc(d.w, (long)((nchunks + WSUB - 1) / WSUB) * wchunk * 2);
     u32x4 rp[CB_NPV], rw[CB_NWV];
     // one staging load (vector j of the 19 per thread).  A wave that issues its loads back to back sits in the issue
     // of each one until the previous has drained (~170 cycles per 1-KiB instruction: the ~6.4 B/clk per-wave limit of
@@ -160,7 +165,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     // of chunk c.
     auto load_one = [&](int nn, int c, auto jc) {          // vector j of chunk c of image nn
         constexpr int j = decltype(jc)::value;
-        const int c0 = c * 32;
+        const int c0 = c * CK;
 #ifdef CB_X_NOLOAD
         if (c > 1 || nn != n0) return;                         // probe: chunks after the first two reuse stale registers
 #endif
@@ -169,16 +174,18 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             if constexpr (KT == 2) {
                 const int q = s2d ? c >> cpc_shift : 0;        // wave-uniform
                 const int soff = s2d ? ((q >> 1) * d.Wi + (q & 1)) * d.x.cs + ((c - (q << cpc_shift)) << 5) : c0;
-                if (((pmk[j] >> q) & 1u) && (s2d || c0 + (int)(tid & 3) * 8 < d.Cin))
+                if (((pmk[j] >> q) & 1u) && (s2d || c0 + (int)(tid % VPP) * 8 < d.Cin))
                     val = *reinterpret_cast<const u32x4*>(xg + nn * ximg + (ptrdiff_t)pgo[j] + soff);
             } else {
-                if (pgo[j] >= 0 && c0 + (int)(tid & 3) * 8 < d.Cin)
+                if (pgo[j] >= 0 && c0 + (int)(tid % VPP) * 8 < d.Cin)
                     val = __builtin_amdgcn_raw_buffer_load_b128(rsx, pgo[j] * 2, (int)((nn * ximg + c0) * 2), 0);
             }
             rp[j] = val;
         } else {
-            if constexpr (KT == 3) rw[j - CB_NPV] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wgo[j - CB_NPV] * 2, (int)(c * wchunk * 2), 0);
-            else rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
+            if (wlo[j - CB_NPV] >= 0) {
+                if constexpr (KT == 3) rw[j - CB_NPV] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (wgo[j - CB_NPV] + (c % WSUB) * CK) * 2, (int)((c / WSUB) * wchunk * 2), 0);
+                else rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
+            }
         }
     };
     auto load_chunk = [&](int nn, int c) { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(nn, c, jc); }); };
@@ -187,7 +194,8 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         for (int q = 0; q < CB_NPV; ++q)
             if (plo[q] >= 0) *reinterpret_cast<u32x4*>(smem + plo[q]) = rp[q];
 #pragma unroll
-        for (int q = 0; q < CB_NWV; ++q) *reinterpret_cast<u32x4*>(smem + wlo[q]) = rw[q];
+        for (int q = 0; q < CB_NWV; ++q)
+            if (wlo[q] >= 0) *reinterpret_cast<u32x4*>(smem + wlo[q]) = rw[q];
     };
 
     // ---- this lane's pixels (one per pixel tile) ----
@@ -405,14 +413,14 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
 
     auto epilogue = [&](int nn, int sbase, auto prec) {
         constexpr bool PRE = decltype(prec)::value;
-        if constexpr (KT == 2) CB_BAR();                      // 2x2: everyone is finished reading the buffer that becomes the slabs
+        if constexpr (T::DB) CB_BAR();                        // in-place slabs: everyone is finished reading the buffer that becomes them
         if constexpr (EP >= 0 && !PRE) {                      // operands of an in-stream epilogue live only here
             OpsR1 l1;
             OpsAcc la;
             OpsMask lm;
             // two operand kinds: 128 registers for all four pixel tiles do not fit next to the accumulator copies
             constexpr int NOPS = (HAS_R1 ? 1 : 0) + (HAS_ACC ? 1 : 0) + (HAS_MASK ? 1 : 0);
-            constexpr bool LAZY = NOPS > 1 || (KT == 2 && NOPS > 0);   // (2x2: staging + prefetched fragments stay live here)
+            constexpr bool LAZY = NOPS > 1 || (T::DB && NOPS > 0);   // (double-buffered: staging + prefetched fragments stay live here)
             if constexpr (!LAZY) load_epi_ops_to(nn, l1, la, lm);
             epilogue_with(nn, sbase, l1, la, lm, std::bool_constant<LAZY>{});
         } else {
@@ -420,8 +428,8 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         }
     };
 
-    if constexpr (KT == 2) {
-        // ---- 2x2 taps: only 8 k-steps (64 MFMAs per wave) per chunk, so a store -> barrier -> MFMA sequence per chunk left
+    if constexpr (T::DB) {
+        // ---- 2x2 taps (and 3x3 in 16-channel chunks): only 8 k-steps (64 MFMAs per wave) per chunk, so a store -> barrier -> MFMA sequence per chunk left
         //      the matrix cores idle for half of the loop (tools/big_probe.hip: 1500 of 5600 cycles in barriers and the
         //      chunk store, 4100 for 2048 cycles of MFMAs).  Two chunk buffers and ONE continuous stream of k-steps instead:
         //      during chunk c   steps 0..3  store chunk c+1 (registers -> the other buffer), after barrier X (everyone is
@@ -431,19 +439,19 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         //                       steps 6..7  already read the first fragments of chunk c+1
         //      The barriers are bare s_barrier + lgkmcnt(0): global loads stay in flight across them. ----
         constexpr int NSTEP = T::NSTEP, CB_PF = 2, NV = CB_NPV + CB_NWV;
-        static_assert(NSTEP == 8 && NV <= 13, "store / load slots of the step schedule");
+        static_assert(NSTEP >= 8 && NV <= 16 && (NSTEP - 4) * 4 >= NV, "store / load slots of the step schedule");
         auto store_one = [&](int base, auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (j < CB_NPV) {
                 if (plo[j] >= 0) *reinterpret_cast<u32x4*>(smem + base + plo[j]) = rp[j];
             } else {
-                *reinterpret_cast<u32x4*>(smem + base + wlo[j - CB_NPV]) = rw[j - CB_NPV];
+                if (wlo[j - CB_NPV] >= 0) *reinterpret_cast<u32x4*>(smem + base + wlo[j - CB_NPV]) = rw[j - CB_NPV];
             }
         };
         u32x4 wq[NSTEP][2], pq[NSTEP][4];
         // memory operation k (0..5) of k-step s_: the two weight fragments, then pixel fragments 0..3
         auto issue1 = [&](int base, auto sc, auto kc) {
-            constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1, k = decltype(kc)::value;
+            constexpr int s_ = decltype(sc)::value, tap = s_ / T::KSUB, kk = s_ % T::KSUB, k = decltype(kc)::value;
             if constexpr (k >= 2)
                 pq[s_][k - 2] = *reinterpret_cast<const u32x4*>(smem + base + a_off[k - 2] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
             else
@@ -477,7 +485,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                     }
                     constexpr int e = k == 1 ? 0 : k == 3 ? 1 : k == 6 ? 2 : k == 7 ? 3 : -1;
                     if constexpr (has1 && e >= 0) {
-                        constexpr int j = (s_ & 3) * 4 + e;       // 13 vectors over 4 steps: 4, 4, 4, 1
+                        constexpr int j = (s_ < 4 ? s_ : s_ - 4) * 4 + e;   // NV vectors, four per step
                         if constexpr (j < NV) {
                             if constexpr (s_ < 4) store_one(nxt, std::integral_constant<int, j>{});
                             else if (has2) load_one(nn2, c2, std::integral_constant<int, j>{});
@@ -526,7 +534,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             // memory operation k (0..5) of k-step s_: the two weight fragments, then pixel fragments 0..3 (the order the
             // MFMAs of that step need them in)
             auto issue1 = [&](auto sc, auto kc) {
-                constexpr int s_ = decltype(sc)::value, tap = s_ >> 1, kk = s_ & 1, k = decltype(kc)::value;
+                constexpr int s_ = decltype(sc)::value, tap = s_ / T::KSUB, kk = s_ % T::KSUB, k = decltype(kc)::value;
                 if constexpr (k >= 2)
                     pq[s_][k - 2] = *reinterpret_cast<const u32x4*>(smem + a_off[k - 2] + ((tap / KT) * CB_PW + tap % KT) * CB_AROW + kk * 32);
                 else
@@ -584,20 +592,20 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     BPROBE(8);
 }
 
-template <int EP, int KT>
+template <int EP, int KT, int CK>
 __global__ __launch_bounds__(256, 1) void conv_big_kernel(const ssr_conv_desc d) {
-    conv_big_body<EP, KT>(d);
+    conv_big_body<EP, KT, CK>(d);
 }
 // up to four descriptors of identical geometry (the output-parity classes of a stride-2 transposed conv), blockIdx.z selects
 struct ssr_conv_desc4b { ssr_conv_desc d[4]; };
-template <int EP, int KT>
+template <int EP, int KT, int CK>
 __global__ __launch_bounds__(256, 1) void conv_big_kernel4(const ssr_conv_desc4b p) {
-    conv_big_body<EP, KT>(p.d[blockIdx.z]);
+    conv_big_body<EP, KT, CK>(p.d[blockIdx.z]);
 }
 
-template <int EP, int KT>
+template <int EP, int KT, int CK>
 int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
-    constexpr int lds = CbT<KT>::LDS;
+    constexpr int lds = CbT<KT, CK>::LDS;
     const ssr_conv_desc& d = ds[0];
     // grid.x = (tile positions per image) x G image groups; a workgroup walks images n0, n0 + G, ... (conv_big_body).
     // G minimises rounds x images-per-workgroup on 256 CUs (one workgroup per CU), then rounds, then prefers more groups.
@@ -620,7 +628,7 @@ int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
     }
     const int tiles = tpi * G;
     if (n == 1) {
-        auto kern = conv_big_kernel<EP, KT>;
+        auto kern = conv_big_kernel<EP, KT, CK>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -629,7 +637,7 @@ int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
         }
         hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, 1), dim3(256), lds, st, d);
     } else {
-        auto kern = conv_big_kernel4<EP, KT>;
+        auto kern = conv_big_kernel4<EP, KT, CK>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -683,23 +691,27 @@ bool ssr_conv_big_qualifies(const ssr_conv_desc& d) {
     return wgs >= 128;                                        // at least half the CUs get a 512-pixel tile
 }
 
-template <int KT>
+template <int KT, int CK>
 static int cb_dispatch(const ssr_conv_desc* ds, int n, hipStream_t st) {
     switch (cb_epilogue_of(ds[0])) {
-        case 0: return launch_big<0, KT>(ds, n, st);
-        case CB_LRELU: return launch_big<CB_LRELU, KT>(ds, n, st);
-        case CB_LRELU | CB_R1: return launch_big<CB_LRELU | CB_R1, KT>(ds, n, st);
-        case CB_LRELU | CB_R1 | CB_Y0: return launch_big<CB_LRELU | CB_R1 | CB_Y0, KT>(ds, n, st);
-        case CB_MASK: return launch_big<CB_MASK, KT>(ds, n, st);
-        case CB_MASK | CB_ACC: return launch_big<CB_MASK | CB_ACC, KT>(ds, n, st);
-        case CB_MASK | CB_R1: return launch_big<CB_MASK | CB_R1, KT>(ds, n, st);
-        default: return launch_big<CB_GENERIC, KT>(ds, n, st);
+        case 0: return launch_big<0, KT, CK>(ds, n, st);
+        case CB_LRELU: return launch_big<CB_LRELU, KT, CK>(ds, n, st);
+        case CB_LRELU | CB_R1: return launch_big<CB_LRELU | CB_R1, KT, CK>(ds, n, st);
+        case CB_LRELU | CB_R1 | CB_Y0: return launch_big<CB_LRELU | CB_R1 | CB_Y0, KT, CK>(ds, n, st);
+        case CB_MASK: return launch_big<CB_MASK, KT, CK>(ds, n, st);
+        case CB_MASK | CB_ACC: return launch_big<CB_MASK | CB_ACC, KT, CK>(ds, n, st);
+        case CB_MASK | CB_R1: return launch_big<CB_MASK | CB_R1, KT, CK>(ds, n, st);
+        default: return launch_big<CB_GENERIC, KT, CK>(ds, n, st);
     }
 }
 
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_big_shape_ok(d) : !ssr_conv_big_qualifies(d)) return false;
-    *rc = d.KH == 3 ? cb_dispatch<3>(&d, 1, st) : cb_dispatch<2>(&d, 1, st);
+    // (CbT<3, 16> — the 3x3 layers on the double-buffered stream in 16-channel chunks — builds and passes the parity tests but
+    // is slower: 49.6 vs 42.5 us on tools/big_probe.hip, 13.86 vs 13.76 ms per step.  A 16-channel chunk reads 32-byte
+    // pieces of every pixel / weight row, so each staging load touches twice the cache lines, and its 48-byte LDS rows are
+    // one third padding.  Not instantiated.)
+    *rc = d.KH == 3 ? cb_dispatch<3, 32>(&d, 1, st) : cb_dispatch<2, 32>(&d, 1, st);
     return true;
 }
 
@@ -714,6 +726,6 @@ bool ssr_conv_big_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int*
     const ssr_conv_desc& d = ds[0];
     const long wgs = (long)d.N * ((d.Gh + CB_TH - 1) / CB_TH) * ((d.Gw + CB_TW - 1) / CB_TW) * (d.CoutPad / 64) * n;
     if (!always && (wgs < 192 || d.Gh < 24)) return false;   // small grids / half-empty 32-row tiles: pipelined kernel
-    *rc = cb_dispatch<2>(ds, n, st);
+    *rc = cb_dispatch<2, 32>(ds, n, st);
     return true;
 }

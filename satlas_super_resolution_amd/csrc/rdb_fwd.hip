@@ -179,77 +179,96 @@ __device__ __forceinline__ void rb_wait_ge(const int* p, int target) {
     while (rb_ld(p) < target) __builtin_amdgcn_s_sleep(1);
 }
 
-// Contraction of one weight slab (32 input channels of slice S) into NMT accumulators; po[m] = this lane's pixel of
-// M-tile m as a byte offset (18*oy + ox) * RB_AROW in the stage's own region.
-// Software pipeline, written out: there is one wave per SIMD, so LDS latency (>= 128 cycles) can only be hidden
-// inside the wave.  Operand reads run RB_PF k-steps ahead of the MFMAs that consume them; the sched_barrier fences
-// pin that order (left alone, hipcc sinks every ds_read next to its MFMA: `ds_read; s_waitcnt lgkmcnt(0); v_mfma`).
-// `mid` runs right after the LAST operand read of the slab has been issued (RB_PF k-steps before the end): the caller
-// hands the ring stage back there (LDS executes a wave's operations in order, so the flag write cannot overtake the
-// reads) and samples the next slab's ready counter, hiding the hand-over latency behind the remaining MFMAs.
-template <int K, int S, int NMT, typename Mid>
-__device__ __forceinline__ void rb_contract(f32x16 (&acc)[NMT], const int (&po)[NMT], const char* smem, const char* slab,
-                                            int plane, int i, int g, Mid&& mid) {
-    constexpr int DELTA = K - S - 1;               // offset of conv K's output region inside slice S's region
-    const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + (DELTA * RB_PITCH + DELTA) * RB_AROW;
+// Contraction of weight slabs into NMT accumulators.  po[m] = this lane's pixel of M-tile m as a byte offset
+// (18*oy + ox) * RB_AROW in the stage's own region.
+// Software pipeline, written out: there is one MFMA wave per SIMD, so LDS latency (>= 128 cycles) can only be hidden
+// inside the wave.  Operand reads run PF k-steps ahead of the MFMAs that consume them; the sched_barrier fences pin that
+// order (left alone, hipcc sinks every ds_read next to its MFMA: `ds_read; s_waitcnt lgkmcnt(0); v_mfma`).
+// The pipeline runs ACROSS slabs: during the last PF steps of a slab the first PF steps of the next one are read (its
+// ring stage is normally complete long before), so the matrix pipe does not drain and refill 26 times per block —
+// restarting cold cost ~300 cycles per slab, as much as the 9 MFMAs of a conv5 slab themselves (tools/rdb_probe.hip:
+// 768 cycles per conv5 slab).  A slab is described by a reader (RbRdK / RbRd5: operand addresses of its k-steps).
+template <int K, int S, int NMT> struct RbRdK {             // slab of conv K < 5 over 32 channels of slice S
+    static constexpr int NSTEP = 18;                         // 9 taps x 2 sixteen-channel k-substeps
     const char* ab[NMT];
+    const char* bb0;
+    const char* bb1;
+    __device__ __forceinline__ void init(const char* smem, const char* slab, int plane, const int (&po)[NMT], int i, int g) {
+        constexpr int DELTA = K - S - 1;           // offset of conv K's output region inside slice S's region
+        const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + (DELTA * RB_PITCH + DELTA) * RB_AROW;
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) ab[m] = sb + po[m];
-    const int bsw = (i >> 2) & 3;
-    const char* bb0 = slab + i * RB_WROW + ((g ^ bsw) << 4);
-    const char* bb1 = slab + i * RB_WROW + (((g ^ bsw) ^ 2) << 4);   // second 16-channel k-substep
-    constexpr int NSTEP = 18, RB_PF = NMT == 1 ? 4 : 3;
-    u32x4 bq[NSTEP], aq[NSTEP][NMT];
-    auto issue = [&](auto n_c) {
-        constexpr int n = decltype(n_c)::value;
+        for (int m = 0; m < NMT; ++m) ab[m] = sb + po[m];
+        const int bsw = (i >> 2) & 3;
+        bb0 = slab + i * RB_WROW + ((g ^ bsw) << 4);
+        bb1 = slab + i * RB_WROW + (((g ^ bsw) ^ 2) << 4);   // second 16-channel k-substep
+    }
+    template <int n> __device__ __forceinline__ void issue(u32x4& b, u32x4 (&a)[NMT], int i, int g) const {
         constexpr int tap = n / 2, kk = n % 2, ky = tap / 3, kx = tap % 3;
 #ifdef RB_X_NOB
-        bq[n] = u32x4{0x3c003c00u + (unsigned)g, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        b = u32x4{0x3c003c00u + (unsigned)g, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
 #else
-        bq[n] = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + tap * 32 * RB_WROW);
+        b = *reinterpret_cast<const u32x4*>((kk ? bb1 : bb0) + tap * 32 * RB_WROW);
 #endif
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #ifdef RB_X_NOA
-            aq[n][m] = u32x4{0x3c003c00u + (unsigned)i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+            a[m] = u32x4{0x3c003c00u + (unsigned)i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
 #else
-            aq[n][m] = *reinterpret_cast<const u32x4*>(ab[m] + (ky * RB_PITCH + kx) * RB_AROW + kk * 32);
+            a[m] = *reinterpret_cast<const u32x4*>(ab[m] + (ky * RB_PITCH + kx) * RB_AROW + kk * 32);
 #endif
-    };
-    static_for<0, RB_PF>([&](auto n_c) { issue(n_c); });
+    }
+};
+// conv5: one (chunk j, 16-channel half h) slab = 9 taps x 64 co rows of 32 B; this wave's N-tile nt -> rows tap*64 + nt*32 + i
+template <int S> struct RbRd5 {
+    static constexpr int NSTEP = 9;
+    const char* ab;
+    const char* bb;
+    __device__ __forceinline__ void init(const char* smem, const char* slab, int plane, int h, int nt, int po, int i, int g) {
+        constexpr int DELTA = 5 - S - 1;
+        ab = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + h * 32 + (DELTA * RB_PITCH + DELTA) * RB_AROW + po;
+        bb = slab + (nt * 32 + i) * 32 + ((g ^ ((i >> 3) & 1)) << 4);
+    }
+    template <int n> __device__ __forceinline__ void issue(u32x4& b, u32x4 (&a)[1], int, int) const {
+        b = *reinterpret_cast<const u32x4*>(bb + n * 64 * 32);
+        a[0] = *reinterpret_cast<const u32x4*>(ab + ((n / 3) * RB_PITCH + n % 3) * RB_AROW);
+    }
+};
+// first PF k-steps of a slab (cold start: beginning of a stage, or behind a slice wait)
+template <int PF, int NMT, typename Rd>
+__device__ __forceinline__ void rb_prime(const Rd& rd, u32x4 (&pb)[PF], u32x4 (&pa)[PF][NMT], int i, int g) {
+    static_for<0, PF>([&](auto n_c) { rd.template issue<decltype(n_c)::value>(pb[decltype(n_c)::value], pa[decltype(n_c)::value], i, g); });
+}
+// One slab.  In: pb / pa = its first PF k-steps (already requested).  `sample` runs two steps before the hand-over (the
+// caller reads the next slab's ready counter there, so that the answer is back when it is needed); `release` right after
+// the LAST operand read of this slab has been issued (LDS executes a wave's operations in order, so the flag write cannot
+// overtake the reads); with HAS_NEXT `next()` then returns the reader of the following slab (acquiring its ring stage)
+// and its first PF k-steps are requested under the remaining MFMAs, out through pb / pa.
+template <int NMT, int PF, bool HAS_NEXT, typename Cur, typename Sample, typename Release, typename Next>
+__device__ __forceinline__ void rb_stream(f32x16 (&acc)[NMT], const Cur& cur, u32x4 (&pb)[PF], u32x4 (&pa)[PF][NMT], int i, int g,
+                                          Sample&& sample, Release&& release, Next&& next) {
+    constexpr int NSTEP = Cur::NSTEP;
+    u32x4 bq[NSTEP], aq[NSTEP][NMT];
+    static_for<0, PF>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        bq[n] = pb[n];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) aq[n][m] = pa[n][m];
+    });
+    decltype(next()) nx = nullptr;                           // reader of the next slab (a pointer; nullptr_t without one)
     static_for<0, NSTEP>([&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + RB_PF < NSTEP) issue(std::integral_constant<int, n + RB_PF>{});
-        if constexpr (n + RB_PF == NSTEP - 1) mid();
+        if constexpr (n + PF < NSTEP) {
+            cur.template issue<n + PF>(bq[n + PF], aq[n + PF], i, g);
+            if constexpr (HAS_NEXT && n + PF == NSTEP - 3) sample();
+            if constexpr (n + PF == NSTEP - 1) release();
+        } else if constexpr (HAS_NEXT) {
+            if constexpr (n + PF == NSTEP) nx = next();
+            nx->template issue<n + PF - NSTEP>(pb[n + PF - NSTEP], pa[n + PF - NSTEP], i, g);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < NMT; ++m) mma16<__bf16>(acc[m], bq[n], aq[n][m]);   // A = weights (rows = co), B = pixels
-    });
-}
-
-// conv5: one (chunk j, 16-channel half h) slab = 9 taps x 64 co rows of 32 B; this wave's N-tile nt -> rows tap*64 + nt*32 + i
-template <int S, typename Mid>
-__device__ __forceinline__ void rb_contract5(f32x16& acc, int po, const char* smem, const char* slab, int plane, int h, int nt,
-                                             int i, int g, Mid&& mid) {
-    constexpr int DELTA = 5 - S - 1;
-    const char* ab = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + h * 32 + (DELTA * RB_PITCH + DELTA) * RB_AROW + po;
-    const char* bb = slab + (nt * 32 + i) * 32 + ((g ^ ((i >> 3) & 1)) << 4);
-    constexpr int NSTEP = 9, RB_PF = 4;
-    u32x4 bq[NSTEP], aq[NSTEP];
-    auto issue = [&](auto n_c) {
-        constexpr int tap = decltype(n_c)::value;
-        bq[tap] = *reinterpret_cast<const u32x4*>(bb + tap * 64 * 32);
-        aq[tap] = *reinterpret_cast<const u32x4*>(ab + ((tap / 3) * RB_PITCH + tap % 3) * RB_AROW);
-    };
-    static_for<0, RB_PF>([&](auto n_c) { issue(n_c); });
-    static_for<0, NSTEP>([&](auto n_c) {
-        constexpr int n = decltype(n_c)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + RB_PF < NSTEP) issue(std::integral_constant<int, n + RB_PF>{});
-        if constexpr (n + RB_PF == NSTEP - 1) mid();
-        __builtin_amdgcn_sched_barrier(0);
-        mma16<__bf16>(acc, bq[n], aq[n]);
     });
 }
 
@@ -351,14 +370,26 @@ struct RbCtx {            // what every stage needs
     const float* bias_lds;
     int n, ty0, tx0, tid, lane, wave, i, g;
     int hint_q, hint;     // ready counter of slab hint_q's ring stage, sampled during the previous slab
+#ifdef SSR_PROBE
+    unsigned long long wait_ticks = 0, wait_n = 0;
+#endif
 };
 // step q: wait for slab q / hand its ring stage back
 __device__ __forceinline__ const char* rb_acquire(RbCtx& c, int q) {
     // slab q is the (q/2 + 1)-th user of stage q % 2: complete when the stage's counter has all its producer parts.
     // (a producer cannot add for slab q + 2 before every consumer has released slab q, so the count is exact)
     const int target = RB_NPROD * (q / RB_NSTAGE + 1);
-    if (!(c.hint_q == q && c.hint >= target))
+    if (!(c.hint_q == q && c.hint >= target)) {
+#ifdef SSR_PROBE   // slots 14 / 15 of thread 0's probe row: ticks spent polling for slabs, number of polls that had to wait
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        int spins = 0;
+        while (rb_ld(c.ctl + CTL_READY + (q % RB_NSTAGE)) < target) ++spins;
+        c.wait_ticks += __builtin_amdgcn_s_memtime() - t0;
+        c.wait_n += (spins > 0) + 1000;
+#else
         while (rb_ld(c.ctl + CTL_READY + (q % RB_NSTAGE)) < target) {}
+#endif
+    }
     return c.ring + (q % RB_NSTAGE) * RB_SLAB;
 }
 __device__ __forceinline__ void rb_release(RbCtx& c, int upto) {   // this wave is finished with every slab < upto
@@ -371,10 +402,45 @@ __device__ __forceinline__ void rb_handover(RbCtx& c, int q) {
     c.hint = rb_ld(c.ctl + CTL_READY + ((q + 1) % RB_NSTAGE));
 }
 
+// sample the ready counter of slab q (consumed by the rb_acquire that follows two k-steps later)
+__device__ __forceinline__ void rb_sample(RbCtx& c, int q) {
+    c.hint_q = q;
+    c.hint = rb_ld(c.ctl + CTL_READY + (q % RB_NSTAGE));
+}
+
+// Chunks J..K of growth conv K (slab Q0 + j): the reader of chunk J and its first PF k-steps come in.  Chunk j+1 is
+// streamed behind chunk j except when it reads slice K-1 (the last chunk of K > 1), which the previous stage may still be
+// writing: that one waits for the slice, sends its 8x8 core to the dense buffer and starts cold.
+template <int K, int NMT, bool BWD, int J, typename Rd>
+__device__ __forceinline__ void rb_stage_chunks(RbCtx& c, f32x16 (&acc)[NMT], const int (&po)[NMT], const Rd& cur,
+                                                u32x4 (&pb)[NMT == 1 ? 4 : 3], u32x4 (&pa)[NMT == 1 ? 4 : 3][NMT]) {
+    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, q = Q0 + J, PF = NMT == 1 ? 4 : 3;
+    constexpr int J1 = J + 1, S1 = J1 < 2 ? 0 : J1 - 1, PL1 = J1 < 2 ? J1 : 0;
+    if constexpr (J == K) {                                   // last chunk of the stage
+        rb_stream<NMT, PF, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+    } else if constexpr (J1 == K && K > 1) {                  // the next chunk starts cold
+        rb_stream<NMT, PF, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+        rb_wait_ge(c.ctl + CTL_SLICE + (K - 1), 4);
+        rb_flush_core<K - 1, BWD>(c.d, c.smem, c.n, c.ty0, c.tx0, c.tid);
+        RbRdK<K, S1, NMT> nxt;
+        nxt.init(c.smem, rb_acquire(c, q + 1), PL1, po, c.i, c.g);
+        rb_prime<PF, NMT>(nxt, pb, pa, c.i, c.g);
+        rb_stage_chunks<K, NMT, BWD, J1>(c, acc, po, nxt, pb, pa);
+    } else {
+        RbRdK<K, S1, NMT> nxt;
+        rb_stream<NMT, PF, true>(acc, cur, pb, pa, c.i, c.g, [&] { rb_sample(c, q + 1); }, [&] { rb_release(c, q + 1); },
+                                 [&]() -> const RbRdK<K, S1, NMT>* {
+                                     nxt.init(c.smem, rb_acquire(c, q + 1), PL1, po, c.i, c.g);
+                                     return &nxt;
+                                 });
+        rb_stage_chunks<K, NMT, BWD, J1>(c, acc, po, nxt, pb, pa);
+    }
+}
+
 // One growth conv (K = 1..4) for NMT M-tiles of this wave: chunks j = 0..K (slab Q0 + j), then the slice epilogue.
 template <int K, int NMT, bool BWD>
 __device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
-    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9;
+    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, PF = NMT == 1 ? 4 : 3;
     f32x16 acc[NMT];
     RbPix px[NMT];
     int po[NMT];
@@ -388,20 +454,40 @@ __device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
     rb_acc_init<BWD>(acc[0], c.bias_lds + 32 * (K - 1), c.g);
 #pragma unroll
     for (int m = 1; m < NMT; ++m) acc[m] = acc[0];
-    static_for<0, K + 1>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int S = j < 2 ? 0 : j - 1, PL = j < 2 ? j : 0;
-        if constexpr (j == K && K > 1) {
-            // last chunk: slice K-1 (stored by the previous stage) must be complete; its 8x8 core also goes to the dense buffer
-            rb_wait_ge(c.ctl + CTL_SLICE + (K - 1), 4);
-            rb_flush_core<K - 1, BWD>(c.d, c.smem, c.n, c.ty0, c.tx0, c.tid);
-        }
-        const char* slab = rb_acquire(c, Q0 + j);
-        rb_contract<K, S, NMT>(acc, po, c.smem, slab, PL, c.i, c.g, [&] { rb_handover(c, Q0 + j); });
-    });
+    u32x4 pb[PF], pa[PF][NMT];
+    RbRdK<K, 0, NMT> first;                                   // chunk 0: plane 0 of the block input
+    first.init(c.smem, rb_acquire(c, Q0), 0, po, c.i, c.g);
+    rb_prime<PF, NMT>(first, pb, pa, c.i, c.g);
+    rb_stage_chunks<K, NMT, BWD, 0>(c, acc, po, first, pb, pa);
 #pragma unroll
     for (int m = 0; m < NMT; ++m) rb_store_slice<K, BWD>(acc[m], px[m], mk[m], c.smem, c.g);
     if (c.lane == 0) __atomic_fetch_add(c.ctl + CTL_SLICE + K, 1, __ATOMIC_RELAXED);   // LDS ops of a wave execute in order
+}
+
+// conv5 slabs T..11 (slab 14 + t = chunk t/2, channel half t%2), same streaming; slab 10 is the first reader of slice 4
+template <bool BWD, int T, typename Rd>
+__device__ __forceinline__ void rb_stage5_slabs(RbCtx& c, f32x16 (&acc)[1], int po, int nt, const Rd& cur, u32x4 (&pb)[4],
+                                                u32x4 (&pa)[4][1]) {
+    constexpr int q = 14 + T, T1 = T + 1, J1 = T1 / 2, H1 = T1 % 2, S1 = J1 < 2 ? 0 : J1 - 1, PL1 = J1 < 2 ? J1 : 0;
+    if constexpr (T == 11) {
+        rb_stream<1, 4, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+    } else if constexpr (T1 == 10) {
+        rb_stream<1, 4, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+        rb_wait_ge(c.ctl + CTL_SLICE + 4, 4);
+        rb_flush_core<4, BWD>(c.d, c.smem, c.n, c.ty0, c.tx0, c.tid);
+        RbRd5<S1> nxt;
+        nxt.init(c.smem, rb_acquire(c, q + 1), PL1, H1, nt, po, c.i, c.g);
+        rb_prime<4, 1>(nxt, pb, pa, c.i, c.g);
+        rb_stage5_slabs<BWD, T1>(c, acc, po, nt, nxt, pb, pa);
+    } else {
+        RbRd5<S1> nxt;
+        rb_stream<1, 4, true>(acc, cur, pb, pa, c.i, c.g, [&] { rb_sample(c, q + 1); }, [&] { rb_release(c, q + 1); },
+                              [&]() -> const RbRd5<S1>* {
+                                  nxt.init(c.smem, rb_acquire(c, q + 1), PL1, H1, nt, po, c.i, c.g);
+                                  return &nxt;
+                              });
+        rb_stage5_slabs<BWD, T1>(c, acc, po, nt, nxt, pb, pa);
+    }
 }
 
 template <bool BWD>
@@ -475,7 +561,18 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
         // slab s: registers (requested RB_RQ slabs ahead) -> ring
         // stage s % 2 once every MFMA wave is finished with slab s - 2 -> publish.  LDS operations of a wave execute
         // in order, so the flag write follows the data.
+#ifdef SSR_PROBE   // producer wave 4: ticks waiting for the consumers (slot 11), waiting for its loads + storing (12), issuing loads (13)
+#define PPROBE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PPROBE_ADD(k, a, b) pacc[(k) - 11] += (b) - (a)
+#else
+#define PPROBE_T(var)
+#define PPROBE_ADD(k, a, b)
+#endif
+#ifdef SSR_PROBE
+        unsigned long long pacc[3] = {0, 0, 0};
+#endif
         auto put = [&](int s_, const u32x4 (&r)[RB_PV]) {
+            PPROBE_T(tp0);
             if (s_ >= RB_NSTAGE) {
                 for (;;) {
                     // inline asm: for a volatile / atomic LDS read hipcc emits `s_waitcnt vmcnt(0)` first, which would
@@ -483,10 +580,17 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
                     u32x4 dn;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(RB_CTL + 4 * CTL_DONE)) : "memory");
                     if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= s_ - (RB_NSTAGE - 1)) break;
+#ifdef RB_POLL_SLEEP
+                    __builtin_amdgcn_s_sleep(RB_POLL_SLEEP);
+#endif
                 }
             }
+            PPROBE_T(tp1);
             rb_store_slab(ring + (s_ % RB_NSTAGE) * RB_SLAB, lane, pw, r);
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(RB_CTL + 4 * (CTL_READY + (s_ % RB_NSTAGE)))), "v"(1) : "memory");
+            PPROBE_T(tp2);
+            PPROBE_ADD(11, tp0, tp1);
+            PPROBE_ADD(12, tp1, tp2);
         };
         // L2 warm-up for the next launch: blocks are dealt to the 8 XCDs round-robin, so the gridDim.x / 8 blocks of an
         // XCD split the lines of w_next among themselves (one dword per 128-byte line, 64 lines per wave instruction).
@@ -510,8 +614,14 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
                 constexpr int u = decltype(uc)::value;
                 const int s_ = s0 + u;
                 if (s_ < RB_NSLAB) put(s_, wq[u]);
+                PPROBE_T(tl0);
                 if (s_ + RB_RQ < RB_NSLAB) rb_load_slab<BWD>(d, s_ + RB_RQ, lane, pw, wq[u]);
+                PPROBE_T(tl1);
+                PPROBE_ADD(13, tl0, tl1);
             });
+#ifdef SSR_PROBE
+        if (tid == 256) for (int k = 0; k < 3; ++k) g_probe[blockIdx.x * 16 + 11 + k] += pacc[k];
+#endif
         if (pf == 0x9e3779b9u) ctl[15] = 1;   // keeps the warm-up loads alive; never true for packed bf16 weights in practice
         return;
     }
@@ -552,16 +662,13 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const u32x2v*>(rp + 8 * q4);
         }
-        static_for<0, 12>([&](auto tc) {
-            constexpr int t = decltype(tc)::value, j = t / 2, h = t % 2;
-            constexpr int S = j < 2 ? 0 : j - 1, PL = j < 2 ? j : 0;
-            if constexpr (t == 10) {
-                rb_wait_ge(ctl + CTL_SLICE + 4, 4);
-                rb_flush_core<4, BWD>(d, smem, n, ty0, tx0, tid);
-            }
-            const char* slab = rb_acquire(c, 14 + t);
-            rb_contract5<S>(acc[0], po[0], smem, slab, PL, h, nt, i, g, [&] { rb_handover(c, 14 + t); });
-        });
+        {
+            u32x4 pb[4], pa[4][1];
+            RbRd5<0> first;                                   // slab 14: chunk 0 (plane 0 of the block input), channels 0..15
+            first.init(smem, rb_acquire(c, 14), 0, 0, nt, po[0], i, g);
+            rb_prime<4, 1>(first, pb, pa, i, g);
+            rb_stage5_slabs<BWD, 0>(c, acc, po[0], nt, first, pb, pa);
+        }
         PROBE(6);
         if (lane == 0) __atomic_fetch_add(ctl + CTL_SLICE + 5, 1, __ATOMIC_RELAXED);
         rb_wait_ge(ctl + CTL_SLICE + 5, 4);   // every wave is finished with the ring: it becomes the output transpose slabs
@@ -600,6 +707,9 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
         }
     }
     PROBE(7);
+#ifdef SSR_PROBE
+    if (threadIdx.x == 0) { g_probe[blockIdx.x * 16 + 14] += c.wait_ticks; g_probe[blockIdx.x * 16 + 15] += c.wait_n; }
+#endif
 }
 
 }  // namespace

@@ -28,6 +28,41 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
 #pragma unroll
                 for (int a = 0; a < NACC; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[a], 0, 0, 0);
+        } else if (MODE == 3) {   // one full pixel-fragment read per 3 taps; the other two taps are lane shifts (DPP wave_shl:1)
+            // merged with a masked fix-up read of the few lanes at row ends: the A traffic of a 3x3 row from 3 reads to ~1.1
+            u32x4 bq[18], aq[18][NACC], fx[18][NACC];
+            const bool edge = ((lane & 31) % 14) >= 12;          // lanes whose right neighbours are in the next region row
+            auto issue = [&](int n) {
+                bq[n] = *reinterpret_cast<const u32x4*>(pb + n * 1024);
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    if (n % 3 == 0) aq[n][a] = *reinterpret_cast<const u32x4*>(pa + (n * 2 + a) * 2560 % 60000);
+                    else if (edge) fx[n][a] = *reinterpret_cast<const u32x4*>(pa + (n * 2 + a) * 2560 % 60000);
+                }
+            };
+#pragma unroll
+            for (int n = 0; n < 3; ++n) issue(n);
+#pragma unroll
+            for (int n = 0; n < 18; ++n) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + 3 < 18) issue(n + 3);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[n]), __builtin_bit_cast(bf16x8, aq[n][a]), acc[a], 0, 0, 0);
+                    if (n % 3 != 2 && n + 1 < 18) {               // derive the next tap's fragment while this MFMA runs
+                        u32x4 nx;
+                        nx.x = __builtin_amdgcn_update_dpp(0u, aq[n][a].x, 0x130, 0xf, 0xf, true);
+                        nx.y = __builtin_amdgcn_update_dpp(0u, aq[n][a].y, 0x130, 0xf, 0xf, true);
+                        nx.z = __builtin_amdgcn_update_dpp(0u, aq[n][a].z, 0x130, 0xf, 0xf, true);
+                        nx.w = __builtin_amdgcn_update_dpp(0u, aq[n][a].w, 0x130, 0xf, 0xf, true);
+                        aq[n + 1][a].x = edge ? fx[n + 1][a].x : nx.x;
+                        aq[n + 1][a].y = edge ? fx[n + 1][a].y : nx.y;
+                        aq[n + 1][a].z = edge ? fx[n + 1][a].z : nx.z;
+                        aq[n + 1][a].w = edge ? fx[n + 1][a].w : nx.w;
+                    }
+                }
+            }
         } else {           // software-pipelined reads: 1 B + NACC A reads per NACC MFMAs, 3 steps ahead
             u32x4 bq[18], aq[18][NACC];
 #pragma unroll
@@ -89,6 +124,8 @@ int main() {
     run<1, 2>("mfma + 1.5 ds_read_b128, 2 acc", 256);
     run<1, 1>("mfma + 2 ds_read_b128, 1 acc", 256);
     run<2, 2>("same as 3 + barrier per 36 mfma", 256);
+    run<3, 2>("dpp-shifted taps, 2 acc", 256);
+    run<3, 1>("dpp-shifted taps, 1 acc", 256);
     run<0, 2>("bare mfma, 2 acc, 1 block", 1);
     return 0;
 }

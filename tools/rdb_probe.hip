@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
     auto run = [&]() { return bwd ? ssr_rdb_backward(&d, 0) : ssr_rdb_forward(&d, 0); };
     for (int it = 0; it < 3; ++it) run();
     hipDeviceSynchronize();
+    hipMemset(probe, 0, (size_t)nblk * 16 * 8);               // slots 14 / 15 accumulate over the 20 timed launches
     hipEventRecord(e0);
     for (int it = 0; it < 20; ++it) run();
     hipEventRecord(e1); hipEventSynchronize(e1);
@@ -38,5 +39,12 @@ int main(int argc, char** argv) {
     for (int b = 0; b < nblk; ++b) for (int k = 8; k < 14; ++k) q[k] += double(h[b * 16 + k] - h[b * 16 + (k == 8 ? 5 : k - 1)]);
     const char* n2[] = {"c5 setup+acq0", "contract0", "rel+acq1", "contract1", "rel+acq2", "contract2"};
     for (int k = 8; k < 14; ++k) printf("    %-12s %9.1f\n", n2[k - 8], q[k] / nblk);
+    double pp[3] = {0, 0, 0};
+    for (int b = 0; b < nblk; ++b) for (int k = 0; k < 3; ++k) pp[k] += double(h[b * 16 + 11 + k]);
+    printf("  producer wave 4 per block: waits for consumers %.0f, waits for its loads + stores %.0f, issues loads %.0f ticks\n",
+           pp[0] / nblk / 20, pp[1] / nblk / 20, pp[2] / nblk / 20);
+    double wt = 0, wn = 0;
+    for (int b = 0; b < nblk; ++b) { wt += double(h[b * 16 + 14]); wn += double(h[b * 16 + 15]); }
+    printf("  slab polls (wave 0): %.1f ticks per launch-block, %.2f fallback polls (x1000) + waits\n", wt / nblk / 20, wn / nblk / 20);
     return 0;
 }

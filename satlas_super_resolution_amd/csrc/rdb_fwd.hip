@@ -173,6 +173,16 @@ __device__ __forceinline__ void rb_store_slab(char* stage, int lane, int pw, con
         *reinterpret_cast<u32x4*>(stage + (jj * RB_NPROD + pw) * 1024 + lane * 16) = r[jj];
 }
 
+// operand prefetch distance in k-steps for stages with one / two pixel tiles per wave
+#ifndef RB_PF1
+#define RB_PF1 4
+#endif
+#ifndef RB_PF2
+#define RB_PF2 3
+#endif
+#ifndef RB_PF5
+#define RB_PF5 4   // conv5 (9 k-steps per slab)
+#endif
 // ---- LDS flags ----
 __device__ __forceinline__ int rb_ld(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void rb_wait_ge(const int* p, int target) {
@@ -413,8 +423,8 @@ __device__ __forceinline__ void rb_sample(RbCtx& c, int q) {
 // writing: that one waits for the slice, sends its 8x8 core to the dense buffer and starts cold.
 template <int K, int NMT, bool BWD, int J, typename Rd>
 __device__ __forceinline__ void rb_stage_chunks(RbCtx& c, f32x16 (&acc)[NMT], const int (&po)[NMT], const Rd& cur,
-                                                u32x4 (&pb)[NMT == 1 ? 4 : 3], u32x4 (&pa)[NMT == 1 ? 4 : 3][NMT]) {
-    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, q = Q0 + J, PF = NMT == 1 ? 4 : 3;
+                                                u32x4 (&pb)[NMT == 1 ? RB_PF1 : RB_PF2], u32x4 (&pa)[NMT == 1 ? RB_PF1 : RB_PF2][NMT]) {
+    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, q = Q0 + J, PF = NMT == 1 ? RB_PF1 : RB_PF2;
     constexpr int J1 = J + 1, S1 = J1 < 2 ? 0 : J1 - 1, PL1 = J1 < 2 ? J1 : 0;
     if constexpr (J == K) {                                   // last chunk of the stage
         rb_stream<NMT, PF, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
@@ -440,7 +450,7 @@ __device__ __forceinline__ void rb_stage_chunks(RbCtx& c, f32x16 (&acc)[NMT], co
 // One growth conv (K = 1..4) for NMT M-tiles of this wave: chunks j = 0..K (slab Q0 + j), then the slice epilogue.
 template <int K, int NMT, bool BWD>
 __device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
-    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, PF = NMT == 1 ? 4 : 3;
+    constexpr int Q0 = K == 1 ? 0 : K == 2 ? 2 : K == 3 ? 5 : 9, PF = NMT == 1 ? RB_PF1 : RB_PF2;
     f32x16 acc[NMT];
     RbPix px[NMT];
     int po[NMT];
@@ -466,22 +476,22 @@ __device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
 
 // conv5 slabs T..11 (slab 14 + t = chunk t/2, channel half t%2), same streaming; slab 10 is the first reader of slice 4
 template <bool BWD, int T, typename Rd>
-__device__ __forceinline__ void rb_stage5_slabs(RbCtx& c, f32x16 (&acc)[1], int po, int nt, const Rd& cur, u32x4 (&pb)[4],
-                                                u32x4 (&pa)[4][1]) {
+__device__ __forceinline__ void rb_stage5_slabs(RbCtx& c, f32x16 (&acc)[1], int po, int nt, const Rd& cur, u32x4 (&pb)[RB_PF5],
+                                                u32x4 (&pa)[RB_PF5][1]) {
     constexpr int q = 14 + T, T1 = T + 1, J1 = T1 / 2, H1 = T1 % 2, S1 = J1 < 2 ? 0 : J1 - 1, PL1 = J1 < 2 ? J1 : 0;
     if constexpr (T == 11) {
-        rb_stream<1, 4, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+        rb_stream<1, RB_PF5, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
     } else if constexpr (T1 == 10) {
-        rb_stream<1, 4, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
+        rb_stream<1, RB_PF5, false>(acc, cur, pb, pa, c.i, c.g, [] {}, [&] { rb_handover(c, q); }, [] { return nullptr; });
         rb_wait_ge(c.ctl + CTL_SLICE + 4, 4);
         rb_flush_core<4, BWD>(c.d, c.smem, c.n, c.ty0, c.tx0, c.tid);
         RbRd5<S1> nxt;
         nxt.init(c.smem, rb_acquire(c, q + 1), PL1, H1, nt, po, c.i, c.g);
-        rb_prime<4, 1>(nxt, pb, pa, c.i, c.g);
+        rb_prime<RB_PF5, 1>(nxt, pb, pa, c.i, c.g);
         rb_stage5_slabs<BWD, T1>(c, acc, po, nt, nxt, pb, pa);
     } else {
         RbRd5<S1> nxt;
-        rb_stream<1, 4, true>(acc, cur, pb, pa, c.i, c.g, [&] { rb_sample(c, q + 1); }, [&] { rb_release(c, q + 1); },
+        rb_stream<1, RB_PF5, true>(acc, cur, pb, pa, c.i, c.g, [&] { rb_sample(c, q + 1); }, [&] { rb_release(c, q + 1); },
                               [&]() -> const RbRd5<S1>* {
                                   nxt.init(c.smem, rb_acquire(c, q + 1), PL1, H1, nt, po, c.i, c.g);
                                   return &nxt;
@@ -663,10 +673,10 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
             for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const u32x2v*>(rp + 8 * q4);
         }
         {
-            u32x4 pb[4], pa[4][1];
+            u32x4 pb[RB_PF5], pa[RB_PF5][1];
             RbRd5<0> first;                                   // slab 14: chunk 0 (plane 0 of the block input), channels 0..15
             first.init(smem, rb_acquire(c, 14), 0, 0, nt, po[0], i, g);
-            rb_prime<4, 1>(first, pb, pa, i, g);
+            rb_prime<RB_PF5, 1>(first, pb, pa, i, g);
             rb_stage5_slabs<BWD, 0>(c, acc, po[0], nt, first, pb, pa);
         }
         PROBE(6);

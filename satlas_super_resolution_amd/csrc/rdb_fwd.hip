@@ -466,9 +466,12 @@ __device__ __forceinline__ void rb_stage(RbCtx& c, const int (&ent)[NMT]) {
     for (int m = 1; m < NMT; ++m) acc[m] = acc[0];
     u32x4 pb[PF], pa[PF][NMT];
     RbRdK<K, 0, NMT> first;                                   // chunk 0: plane 0 of the block input
+    if constexpr (K == 1) PROBE(8);
     first.init(c.smem, rb_acquire(c, Q0), 0, po, c.i, c.g);
+    if constexpr (K == 1) PROBE(9);
     rb_prime<PF, NMT>(first, pb, pa, c.i, c.g);
     rb_stage_chunks<K, NMT, BWD, 0>(c, acc, po, first, pb, pa);
+    if constexpr (K == 1) PROBE(10);
 #pragma unroll
     for (int m = 0; m < NMT; ++m) rb_store_slice<K, BWD>(acc[m], px[m], mk[m], c.smem, c.g);
     if (c.lane == 0) __atomic_fetch_add(c.ctl + CTL_SLICE + K, 1, __ATOMIC_RELAXED);   // LDS ops of a wave execute in order

@@ -35,10 +35,13 @@ int main(int argc, char** argv) {
     printf("N=%d blocks=%d avg launch = %.2f us\n", N, nblk, ms * 1000 / 20);
     const char* names[] = {"", "issue x + slab0", "conv1", "conv2", "conv3", "conv4", "conv5 mfma", "conv5 epilogue"};
     for (int k = 1; k < 8; ++k) printf("  %-18s %10.1f ticks avg\n", names[k], ph[k] / nblk);
-    double q[16] = {0};
-    for (int b = 0; b < nblk; ++b) for (int k = 8; k < 14; ++k) q[k] += double(h[b * 16 + k] - h[b * 16 + (k == 8 ? 5 : k - 1)]);
-    const char* n2[] = {"c5 setup+acq0", "contract0", "rel+acq1", "contract1", "rel+acq2", "contract2"};
-    for (int k = 8; k < 14; ++k) printf("    %-12s %9.1f\n", n2[k - 8], q[k] / nblk);
+    double st1[3] = {0, 0, 0};                                // stage 1 of wave 0: setup, wait for slab 0, both chunks
+    for (int b = 0; b < nblk; ++b) {
+        st1[0] += double(h[b * 16 + 8] - h[b * 16 + 1]); st1[1] += double(h[b * 16 + 9] - h[b * 16 + 8]);
+        st1[2] += double(h[b * 16 + 10] - h[b * 16 + 9]);
+    }
+    printf("    conv1: setup %.0f, wait for slab 0 %.0f, two chunks %.0f, slice store + flag %.0f\n", st1[0] / nblk, st1[1] / nblk,
+           st1[2] / nblk, (ph[2] - st1[0] - st1[1] - st1[2]) / nblk);
     double pp[3] = {0, 0, 0};
     for (int b = 0; b < nblk; ++b) for (int k = 0; k < 3; ++k) pp[k] += double(h[b * 16 + 11 + k]);
     printf("  producer wave 4 per block: waits for consumers %.0f, waits for its loads + stores %.0f, issues loads %.0f ticks\n",

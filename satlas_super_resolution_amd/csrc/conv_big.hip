@@ -9,11 +9,20 @@
 //   * register tiling 4 pixel tiles x 2 channel tiles per wave (8 accumulators): 6 operand reads feed 8 MFMAs
 //     (0.75 per MFMA) and the weight slab is amortised over 512 pixels;
 //   * per 32-channel chunk: 49 KB patch + 46 KB weights in ONE LDS stage (80-byte padded rows), the next chunk
-//     waits in registers (19 x 16 B per lane) while 144 MFMAs per wave run: 4.1 B/clk per wave;
+//     waits in registers (19 x 16 B per lane) while 144 MFMAs per wave run: 4.1 B/clk per wave; inside a k-step every
+//     LDS read / staging load is issued BETWEEN two MFMAs (bunched at the step boundary they idle the matrix pipe);
+//   * 2x2 kernels (KT = 2: the parity classes of a stride-2 dgrad, or a 4x4 stride-2 forward layer through the
+//     space-to-depth view of ssr_conv_desc.s2d) have only 64 MFMAs per chunk: two chunk buffers and one continuous
+//     k-step stream (store chunk c+1 / request chunk c+2 under the MFMAs of chunk c, two bare barriers per chunk);
+//   * workgroups are PERSISTENT over images (same tile position, image = scalar offset): the chunk stream crosses image
+//     boundaries, so the first chunk's latency and the epilogue's stores hide under MFMAs; the stream's last chunk is
+//     a separate instantiation whose (dead) staging registers hold the prefetched epilogue operands;
 //   * lane i of a pixel tile owns pixel (row i >> 4, column i or (i + 14) & 15 for the second row): rows are distinct
 //     mod 16 inside the hardware's 16-lane read groups for every tap -> conflict-free ds_read_b128 (pitch 18);
 //   * operands swapped (A = weights, B = pixels): a lane ends with ONE pixel x 16 channels per channel tile; the
-//     epilogue is pixel-per-lane, branch-free per feature set (template), outputs leave as 16-byte vectors.
+//     epilogue is pixel-per-lane, branch-free per feature set (template), outputs leave as 16-byte vectors through
+//     144-byte-pitch transpose slabs; staging loads, epilogue operands and output stores use buffer addressing (SGPR
+//     resource + 32-bit lane offset + scalar offset) — 64-bit pointers cost a register pair per vector.
 // Same descriptor and epilogue contract as conv.hip (ssr_conv_desc).
 //
 // Replaces nn.Conv2d 3x3 forward / dgrad at /root/reference/ssr/archs/discriminator_arch.py:35-37,55,59,63

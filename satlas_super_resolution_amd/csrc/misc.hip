@@ -375,7 +375,22 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const ssr_sn_item* __restric
     const int row = blockIdx.x * 4 + w;
     if (row >= it.rows) return;
     float s = 0.f;
-    for (int j = lane; j < it.cols; j += 64) s += it.w[(long)row * it.cols + j] * vsrc[j];
+    const float* __restrict__ wr = it.w + (long)row * it.cols;
+    if ((it.cols & 3) == 0 && ((uintptr_t)wr & 15) == 0 && ((uintptr_t)vsrc & 15) == 0) {
+        // 16-byte loads, four independent partial sums (one wave streams a row of up to 18 KB: the scalar loop with one
+        // dependent accumulator was latency bound, 31 us for 17.6 MB)
+        const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(wr);
+        const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(vsrc);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int j = lane; j < (it.cols >> 2); j += 64) {
+            const f32x4 x = w4[j], y = v4[j];
+            a.x += x.x * y.x; a.y += x.y * y.y; a.z += x.z * y.z; a.w += x.w * y.w;
+        }
+        s = (a.x + a.y) + (a.z + a.w);
+    } else {
+        for (int j = lane; j < it.cols; j += 64) s += wr[j] * vsrc[j];
+    }
     s = wave_sum(s) * inv;
     if (lane == 0) it.tmp[row] = s;
 }
@@ -403,8 +418,19 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const ssr_sn_bwd_item* 
     const ssr_sn_bwd_item it = items[blockIdx.y];
     const long n = (long)it.rows * it.cols;
     float s = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-        s += it.dw_sn[e] * it.w[e];
+    if ((n & 3) == 0 && (((uintptr_t)it.dw_sn | (uintptr_t)it.w) & 15) == 0) {
+        const f32x4* __restrict__ a4 = reinterpret_cast<const f32x4*>(it.dw_sn);
+        const f32x4* __restrict__ b4 = reinterpret_cast<const f32x4*>(it.w);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (n >> 2); e += (long)gridDim.x * blockDim.x) {
+            const f32x4 x = a4[e], y = b4[e];
+            a.x += x.x * y.x; a.y += x.y * y.y; a.z += x.z * y.z; a.w += x.w * y.w;
+        }
+        s = (a.x + a.y) + (a.z + a.w);
+    } else {
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+            s += it.dw_sn[e] * it.w[e];
+    }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) atomicAdd(it.tmp, s);
 }
@@ -415,9 +441,25 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const ssr_sn_bwd_item
     const float sigma = it.sigma[0];
     const float coef = it.tmp[0] / (sigma * sigma);  // <dW_sn, W> / sigma^2 = <dW_sn, W_sn> / sigma
     const float inv = 1.f / sigma;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(e / it.cols), j = (int)(e - (long)i * it.cols);
-        it.dw[e] += it.dw_sn[e] * inv - coef * it.u[i] * it.v[j];
+    if ((it.cols & 3) == 0 && n < (1L << 31) && (((uintptr_t)it.dw_sn | (uintptr_t)it.dw | (uintptr_t)it.v) & 15) == 0) {
+        // four columns per thread: one 32-bit division per 16 bytes (the per-element 64-bit division made this VALU bound)
+        const unsigned n4 = (unsigned)(n >> 2), c4 = (unsigned)it.cols >> 2;
+        const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(it.dw_sn);
+        const f32x4* __restrict__ v4 = reinterpret_cast<const f32x4*>(it.v);
+        f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(it.dw);
+        for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
+            const unsigned i = e / c4, j = e - i * c4;
+            const float cu = coef * it.u[i];
+            const f32x4 g = s4[e], v = v4[j];
+            f32x4 o = d4[e];
+            o.x += g.x * inv - cu * v.x; o.y += g.y * inv - cu * v.y; o.z += g.z * inv - cu * v.z; o.w += g.w * inv - cu * v.w;
+            d4[e] = o;
+        }
+    } else {
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+            const int i = (int)(e / it.cols), j = (int)(e - (long)i * it.cols);
+            it.dw[e] += it.dw_sn[e] * inv - coef * it.u[i] * it.v[j];
+        }
     }
 }
 
@@ -516,7 +558,9 @@ inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 
 extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream) {
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
-    dim3 grid(64, n_items);
+    // a table of a few large layers (the discriminator: conv3 alone is 131k (co, ci) pairs x 16 taps) needs more than 64
+    // workgroups per layer to fill the chip (r01 rocprofv3: 42 us for 35 MB); the generator's 351 small layers do not
+    dim3 grid(n_items <= 16 ? 1024 : 64, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
     else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
     else return SSR_EUNSUP;

@@ -220,7 +220,10 @@ class ESRGANTrainStep:
             if not self._warm:     # first touch of every kernel (hipFuncSetAttribute etc.) outside capture
                 return fn()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only this thread's calls are policed during capture.  With RCCL the process group's watchdog
+            # thread queries events at any time; in the default global mode such a call from another thread invalidates
+            # the capture.  Everything captured here is launched from this thread.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self._graphs[name] = g
         g.replay()

@@ -119,3 +119,16 @@ def test_stitch_and_sharded_chunk_loop():
     assert sorted(r0) == list(range(0, 11, 2)) and sorted(r1) == list(range(1, 11, 2))
     for k, v in {**r0, **r1}.items():
         assert v.shape == (128, 128, 3) and (v == full[k]).all()
+
+
+def test_discriminator_specs_steer_the_space_to_depth_path_by_grid_size():
+    """engine.discriminator_specs(in_hw=...): the 4x4 stride-2 layers (discriminator_arch.py:31-33) take the space-to-depth
+    big-tile path only on output grids of at least 24 rows; without a size hint the choice is left to the shape check."""
+    from satlas_super_resolution_amd import engine
+    flags = lambda hw: {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=hw) if s.k == 4}
+    assert flags(None) == {"conv1": None, "conv2": None, "conv3": None}
+    assert flags((128, 128)) == {"conv1": None, "conv2": None, "conv3": False}      # grids 64, 32, 16
+    assert flags((32, 32)) == {"conv1": False, "conv2": False, "conv3": False}      # the small parity shapes
+    assert flags((256, 96)) == {"conv1": None, "conv2": None, "conv3": False}       # min side decides: 48, 24, 12
+    names = [s.name for s in engine.discriminator_specs(3, 64)]
+    assert names == ["conv%d" % i for i in range(10)]

@@ -282,32 +282,37 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, 
     const T* __restrict__ mp = reinterpret_cast<const T*>(m.p);
     T* __restrict__ y1p = reinterpret_cast<T*>(y1.p);
     T* __restrict__ yp = reinterpret_cast<T*>(y.p);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % CV) * V;
-        long q = e / CV;
-        const int ix = (int)(q % W); q /= W;
-        const int iy = (int)(q % H);
-        const int n = (int)(q / H);
+    // (32-bit index arithmetic: the host checks total < 2^31; three 64-bit divisions per vector made this VALU bound)
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < (unsigned)total; e += gridDim.x * blockDim.x) {
+        const int c = (int)(e % (unsigned)CV) * V;
+        unsigned q = e / (unsigned)CV;
+        const int ix = (int)(q % (unsigned)W); q /= (unsigned)W;
+        const int iy = (int)(q % (unsigned)H);
+        const int n = (int)(q / (unsigned)H);
         float s[V], t[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) s[k] = 0.f;
         if (MODE == 0) {
+            // transpose of bil_src: input i receives 0.25 of output 2i-1, 0.75 of 2i (all of it at i = 0: the top border
+            // blends (0, 0)), 0.75 of 2i+1 (all of it at i = n-1) and 0.25 of 2i+2.  Fixed weights, clamped unconditional
+            // loads (weight 0 where the output does not exist), rows combined first.
+            const float wy[4] = {iy > 0 ? 0.25f : 0.f, iy > 0 ? 0.75f : 1.f, iy < H - 1 ? 0.75f : 1.f, iy < H - 1 ? 0.25f : 0.f};
+            const float wx[4] = {ix > 0 ? 0.25f : 0.f, ix > 0 ? 0.75f : 1.f, ix < W - 1 ? 0.75f : 1.f, ix < W - 1 ? 0.25f : 0.f};
 #pragma unroll
-            for (int dyy = -1; dyy <= 2; ++dyy) {
-                const int oy = 2 * iy + dyy;
-                if (oy < 0 || oy >= H2) continue;
-                const float wy = bil_w(oy, H, iy);
-                if (wy == 0.f) continue;
+            for (int a = 0; a < 4; ++a) {
+                const int oy = min(max(2 * iy - 1 + a, 0), H2 - 1);
+                float rs[V];
 #pragma unroll
-                for (int dxx = -1; dxx <= 2; ++dxx) {
-                    const int ox = 2 * ix + dxx;
-                    if (ox < 0 || ox >= W2) continue;
-                    const float wx = bil_w(ox, W, ix);
-                    if (wx == 0.f) continue;
-                    VecIO<T>::load(dp + (((long)n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c, t);
+                for (int k = 0; k < V; ++k) rs[k] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < V; ++k) s[k] += wy * wx * t[k];
+                for (int b = 0; b < 4; ++b) {
+                    const int ox = min(max(2 * ix - 1 + b, 0), W2 - 1);
+                    VecIO<T>::load(dp + ((size_t)(n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c, t);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) rs[k] += wx[b] * t[k];
                 }
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] += wy[a] * rs[k];
             }
         } else {
 #pragma unroll
@@ -655,6 +660,7 @@ static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m
                     int32_t W, int32_t C, void* stream) {
     if (!dy.p || (!y.p && !y1.p) || (C % 8) != 0 || (dy.cs % 8) || (dy.coff % 8)) return SSR_EINVAL;
     const long total = (long)N * H * W * C / 4;
+    if (total >= (1L << 31)) return SSR_EINVAL;               // the kernel indexes in 32 bits
     if (dtype == SSR_F32)
         hipLaunchKernelGGL((up2x_bwd_kernel<float, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
                            dy, r, y1, y, m, N, H, W, C);

@@ -140,6 +140,9 @@ constexpr int RB_NSLAB = 26;
 constexpr int RB_PV = 18 / RB_NPROD;
 template <bool BWD>
 __device__ __forceinline__ void rb_load_slab(const ssr_rdb_desc& d, int q, int lane, int pw, u32x4 (&r)[RB_PV]) {
+#ifdef RB_X_NOWLOAD    // probe: only the first RB_RQ slabs are fetched (wrong results, the weight stream removed)
+    if (q >= 8) return;
+#endif
     int k, j, h = 0;
     if (q < 2) { k = 0; j = q; }
     else if (q < 5) { k = 1; j = q - 2; }
@@ -168,6 +171,9 @@ __device__ __forceinline__ void rb_load_slab(const ssr_rdb_desc& d, int q, int l
     }
 }
 __device__ __forceinline__ void rb_store_slab(char* stage, int lane, int pw, const u32x4 (&r)[RB_PV]) {
+#ifdef RB_X_NOWSTORE   // probe: the producers publish without storing (wrong results, LDS write traffic removed)
+    if (r[0].x != 0x7f7f7f7fu) return;
+#endif
 #pragma unroll
     for (int jj = 0; jj < RB_PV; ++jj)
         *reinterpret_cast<u32x4*>(stage + (jj * RB_NPROD + pw) * 1024 + lane * 16) = r[jj];
@@ -208,6 +214,10 @@ template <int K, int S, int NMT> struct RbRdK {             // slab of conv K < 
         const char* sb = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + (DELTA * RB_PITCH + DELTA) * RB_AROW;
 #pragma unroll
         for (int m = 0; m < NMT; ++m) ab[m] = sb + po[m];
+#ifdef RB_X_LINA   // probe: pixel fragments from consecutive rows (wrong results; the address pattern of tools/mfma_probe.hip)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) ab[m] = smem + rb_slice_base(S) + plane * RB_X0P + g * 16 + (i + 32 * m) * RB_AROW;
+#endif
         const int bsw = (i >> 2) & 3;
         bb0 = slab + i * RB_WROW + ((g ^ bsw) << 4);
         bb1 = slab + i * RB_WROW + (((g ^ bsw) ^ 2) << 4);   // second 16-channel k-substep

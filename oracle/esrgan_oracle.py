@@ -33,6 +33,92 @@ LRELU_SLOPE = 0.2  # ssr/archs/rrdbnet_arch.py:32, discriminator_arch.py:44
 
 
 # ----------------------------------------------------------------------------
+# Precision model.  The reference computes in fp32 (`Prec()` = identity: the restatement proper).
+# `BF16` models the throughput mode of the HIP path (BASELINE.json configs[1] "bf16"): the SAME
+# algorithm with every tensor the device keeps in HBM rounded to bfloat16 at the point where it is
+# stored (conv outputs after their fused epilogue, interpolation outputs, network inputs, the logits
+# and the gradients flowing back through those same buffers), weights rounded where they are packed
+# for the matrix core, and everything in between (accumulation, bias, LeakyReLU, residual sums,
+# losses, spectral norm, Adam, EMA, master weights) in fp32.  It exists so that the bf16 kernels are
+# held to the rounding they are entitled to (1 bf16 ulp per stored value) instead of a loose
+# end-to-end tolerance against the fp32 result.
+# ----------------------------------------------------------------------------
+class _RoundBoth(torch.autograd.Function):
+    """x -> bf16(x) going forward, g -> bf16(g) going back: a tensor AND its gradient live in bf16 buffers."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """packed weights: rounded for the matrix core, gradient (an fp32 wgrad into the fp32 arena) untouched."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity forward, bf16 gradient: a gradient buffer without a forward twin (the L1 gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class Prec:
+    """fp32: all three hooks are the identity."""
+    name = "fp32"
+
+    def a(self, x):      # an activation stored in HBM (and its gradient)
+        return x
+
+    def w(self, x):      # a weight tensor as the matrix core sees it
+        return x
+
+    def g(self, x):      # a gradient-only buffer
+        return x
+
+    def act(self, pre):  # LeakyReLU output stored in HBM; its gradient buffer holds the PRE-activation gradient
+        return F.leaky_relu(pre, LRELU_SLOPE)
+
+
+class _PrecBF16(Prec):
+    name = "bf16"
+
+    def a(self, x):
+        return _RoundBoth.apply(x)
+
+    def w(self, x):
+        return _RoundFwd.apply(x)
+
+    def g(self, x):
+        return _RoundBwd.apply(x)
+
+    def act(self, pre):
+        # forward: round(lrelu(acc)) in the producer's epilogue; backward: the consumer-side epilogue applies the
+        # LeakyReLU mask to the fp32 gradient sum and THEN rounds (the buffers hold pre-activation gradients)
+        return _RoundFwd.apply(F.leaky_relu(_RoundBwd.apply(pre), LRELU_SLOPE))
+
+
+FP32 = Prec()
+BF16 = _PrecBF16()
+
+
+# ----------------------------------------------------------------------------
 # integer index maps (bit-exact gate)
 # ----------------------------------------------------------------------------
 def pixel_unshuffle_index(c: int, hh: int, hw: int, s: int):
@@ -78,29 +164,31 @@ def quantize_u8_truncate(x: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 # Generator: SSR_RRDBNet (ssr/archs/rrdbnet_arch.py)
 # ----------------------------------------------------------------------------
-def _conv(sd, name, x, stride=1, pad=1):
-    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=pad)
+def _conv(sd, name, x, stride=1, pad=1, prec: Prec = FP32):
+    return F.conv2d(x, prec.w(sd[name + ".weight"]), sd.get(name + ".bias"), stride=stride, padding=pad)
 
 
 def _lrelu(x):
     return F.leaky_relu(x, LRELU_SLOPE)
 
 
-def rdb_forward(sd, pfx: str, x: torch.Tensor) -> torch.Tensor:
-    """ResidualDenseBlock.forward, rrdbnet_arch.py:37-44."""
+def rdb_forward(sd, pfx: str, x: torch.Tensor, prec: Prec = FP32, store: bool = True) -> torch.Tensor:
+    """ResidualDenseBlock.forward, rrdbnet_arch.py:37-44.  `store=False`: the caller folds the result into a
+    larger fused epilogue and rounds there (third RDB of an RRDB)."""
     feats = [x]
     for k in range(1, 5):
-        feats.append(_lrelu(_conv(sd, f"{pfx}.conv{k}", torch.cat(feats, 1))))
-    x5 = _conv(sd, f"{pfx}.conv5", torch.cat(feats, 1))
-    return x5 * 0.2 + x
+        feats.append(prec.act(_conv(sd, f"{pfx}.conv{k}", torch.cat(feats, 1), prec=prec)))
+    x5 = _conv(sd, f"{pfx}.conv5", torch.cat(feats, 1), prec=prec)
+    out = x5 * 0.2 + x
+    return prec.a(out) if store else out
 
 
-def rrdb_forward(sd, pfx: str, x: torch.Tensor) -> torch.Tensor:
-    """RRDB.forward, rrdbnet_arch.py:63-68."""
+def rrdb_forward(sd, pfx: str, x: torch.Tensor, prec: Prec = FP32) -> torch.Tensor:
+    """RRDB.forward, rrdbnet_arch.py:63-68.  (bf16 model: `(x5*0.2 + x)*0.2 + x_rrdb` is ONE epilogue, one rounding.)"""
     out = x
     for j in (1, 2, 3):
-        out = rdb_forward(sd, f"{pfx}.rdb{j}", out)
-    return out * 0.2 + x
+        out = rdb_forward(sd, f"{pfx}.rdb{j}", out, prec, store=(j < 3))
+    return prec.a(out * 0.2 + x)
 
 
 def generator_num_blocks(sd) -> int:
@@ -110,26 +198,29 @@ def generator_num_blocks(sd) -> int:
     return n
 
 
-def generator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, scale: int = 4) -> torch.Tensor:
+def generator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, scale: int = 4, prec: Prec = FP32) -> torch.Tensor:
     """SSR_RRDBNet.forward, rrdbnet_arch.py:116-137.  `sd` uses the reference's key layout."""
+    a = prec.a
+    x = a(x)
     if scale == 2:
         feat = pixel_unshuffle(x, 2)
     elif scale == 1:
         feat = pixel_unshuffle(x, 4)
     else:
         feat = x
-    feat = _conv(sd, "conv_first", feat)
+    feat = a(_conv(sd, "conv_first", feat, prec=prec))
     body = feat
     for i in range(generator_num_blocks(sd)):
-        body = rrdb_forward(sd, f"body.{i}", body)
-    feat = feat + _conv(sd, "conv_body", body)
-    feat = _lrelu(_conv(sd, "conv_up1", F.interpolate(feat, scale_factor=2, mode="nearest")))
-    feat = _lrelu(_conv(sd, "conv_up2", F.interpolate(feat, scale_factor=2, mode="nearest")))
+        body = rrdb_forward(sd, f"body.{i}", body, prec)
+    feat = a(feat + _conv(sd, "conv_body", body, prec=prec))
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")   # folded into the consumer's read: never stored
+    feat = prec.act(_conv(sd, "conv_up1", up(feat), prec=prec))
+    feat = prec.act(_conv(sd, "conv_up2", up(feat), prec=prec))
     if scale in (8, 16):
-        feat = _lrelu(_conv(sd, "conv_up3", F.interpolate(feat, scale_factor=2, mode="nearest")))
+        feat = prec.act(_conv(sd, "conv_up3", up(feat), prec=prec))
         if scale == 16:
-            feat = _lrelu(_conv(sd, "conv_up4", F.interpolate(feat, scale_factor=2, mode="nearest")))
-    return _conv(sd, "conv_last", _lrelu(_conv(sd, "conv_hr", feat)))
+            feat = prec.act(_conv(sd, "conv_up4", up(feat), prec=prec))
+    return a(_conv(sd, "conv_last", prec.act(_conv(sd, "conv_hr", feat, prec=prec)), prec=prec))
 
 
 def generator_init(num_in_ch, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32,
@@ -198,7 +289,7 @@ def spectral_norm_weight(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
 
 
 def discriminator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, train: bool = True,
-                          skip_connection: bool = True, update_buffers: bool = True) -> torch.Tensor:
+                          skip_connection: bool = True, update_buffers: bool = True, prec: Prec = FP32) -> torch.Tensor:
     """SSR_UNetDiscriminatorSN.forward, discriminator_arch.py:42-71.
     `sd` holds conv0/conv9 .weight/.bias and conv1..8 .weight_orig/.weight_u/.weight_v.
     When `train` and `update_buffers`, the u/v entries of `sd` are replaced by the updated vectors
@@ -209,30 +300,34 @@ def discriminator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, train: b
                                           sd[name + ".weight_v"], train)
         if train and update_buffers:
             sd[name + ".weight_u"], sd[name + ".weight_v"] = u, v
-        w[name] = w_sn
+        w[name] = prec.w(w_sn)     # W/sigma is formed in fp32 and rounded when it is packed
+
+    a = prec.a
 
     def sn(name, t, stride, pad):
         return F.conv2d(t, w[name], None, stride=stride, padding=pad)
 
-    x0 = _lrelu(F.conv2d(x, sd["conv0.weight"], sd["conv0.bias"], padding=1))
-    x1 = _lrelu(sn("conv1", x0, 2, 1))
-    x2 = _lrelu(sn("conv2", x1, 2, 1))
-    x3 = _lrelu(sn("conv3", x2, 2, 1))
-    x3 = F.interpolate(x3, scale_factor=2, mode="bilinear", align_corners=False)
-    x4 = _lrelu(sn("conv4", x3, 1, 1))
+    bil = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+    x0 = prec.act(F.conv2d(a(x), prec.w(sd["conv0.weight"]), sd["conv0.bias"], padding=1))
+    x1 = prec.act(sn("conv1", x0, 2, 1))
+    x2 = prec.act(sn("conv2", x1, 2, 1))
+    x3 = prec.act(sn("conv3", x2, 2, 1))
+    x3 = a(bil(x3))
+    x4 = prec.act(sn("conv4", x3, 1, 1))
     if skip_connection:
-        x4 = x4 + x2
-    x4 = F.interpolate(x4, scale_factor=2, mode="bilinear", align_corners=False)
-    x5 = _lrelu(sn("conv5", x4, 1, 1))
+        x4 = x4 + prec.g(x2)    # the sum is formed inside the interpolation's read (bf16 model: not stored; the skip
+    x4 = a(bil(x4))             # branch's gradient is a buffer of its own)
+    x5 = prec.act(sn("conv5", x4, 1, 1))
     if skip_connection:
-        x5 = x5 + x1
-    x5 = F.interpolate(x5, scale_factor=2, mode="bilinear", align_corners=False)
-    x6 = _lrelu(sn("conv6", x5, 1, 1))
-    if skip_connection:
-        x6 = x6 + x0
-    out = _lrelu(sn("conv7", x6, 1, 1))
-    out = _lrelu(sn("conv8", out, 1, 1))
-    return F.conv2d(out, sd["conv9.weight"], sd["conv9.bias"], padding=1)
+        x5 = x5 + prec.g(x1)
+    x5 = a(bil(x5))
+    if skip_connection:         # conv6's epilogue stores lrelu(acc) + x0 with ONE rounding
+        x6 = prec.w(_lrelu(prec.g(sn("conv6", x5, 1, 1))) + prec.g(x0))
+    else:
+        x6 = prec.act(sn("conv6", x5, 1, 1))
+    out = prec.act(sn("conv7", x6, 1, 1))
+    out = prec.act(sn("conv8", out, 1, 1))
+    return a(F.conv2d(out, prec.w(sd["conv9.weight"]), sd["conv9.bias"], padding=1))
 
 
 def discriminator_init(num_in_ch, num_feat=64, seed: Optional[int] = None):
@@ -367,6 +462,9 @@ class StepConfig:
     net_d_init_iters: int = 0
     feed_disc_lr: bool = False
     scale: int = 4
+    l1_gt_usm: bool = False        # ssr_esrgan_model.py:121-129 (the measured configuration uses the plain gt)
+    gan_gt_usm: bool = False
+    prec: Prec = FP32              # FP32 = the reference's arithmetic; BF16 = model of the HIP throughput mode
 
 
 class ESRGANOracle:
@@ -385,21 +483,35 @@ class ESRGANOracle:
         self.log = OrderedDict()
         self.output = None
 
-    def _disc_input(self, img, lr_resized):
-        # ssr_esrgan_model.py:171-178 / :202-213 (old_hr not part of the measured configs)
-        return torch.cat((img, lr_resized), 1) if self.cfg.feed_disc_lr else img
+    def _disc_input(self, img, lr_resized, old_hr=None):
+        # ssr_esrgan_model.py:171-178 / :202-213: [img | lr_resized (feed_disc_lr) | old_hr (when the batch has one)]
+        parts = [img]
+        if self.cfg.feed_disc_lr:
+            parts.append(lr_resized)
+        if old_hr is not None:
+            parts.append(old_hr)
+        return torch.cat(parts, 1) if len(parts) > 1 else img
 
-    def step(self, lr: torch.Tensor, gt: torch.Tensor, current_iter: int = 1):
+    def step(self, lr: torch.Tensor, gt: torch.Tensor, current_iter: int = 1, old_hr: Optional[torch.Tensor] = None):
         cfg = self.cfg
+        prec = cfg.prec
         log = OrderedDict()
+        with torch.no_grad():
+            lr = prec.a(lr)
+            gt_usm = usm_sharp(gt) if (cfg.l1_gt_usm or cfg.gan_gt_usm) else None   # :109
+            l1_gt = prec.a(gt_usm if cfg.l1_gt_usm else gt)                          # :121-129
+            gan_gt = prec.a(gt_usm if cfg.gan_gt_usm else gt)
+            old_hr = prec.a(old_hr) if old_hr is not None else None
+            gt = gan_gt
         lr_resized = F.interpolate(lr, scale_factor=4)  # :133 (nearest)
         # ---- optimize net_g (:136-193); D params frozen -> D contributes dgrad only
         gp = OrderedDict((k, v.detach().requires_grad_(True)) for k, v in self.g.items())
         d_frozen = OrderedDict((k, v.detach()) for k, v in self.d.items())
-        output = generator_forward(gp, lr, cfg.scale)
+        output = generator_forward(gp, lr, cfg.scale, prec)
         if current_iter % cfg.net_d_iters == 0 and current_iter > cfg.net_d_init_iters:
-            l_g_pix = l1_loss(output, gt, cfg.l1_weight)
-            fake_g_pred = discriminator_forward(d_frozen, self._disc_input(output, lr_resized), train=True)
+            l_g_pix = l1_loss(prec.g(output), l1_gt, cfg.l1_weight)
+            fake_g_pred = discriminator_forward(d_frozen, self._disc_input(output, lr_resized, old_hr), train=True,
+                                                prec=prec)
             l_g_gan = gan_loss_vanilla(fake_g_pred, True, is_disc=False, loss_weight=cfg.gan_weight)
             l_g_total = l_g_pix + l_g_gan
             grads = torch.autograd.grad(l_g_total, list(gp.values()))
@@ -415,11 +527,12 @@ class ESRGANOracle:
         # ---- optimize net_d (:196-228): two backward() calls accumulate into the same .grad
         dp = OrderedDict((k, (v.detach().requires_grad_(True) if k in D_PARAM_KEYS else v.detach()))
                          for k, v in self.d.items())
-        real_d_pred = discriminator_forward(dp, self._disc_input(gt, lr_resized), train=True)
+        real_d_pred = discriminator_forward(dp, self._disc_input(gt, lr_resized, old_hr), train=True, prec=prec)
         l_d_real = gan_loss_vanilla(real_d_pred, True, is_disc=True)
         plist = [dp[k] for k in D_PARAM_KEYS]
         g_real = torch.autograd.grad(l_d_real, plist)
-        fake_d_pred = discriminator_forward(dp, self._disc_input(output, lr_resized).detach().clone(), train=True)
+        fake_d_pred = discriminator_forward(dp, self._disc_input(output, lr_resized, old_hr).detach().clone(), train=True,
+                                            prec=prec)
         l_d_fake = gan_loss_vanilla(fake_d_pred, False, is_disc=True)
         g_fake = torch.autograd.grad(l_d_fake, plist)
         self.d_grads = OrderedDict((k, a + b) for k, a, b in zip(D_PARAM_KEYS, g_real, g_fake))

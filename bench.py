@@ -50,8 +50,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed oracle steps after one warm-up (~8 s of CPU work at the default)")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="oracle threads (PyTorch CPU does not scale past ~16 on this network at batch 2)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads; 0 = every host core (stated in the record)")
+    ap.add_argument("--blocks-timed", type=int, default=5, help="extra timed blocks of --steps steps (median reported beside the contract's single region)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32-storage / split-bf16 parity-mode leg")
+    ap.add_argument("--parity-steps", type=int, default=6)
     return ap.parse_args()
 
 
@@ -161,7 +163,8 @@ def wgrad_flops(ts):
 def cpu_baseline(args, c_in, c_d):
     from oracle import esrgan_oracle as O
     torch.manual_seed(0)
-    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores if args.cpu_threads <= 0 else max(1, min(args.cpu_threads, ncores)))
     B = args.cpu_batch
     g0 = O.generator_init(num_in_ch=c_in, num_block=args.blocks, seed=0)
     d0 = O.discriminator_init(c_d, 64, seed=1)
@@ -183,9 +186,10 @@ def cpu_baseline(args, c_in, c_d):
                     break
     except OSError:
         pass
-    return {"value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": ncores, "kind": "port",
             "sample": f"{args.cpu_steps} timed G+D steps (median) at batch {B}, fp32, same architecture/shapes, "
-                      f"after 1 warm-up; host CPU: {cpu}; oracle/esrgan_oracle.py (PyTorch CPU restatement)"}
+                      f"after 1 warm-up, torch.set_num_threads({torch.get_num_threads()}) of {ncores} host cores; host CPU: {cpu}; "
+                      f"oracle/esrgan_oracle.py (PyTorch CPU restatement; the reference itself is not on this box)"}
 
 
 def main():
@@ -227,6 +231,21 @@ def main():
     if ctx.active:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    # beside the contract's single timed region: further blocks of the same K steps, median reported (boxes differ by a few %
+    # and a 0.3 s region sees clock ramps)
+    blocks = []
+    for _ in range(max(0, args.blocks_timed)):
+        ctx.barrier()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            ts.step()
+        torch.cuda.synchronize()
+        ctx.barrier()
+        tb = torch.tensor([time.perf_counter() - tb], device="cuda", dtype=torch.float64)
+        if ctx.active:
+            torch.distributed.all_reduce(tb, op=torch.distributed.ReduceOp.MAX)
+        blocks.append(1e3 * float(tb.item()) / args.steps)
     log = ts.log()
     finite = all(v == v and abs(v) < 1e30 for v in log.values())
 
@@ -247,6 +266,8 @@ def main():
         "step_tflops": value * gflop_img / 1e3,
         "frac_of_mfma_peak_whole_step": value * gflop_img / 1e3 / (PEAK_TFLOPS[args.dtype] * ctx.world),
         "losses_finite": finite,
+        "ms_per_step_blocks": [round(b, 4) for b in blocks],
+        "ms_per_step_median_of_blocks": (sorted(blocks)[len(blocks) // 2] if blocks else None),
     }
     # the instrumented step contains the gradient exchanges: every rank runs it (collectives must match), rank 0 reports
     agg = instrumented_step(ts, args) if not args.no_roofline else None
@@ -254,18 +275,33 @@ def main():
         conv = {k: v for k, v in agg.items() if v[2] > 0}      # MFMA kernels (algorithmic FLOPs known)
         dom = max(conv, key=lambda k: conv[k][1])
         n, secs, fl = conv[dom]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc
+        # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py).  Counters cannot be collected from inside
+        # this process, so the number is only reported when profiles/traffic.json was collected on THIS build of the library
+        # (source hash) at THIS configuration; otherwise null, with a pointer to the dated file.
+        traffic, traffic_note = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                detail = json.load(open(tp)).get(dom)
-                traffic = detail["bytes_per_launch"] if isinstance(detail, dict) else detail
-            except Exception:
-                traffic = None
+                from satlas_super_resolution_amd import build as bld
+                tj = json.load(open(tp))
+                meta = tj.get("_meta", {})
+                same = (meta.get("source_hash") == bld.source_hash() and meta.get("batch") == B and meta.get("frames") == args.frames
+                        and meta.get("dtype") == args.dtype)
+                detail = tj.get(dom)
+                if same and isinstance(detail, dict):
+                    traffic = detail["bytes_per_launch"]
+                else:
+                    traffic_note = (f"profiles/traffic.json holds PMC traffic for build {str(meta.get('source_hash'))[:12]} at "
+                                    f"batch {meta.get('batch')}, frames {meta.get('frames')}, {meta.get('dtype')} "
+                                    f"({meta.get('collected', 'undated')}): not this build/config, so not reported as this run's")
+            except Exception as e:   # noqa: BLE001
+                traffic_note = f"profiles/traffic.json unreadable: {e}"
         out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": n,
                            "avg_launch_us": 1e6 * secs / n, "flops_per_launch": fl / n,
                            "achieved": fl / secs / 1e12, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": fl / secs / 1e12 / PEAK_TFLOPS[args.dtype], "traffic": traffic}
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
         out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in
                                            sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:

@@ -287,6 +287,21 @@ int ssr_adam_step(const ssr_adam_args* a, void* stream);
 /* y = a*x + b*y over n fp32 elements (grad averaging / accumulation helpers) */
 int ssr_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
 
+/* ---- image quantisation and validation metrics (csrc/metrics.hip) ----
+ * ssr_quantize_u8: fp32 NCHW -> uint8 NHWC, clamp(0,1) * 255 then mode 0: round half to even (basicsr tensor2img as called at
+ *   /root/reference/ssr/models/ssr_esrgan_model.py:302-305), mode 1: truncate (astype(uint8) at /root/reference/ssr/infer_grid.py:60-64,
+ *   infer.py:58-60).
+ * ssr_metric_shift_sums: a, b uint8 [H][W][C], C <= 4.  For every offset pair (ro, co) in [0, max_offset]^2 and channel c writes
+ *   out[((ro*(max_offset+1) + co)*C + c)*2 + {0,1}] = sum d, sum d^2 (exact, int64) over the window of
+ *   (H-2*crop-max_offset) x (W-2*crop-max_offset) pixels, d = a[y+crop+ro][x+crop+co][c] - b[y+crop+max_offset-ro][x+crop+max_offset-co][c]:
+ *   max_offset 0 -> PSNR (basicsr calculate_psnr), 8 -> cPSNR (/root/reference/ssr/metrics/cpsnr.py:36-55).
+ * ssr_metric_ssim_sums: out[c] = sum over the valid region of the SSIM map of channel c (11x11 Gaussian window, sigma 1.5, fp64;
+ *   basicsr calculate_ssim); the caller divides by (H-2*crop-10)*(W-2*crop-10). */
+int ssr_quantize_u8(const float* src_nchw, uint8_t* dst_nhwc, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode, void* stream);
+int ssr_metric_shift_sums(const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, int32_t C, int32_t crop, int32_t max_offset,
+                          int64_t* out, void* stream);
+int ssr_metric_ssim_sums(const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, int32_t C, int32_t crop, double* out, void* stream);
+
 /* library / device info: writes "gfx950 CUs=256 ..." style text */
 int ssr_device_info(char* buf, int32_t buflen);
 int ssr_abi_version(void);

@@ -62,6 +62,7 @@ class HipNet(nn.Module):
             attach(self, s.name, ConvParams(s, "rdb" if s.name.startswith(rdb_prefix) else "default"))
         self._store = None
         self._plans: Dict[Tuple, object] = {}
+        self._packed_version = None
 
     # ---- flat-arena storage ----
     def _leaf(self, name: str) -> nn.Module:
@@ -98,7 +99,22 @@ class HipNet(nn.Module):
                     leaf.weight_v = st.v[s.name]
         self._store = st
         self._plans.clear()
+        self._packed_version = None
         return st
+
+    def pack_if_stale(self):
+        """The kernels read packed compute-dtype copies of the weights.  Re-pack only when a parameter changed since the last
+        packing: every in-place update through the Parameter objects (optimizer steps, load_state_dict, .copy_) bumps the
+        tensor's version counter.  Under no_grad inference (infer.py / infer_grid.py call the module once per chunk) the 351
+        weight tensors are packed once, not per forward.  Code that writes through `.data` must call mark_weights_dirty()."""
+        st = self.store()
+        ver = sum(p._version for p in self.parameters())
+        if ver != self._packed_version:
+            st.pack()
+            self._packed_version = ver
+
+    def mark_weights_dirty(self):
+        self._packed_version = None
 
     def grads_from_arena(self, needs: List[bool]):
         st = self._store

@@ -20,7 +20,7 @@ class _GeneratorFn(torch.autograd.Function):
         st = net.store()
         B, _, H, W = x.shape
         plan = net.plan(B, H, W, training=need)
-        st.pack()
+        net.pack_if_stale()
         plan.load_input(x.detach().contiguous().float())
         plan.fwd.run()
         plan.generation = getattr(plan, "generation", 0) + 1

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv.hip", "conv_res.hip", "conv_ws.hip", "conv_big.hip", "conv_thin.hip", "rdb_fwd.hip", "wgrad.hip", "wgrad_bf16.hip", "misc.hip"]
+SOURCES = ["conv.hip", "conv_res.hip", "conv_ws.hip", "conv_big.hip", "conv_thin.hip", "rdb_fwd.hip", "wgrad.hip", "wgrad_bf16.hip", "misc.hip", "metrics.hip"]
 OUT = os.path.join(HERE, "libssr_hip.so")
 
 
@@ -17,13 +17,30 @@ def hipcc() -> str:
     return "hipcc"
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+STAMP = OUT + ".srchash"     # sha256 of every source, header and flag the library was built from (travels with the .so)
+
+
+def source_hash() -> str:
+    """Content hash of the inputs of the build: a stale prebuilt library (older sources, other flags) is rebuilt whatever
+    the file times say, and `build()` re-using a library means it was built from exactly these sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+           [os.path.join(ROOT, "include", "ssr_hip.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "wgrad_common.h"), os.path.join(CSRC, "conv_epilogue.h"),
-                                                       os.path.join(ROOT, "include", "ssr_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -34,14 +51,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-I" + os.path.join(ROOT, "include")]
+    flags = FLAGS + ["-I" + os.path.join(ROOT, "include")]
+    stamp = source_hash()
+
+    import glob
+    import hashlib
+    hdr = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "ssr_hip.h")]:
+        with open(d, "rb") as f:
+            hdr.update(f.read())
 
     def compile_one(src: str) -> str:
+        """One object per source; an object is reused only if its source, every header and the flags are unchanged."""
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        h = hdr.copy()
+        with open(os.path.join(CSRC, src), "rb") as f:
+            h.update(f.read())
+        tag = obj + ".srchash"
+        if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read().strip() == h.hexdigest():
+            return obj
         cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+        with open(tag, "w") as f:
+            f.write(h.hexdigest() + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
@@ -50,6 +84,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(stamp + "\n")
     return OUT
 
 

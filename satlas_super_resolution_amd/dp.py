@@ -27,7 +27,11 @@ def init_distributed(backend: Optional[str] = None) -> "DPContext":
     """One process per GPU, env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), mirroring
     basicsr.utils.dist_util.init_dist('pytorch') as called from /root/reference/ssr/utils/options.py:65-74."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    # SSR_DP_FORCE=1: run the data-parallel branch (phase graphs, side-stream exchanges over the real backend) even with
+    # one rank.  An all-reduce over one rank is the identity, so the result equals the single-process step; this is how the
+    # RCCL code path is exercised on a one-GPU box (tests/test_dp_gpu.py).
+    force = os.environ.get("SSR_DP_FORCE", "0") == "1" and "RANK" in os.environ
+    if world <= 1 and not force:
         return DPContext(None, 0, 1)
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
@@ -37,19 +41,20 @@ def init_distributed(backend: Optional[str] = None) -> "DPContext":
         torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return DPContext(dist.group.WORLD, rank, world)
+    return DPContext(dist.group.WORLD, rank, world, force=force)
 
 
 class DPContext:
-    def __init__(self, group, rank: int, world: int, chunk_bytes: int = 32 << 20):
+    def __init__(self, group, rank: int, world: int, chunk_bytes: int = 32 << 20, force: bool = False):
         self.group, self.rank, self.world = group, rank, world
+        self.force = force
         self.chunk_elems = max(1, chunk_bytes // 4)
         self._comm_stream = None
         self._pending: List = []
 
     @property
     def active(self) -> bool:
-        return self.world > 1
+        return self.world > 1 or self.force
 
     @property
     def grad_scale(self) -> float:

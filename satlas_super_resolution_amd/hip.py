@@ -107,6 +107,7 @@ ABI_SYMBOLS = [
     "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
+    "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums",
     "ssr_device_info", "ssr_abi_version",
 ]
 
@@ -155,6 +156,9 @@ def lib() -> C.CDLL:
     l.ssr_bce_logits_loss.argtypes = [View, View, i32, i64, f32, f32, vp, vp, vp]
     l.ssr_adam_step.argtypes = [C.POINTER(AdamArgs), vp]
     l.ssr_axpby_f32.argtypes = [f32, vp, f32, vp, i64, vp]
+    l.ssr_quantize_u8.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    l.ssr_metric_shift_sums.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    l.ssr_metric_ssim_sums.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     l.ssr_device_info.argtypes = [C.c_char_p, i32]
     l.ssr_abi_version.argtypes = []
     for s in ABI_SYMBOLS:

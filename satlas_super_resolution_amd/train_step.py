@@ -26,13 +26,17 @@ class StepConfig:
     lr_g: float = 1e-4             # optim_g                         (:98-102)
     lr_d: float = 1e-4             # optim_d                         (:103-107)
     betas: Tuple[float, float] = (0.9, 0.99)
+    betas_d: Optional[Tuple[float, float]] = None   # optim_d.betas (None: same as optim_g's)
     eps: float = 1e-8
     ema_decay: float = 0.999       # train.ema_decay                 (:97)
     net_d_iters: int = 1           # (:146)
     net_d_init_iters: int = 0      # (:147)
     feed_disc_lr: bool = False     # top-level feed_disc_lr          (:14)
+    old_hr: bool = False           # batches carry 'old_hr' (an older high-res image of the same place) for D (ssr_esrgan_model.py:112-114)
     l1_gt_usm: bool = False        # L1 target = USM-sharpened gt    (ssr_esrgan_model.py:121-125; yml :9)
     gan_gt_usm: bool = False       # D real input = USM-sharpened gt (:127-129; yml :11)
+    percep_gt_usm: bool = False    # perceptual target = USM-sharpened gt (:125-126; yml :10)
+    perceptual: Optional[Dict] = None   # train.perceptual_opt (VGG19 feature L1, :153-160; yml :123-137)
     real_label: float = 1.0
     fake_label: float = 0.0
 
@@ -71,6 +75,8 @@ class ESRGANTrainStep:
                  cfg: StepConfig = StepConfig(), dp: Optional[DPContext] = None, use_graph: bool = True,
                  g_store: Optional[engine.ParamStore] = None, d_store: Optional[engine.ParamStore] = None):
         assert g_kwargs.get("scale", 4) == 4, "the train step is defined for scale 4 (all shipped configs)"
+        if cfg.perceptual:
+            raise NotImplementedError("train.perceptual_opt (VGG19 perceptual loss): not built yet (SURVEY.md §8f rank 2)")
         self.cfg, self.B, self.h, self.w = cfg, B, h, w
         self.dt = hip.dtype_code(dtype)
         self.dp = dp if dp is not None else DPContext(None, 0, 1)
@@ -78,8 +84,8 @@ class ESRGANTrainStep:
         self.g_kwargs, self.d_kwargs = dict(g_kwargs), dict(d_kwargs)
         cin, cout = g_kwargs["num_in_ch"], g_kwargs.get("num_out_ch", 3)
         cd = d_kwargs["num_in_ch"]
-        assert cd == cout + (cin if cfg.feed_disc_lr else 0), \
-            f"network_d.num_in_ch={cd} must be {cout} (+{cin} with feed_disc_lr): ssr_esrgan_model.py:171-178"
+        assert cd == cout + (cin if cfg.feed_disc_lr else 0) + (cout if cfg.old_hr else 0), \
+            f"network_d.num_in_ch={cd} must be {cout} (+{cin} with feed_disc_lr, +{cout} with old_hr): ssr_esrgan_model.py:171-178"
         self.cin, self.cout, self.cd = cin, cout, cd
         self.g_store = g_store or engine.ParamStore(engine.generator_specs(**g_kwargs), self.dt)
         self.d_store = d_store or engine.ParamStore(
@@ -89,8 +95,8 @@ class ESRGANTrainStep:
         self.H, self.W = H, W
         cdp = engine.rup(cd, 8)
         z = lambda *s: torch.zeros(*s, dtype=tdt, device=dev)
-        self.fake_in = z(B, H, W, cdp)      # [G output | lr_resized]   (ssr_esrgan_model.py:171-178)
-        self.real_in = z(B, H, W, cdp)      # [gt       | lr_resized]   (:202-213)
+        self.fake_in = z(B, H, W, cdp)      # [G output | lr_resized | old_hr]   (ssr_esrgan_model.py:171-178)
+        self.real_in = z(B, H, W, cdp)      # [gt       | lr_resized | old_hr]   (:202-213)
         self.grad_l1 = z(B, H, W, cdp)
         # L1 target: the D-real buffer unless exactly one of the two is USM-sharpened (ssr_esrgan_model.py:121-129)
         self.l1_tgt = self.real_in if cfg.l1_gt_usm == cfg.gan_gt_usm else z(B, H, W, cdp)
@@ -102,9 +108,9 @@ class ESRGANTrainStep:
         self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in,
                                            d_out_buf=self.d_plan.g_in, **g_kwargs)
         self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
-        self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
+        self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas_d or cfg.betas, cfg.eps, 0.0)
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
-        self._warm = False
+        self._warm = set()
         self.iter = 0
 
     # ------------------------------------------------------------------ state
@@ -120,17 +126,21 @@ class ESRGANTrainStep:
             out[key] = self.g_store.tensor(key, self.opt_g.ema).clone()
         return out
 
-    def sync_params_from_rank0(self):
+    def sync_params_from_rank0(self, reset_ema: bool = True):
         """DDP constructor semantics."""
         for t in (self.g_store.data, self.d_store.data, *self.d_store.u.values(), *self.d_store.v.values()):
             self.dp.broadcast_(t)
         if self.opt_g.ema is not None:
-            self.opt_g.ema.copy_(self.g_store.data)
+            if reset_ema:
+                self.opt_g.ema.copy_(self.g_store.data)
+            else:
+                self.dp.broadcast_(self.opt_g.ema)
 
     # ------------------------------------------------------------------ data
-    def feed_data(self, lr: torch.Tensor, gt: torch.Tensor, scale: float = 1.0):
-        """lr: [B,Cin,h,w], gt: [B,3,4h,4w] float32 NCHW on the GPU (`scale` = 1/255 for uint8-valued
-        inputs: ssr_esrgan_model.py:106-108)."""
+    def feed_data(self, lr: torch.Tensor, gt: torch.Tensor, scale: float = 1.0, old_hr: Optional[torch.Tensor] = None):
+        """lr: [B,Cin,h,w], gt (and old_hr): [B,3,4h,4w] float32 NCHW on the GPU (`scale` = 1/255 for uint8-valued
+        inputs: ssr_esrgan_model.py:106-108,112-114)."""
+        assert (old_hr is not None) == self.cfg.old_hr, "old_hr must be fed iff StepConfig.old_hr (the D input width is static)"
         L = hip.lib()
         st = hip.stream_ptr()
         lr = lr.contiguous()
@@ -155,6 +165,12 @@ class ESRGANTrainStep:
                 hip.check(L.ssr_nchw_to_nhwc(lr.data_ptr(), self.B, self.cin, self.h, self.w,
                                              hip.View(buf.data_ptr(), buf.shape[-1], self.cout), self.dt, 1, 4, scale,
                                              st), "lr_resized")
+        if old_hr is not None:      # torch.cat((.., self.old_hr), dim=1): the last 3 channels of both D inputs  (:171-175,:202-207)
+            old_hr = old_hr.contiguous()
+            coff = self.cout + (self.cin if self.cfg.feed_disc_lr else 0)
+            for buf in (self.real_in, self.fake_in):
+                hip.check(L.ssr_nchw_to_nhwc(old_hr.data_ptr(), self.B, self.cout, self.H, self.W,
+                                             hip.View(buf.data_ptr(), buf.shape[-1], coff), self.dt, 1, 1, scale, st), "old_hr")
 
     # ------------------------------------------------------------------ phases
     def _bce(self, target, weight, loss_idx, mean_idx, with_grad=True):
@@ -210,6 +226,15 @@ class ESRGANTrainStep:
     def _phase_opt_d(self):
         self.opt_d.update(self.dp.grad_scale)                              # :228
 
+    def _phase_ema_only(self):
+        """model_ema runs on EVERY iteration (:230-231), also when the gate at :144 kept G's optimizer from stepping (then
+        the fused Adam+EMA launch does not run): ema = ema*decay + p*(1-decay)."""
+        o = self.opt_g
+        if o.ema is not None:
+            dec = self.cfg.ema_decay
+            hip.check(hip.lib().ssr_axpby_f32(1.0 - dec, o.store.data.data_ptr(), dec, o.ema.data_ptr(), o.store.numel,
+                                              hip.stream_ptr()), "ssr_axpby_f32 (ema)")
+
     # ------------------------------------------------------------------ driver
     def _run(self, name, fn):
         if not self.use_graph:
@@ -217,7 +242,8 @@ class ESRGANTrainStep:
             return
         g = self._graphs.get(name)
         if g is None:
-            if not self._warm:     # first touch of every kernel (hipFuncSetAttribute etc.) outside capture
+            if name not in self._warm:     # first touch of every kernel of THIS launch list (hipFuncSetAttribute, lazily
+                self._warm.add(name)       # built backward plans) outside capture; captured on its second use
                 return fn()
             g = torch.cuda.CUDAGraph()
             # thread_local: only this thread's calls are policed during capture.  With RCCL the process group's watchdog
@@ -247,6 +273,8 @@ class ESRGANTrainStep:
             if g_on:
                 self.dp.wait(hg)                                   # G's Adam runs under D's exchange
                 self._run("opt_g", self._phase_opt_g)
+            else:
+                self._run("ema", self._phase_ema_only)
             self.dp.wait(hd)
             self._run("opt_d", self._phase_opt_d)
         else:
@@ -260,8 +288,8 @@ class ESRGANTrainStep:
                 self._phase_g_skipped()
                 self._phase_d()
                 self._phase_opt_d()
+                self._phase_ema_only()
             self._run("step" if g_on else "step_skip", whole if g_on else whole_skip)
-        self._warm = True
 
     # ------------------------------------------------------------------ results
     def log(self) -> "OrderedDict[str, float]":

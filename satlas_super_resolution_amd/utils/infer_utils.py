@@ -15,47 +15,46 @@ import torch
 
 def format_s2naip_data(s2_data, n_s2_images: int, device):
     """infer_utils.py:6-39.  s2_data: uint8 [T*32, 32, 3] (T stacked Sentinel-2 frames of one 32x32 chunk).  Picks
-    n_s2_images frames with `random.sample`, preferring frames without any black ([0,0,0]) pixel, and returns
-    (float tensor [1, n_s2_images*3, 32, 32] in [0,1] on `device`, the first frame as uint8 [32,32,3])."""
-    s2_chunks = np.reshape(s2_data, (-1, 32, 32, 3))
-    s2_image = s2_chunks[0]
-    goods, bads = [], []
-    for i, ts in enumerate(s2_chunks):
-        # `[0, 0, 0] in ts` on an ndarray is (ts == [0,0,0]).any(): true as soon as ANY channel value is 0 (:17)
-        if (ts == np.array([0, 0, 0])).any():
-            bads.append(i)
-        else:
-            goods.append(i)
-    if len(goods) >= n_s2_images:
-        rand_indices = random.sample(goods, n_s2_images)
+    n_s2_images frames with `random.sample`, preferring frames without a zero-valued sample, and returns
+    (float tensor [1, n_s2_images*3, 32, 32] in [0,1] on `device`, the first frame as uint8 [32,32,3]).
+
+    The reference's validity test `[0, 0, 0] in frame` on an ndarray is `(frame == [0, 0, 0]).any()`: a frame is set aside
+    as soon as ANY of its values is 0 (:17).  The `random` module is consumed exactly as the reference does (one
+    `random.sample` over the index list of the same length), so the same seed picks the same frames."""
+    frames = np.reshape(s2_data, (-1, 32, 32, 3))
+    has_zero = (frames == 0).any(axis=(1, 2, 3))
+    clean, dirty = np.flatnonzero(~has_zero).tolist(), np.flatnonzero(has_zero).tolist()
+    if len(clean) >= n_s2_images:
+        chosen = random.sample(clean, n_s2_images)
     else:
-        need = n_s2_images - len(goods)
-        rand_indices = goods + random.sample(bads, need)
-    picked = np.array([s2_chunks[i] for i in rand_indices])
-    chunks = [torch.as_tensor(img).permute(2, 0, 1) for img in picked]
-    s2_tensor = torch.cat(chunks).unsqueeze(0)
-    s2_tensor = s2_tensor.to(device).float() / 255
-    return s2_tensor, s2_image
+        chosen = clean + random.sample(dirty, n_s2_images - len(clean))
+    stack = torch.from_numpy(np.ascontiguousarray(frames[chosen]))                  # [n, 32, 32, 3] uint8
+    s2_tensor = stack.permute(0, 3, 1, 2).reshape(1, n_s2_images * 3, 32, 32)      # frame-major, RGB inside a frame
+    return s2_tensor.to(device).float() / 255, frames[0]
 
 
 def quantize_output(output: torch.Tensor) -> np.ndarray:
-    """infer_grid.py:60-64 / infer.py: clamp(0,1) -> *255 -> astype(uint8) (truncation), NCHW -> [N,H,W,3]."""
-    out = torch.clamp(output, 0, 1).detach().float().cpu().numpy()
+    """infer_grid.py:60-64 / infer.py:58-60: clamp(0,1) -> *255 -> astype(uint8) (truncation), NCHW -> uint8 [N,H,W,C] on
+    the host.  Device tensors are quantised on the device (ssr_quantize_u8, csrc/metrics.hip) and only bytes cross PCIe."""
+    if output.is_cuda:
+        from ..metrics import tensor2img_u8
+        return tensor2img_u8(output.detach(), truncate=True).cpu().numpy()
+    out = torch.clamp(output, 0, 1).detach().float().numpy()
     return np.transpose(out * 255, (0, 2, 3, 1)).astype(np.uint8)
 
 
 def stitch_arrays(chunks: Dict, img_size: int, grid_size: int = 16, sentinel2: bool = False) -> np.ndarray:
-    """The paste loop of infer_utils.stitch (:41-60) on in-memory chunks: chunks[(i, j)] is the uint8 image of grid cell
-    row i, column j ([n*32,32,3] Sentinel-2 stacks contribute their first frame when sentinel2=True)."""
-    chunk_size = int(img_size / grid_size)
-    empty = np.zeros((img_size, img_size, 3))
-    for i in range(grid_size):
-        for j in range(grid_size):
-            load = np.asarray(chunks[(i, j)])
-            if sentinel2:
-                load = np.reshape(load, (-1, 32, 32, 3))[0]
-            empty[i * chunk_size:i * chunk_size + chunk_size, j * chunk_size:j * chunk_size + chunk_size, :] = load
-    return empty.astype(np.uint8)
+    """infer_utils.stitch (:41-60) on in-memory chunks: cell (i, j) lands at rows i*cs.., columns j*cs.. with
+    cs = int(img_size / grid_size); [n*32,32,3] Sentinel-2 stacks contribute their first frame when sentinel2=True.
+    One gather + one transpose instead of 256 slice assignments."""
+    cs = int(img_size / grid_size)
+    first = (lambda a: np.reshape(a, (-1, 32, 32, 3))[0]) if sentinel2 else (lambda a: a)
+    tiles = np.stack([first(np.asarray(chunks[(i, j)])) for i in range(grid_size) for j in range(grid_size)])
+    assert tiles.shape[1:] == (cs, cs, 3), (tiles.shape, cs)
+    mosaic = tiles.reshape(grid_size, grid_size, cs, cs, 3).transpose(0, 2, 1, 3, 4).reshape(grid_size * cs, grid_size * cs, 3)
+    canvas = np.zeros((img_size, img_size, 3), np.uint8)      # img_size not divisible by grid_size: zero margin, as the reference
+    canvas[:grid_size * cs, :grid_size * cs] = mosaic
+    return canvas
 
 
 def stitch(chunks_dir: str, img_size: int, save_path: str, scale: int = 4, grid_size: int = 16, sentinel2: bool = False):

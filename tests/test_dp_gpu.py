@@ -127,3 +127,56 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["losses_finite"]
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+
+
+def _rccl_worker(port, outdir):
+    """one rank, backend nccl (= RCCL on ROCm), data-parallel branch forced: phase graphs captured in thread-local mode,
+    RCCL all-reduces of both gradient arenas on the side stream between them, event waits, 1/world in Adam."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      SSR_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("SSR_DIST_BACKEND", None)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.dp import DPContext, init_distributed
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    ctx = init_distributed()
+    assert torch.distributed.get_backend() == "nccl" and ctx.active and ctx.world == 1
+    g0, d0 = O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6)
+    res = {}
+    for name, dp in (("dp", ctx), ("single", DPContext(None, 0, 1))):
+        ts = ESRGANTrainStep(G_KW, D_KW, 2, 8, 8, "fp32", StepConfig(), dp=dp, use_graph=True)
+        ts.load_state(g0, d0)
+        if dp.active:
+            ts.sync_params_from_rank0()
+        logs = []
+        for rep in range(2):               # second pass replays the captured phase graphs around the live collectives
+            for it, (lr, gt) in enumerate(_data(), start=1 + 2 * rep):
+                ts.feed_data(lr.cuda(), gt.cuda())
+                ts.step(it)
+                logs.append(dict(ts.log()))
+        torch.cuda.synchronize()
+        if dp.active:
+            assert set(ts._graphs) == {"g", "d", "opt_g", "opt_d"}, set(ts._graphs)
+        res[name] = (logs, ts.g_store.data.cpu().clone(), ts.d_store.data.cpu().clone(), ts.opt_g.ema.cpu().clone())
+    torch.save(res, os.path.join(outdir, "rccl.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_branch_over_rccl_world1_equals_single_process_step(tmp_path):
+    """The RCCL path itself (backend "nccl", not the gloo stand-in) on the one GPU a test box has: world_size 1 with the DP
+    branch forced.  Sum over one rank is the identity and grad_scale is 1, so parameters, EMA and logs must equal the
+    single-process whole-step graph bit for bit in value (same kernels, same order of device work per arena)."""
+    mpc = mp.get_context("spawn")
+    p = mpc.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(timeout=900)
+    assert p.exitcode == 0
+    res = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=False)
+    (la, ga, da, ea), (lb, gb, db, eb) = res["dp"], res["single"]
+    for x, y in zip(la, lb):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 1e-6 * max(1.0, abs(y[k])), (k, x[k], y[k])
+    # wgrad accumulates with fp32 atomics: run-to-run differences at the 1e-7 level are expected, nothing larger
+    assert rel_err(ga, gb) < 1e-5 and rel_err(da, db) < 1e-5 and rel_err(ea, eb) < 1e-5

@@ -1,0 +1,319 @@
+"""GPU parity at the shapes the benchmark runs (BASELINE.json configs[1..3]): nf=64, gc=32, nb=23, 32x32 -> 128x128,
+C_in in {3, 24, 96}, C_d in {3, 27, 99}, in every arithmetic mode of the HIP path.
+
+Two kinds of check, both against the CPU oracle (never kernel against kernel):
+
+ * layer-local (oracle/layerwise.py, pinned against autograd of the oracle by tests/test_layerwise_oracle.py): every
+   stored activation, every gradient buffer and every parameter gradient of a full forward + backward is recomputed
+   on the CPU from the device's own inputs of that layer.  This is what holds each kernel family (fused dense block
+   forward/backward, weight-stationary, big-tile 3x3 / 2x2-parity / space-to-depth, thin-output, K-resident, pipelined;
+   bf16 transpose-read wgrad) to <= 4e-3 * max|ref| per layer in bf16 mode (the only legitimate difference: a bf16 store
+   on the other side of a rounding boundary) and to 1e-4 in the fp32 modes — at the batch and depth of the benchmark.
+ * end-to-end: generator forward and one whole optimize_parameters() against the oracle in the same precision model
+   (fp32 modes: the north-star 1e-3 gate; bf16: the bf16 oracle, tolerance stated at the assert).
+"""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import parity_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+NF, GC = 64, 32
+
+
+def _nchw(buf, c0, c1):
+    return buf[..., c0:c1].float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _tols(mode):
+    # (activations / gradient buffers: max, mean), (parameter gradients: max, mean), all relative to max|ref| of the layer
+    if mode == "bf16":
+        return (4e-3, 5e-5), (1e-3, 1e-4)
+    return (1e-4, 1e-5), (1e-4, 1e-5)
+
+
+def _set_mode(mode):
+    """'fp32' = exact fp32 MFMA; 'fp32x3' = fp32 storage, three bf16 MFMAs per product (split operands)."""
+    from satlas_super_resolution_amd import hip
+    if hasattr(hip, "set_fp32_math"):
+        hip.set_fp32_math("x3" if mode == "fp32x3" else "exact")
+    elif mode == "fp32x3":
+        pytest.skip("split-bf16 fp32 mode not built")
+    return hip.dtype_code("bf16" if mode == "bf16" else "fp32")
+
+
+@pytest.fixture(autouse=True)
+def _restore_math_mode():
+    yield
+    from satlas_super_resolution_amd import hip
+    if hasattr(hip, "set_fp32_math"):
+        hip.set_fp32_math("exact")
+
+
+def _gen_state(c_in, nb, seed=11):
+    from oracle import esrgan_oracle as O
+    kw = dict(num_in_ch=c_in, num_out_ch=3, scale=4, num_feat=NF, num_block=nb, num_grow_ch=GC)
+    sd = O.generator_init(seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in list(sd):      # the reference zero-initialises the dense-block biases: make them non-zero so the bias path is tested
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+    return kw, sd
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp32x3"])
+@pytest.mark.parametrize("c_in,B", [(24, 32), (3, 4), (96, 4)])
+def test_generator_every_layer_at_baseline_shape(mode, c_in, B):
+    """SSR_RRDBNet(nf=64, nb=23, gc=32) forward + backward, 32x32 tiles: 351 convs forward, their dgrads, 351 weight and
+    bias gradients, layer by layer.  (24, 32) is the benchmarked configuration exactly."""
+    from oracle import layerwise as LW
+    from satlas_super_resolution_amd import engine
+    if mode != "bf16" and B > 4:
+        B = 8                                  # fp32 modes: same kernels at any batch >= 8 tiles; keep the CPU side short
+    dt = _set_mode(mode)
+    nb = 23
+    kw, sd = _gen_state(c_in, nb)
+    st = engine.ParamStore(engine.generator_specs(**kw), dt)
+    st.load_state_dict(sd)
+    plan = engine.GeneratorPlan(st, B, 32, 32, training=True, **kw)
+    torch.manual_seed(c_in)
+    x = torch.rand(B, c_in, 32, 32)
+    gout = torch.randn(B, 3, 128, 128)
+    st.pack()
+    plan.load_input(x.cuda())
+    plan.fwd.run()
+    plan.load_output_grad(gout.cuda())
+    st.grad.zero_()
+    plan.bwd.run()
+    torch.cuda.synchronize()
+    cd = NF + 4 * GC
+    bufs = {"xin": _nchw(plan.xin, 0, c_in), "rdb": [_nchw(b, 0, cd) for b in plan.bufs],
+            "body_out": _nchw(plan.body_out, 0, NF), "trunk": _nchw(plan.trunk, 0, NF),
+            "ups": [_nchw(u, 0, NF) for u in plan.ups], "hr": _nchw(plan.hr, 0, NF), "out": _nchw(plan.out, 0, 3)}
+    gb = {"d_out": _nchw(plan.d_out, 0, 3), "g_hr": _nchw(plan.g_hr, 0, NF), "g_ups": [_nchw(u, 0, NF) for u in plan.g_ups],
+          "g_tmp": [_nchw(u, 0, NF) for u in plan.g_tmp], "g_trunk": _nchw(plan.g_trunk, 0, NF),
+          "g_body_out": _nchw(plan.g_body_out, 0, NF), "drdb": [_nchw(b, 0, cd) for b in plan.dbufs]}
+    grads = {k: st.tensor(k, st.grad).cpu() for k in st.offsets}
+    lmode = "bf16" if mode == "bf16" else "fp32"
+    (amax, amean), (wmax, wmean) = _tols(mode)
+    if mode == "fp32x3":
+        amax, amean, wmax, wmean = 2e-4, 2e-5, 2e-4, 2e-5     # split operands: ~2^-16 relative per product
+    rep = LW.Report()
+    LW.generator_forward_layers(sd, bufs, NF, GC, nb, lmode, rep)
+    assert len(rep.rows) == 1 + 5 * 69 + 1 + 2 + 2
+    rep.check(amax, amean)
+    fwd = rep.summary()
+    rep = LW.Report()
+    LW.generator_backward_layers(sd, bufs, gb, grads, NF, GC, nb, lmode, rep, fused_bwd_weights=plan.fused_rdb)
+    rep_w = LW.Report()
+    rep_w.rows = [r for r in rep.rows if r[0].startswith(("wgrad", "bgrad"))]
+    rep.rows = [r for r in rep.rows if not r[0].startswith(("wgrad", "bgrad"))]
+    assert len(rep.rows) == 5 * 69 + 2 + 4 + 1 and len(rep_w.rows) >= 351
+    rep.check(amax, amean)
+    rep_w.check(wmax, wmean)
+    print(f"\n[layerwise G {mode} C_in={c_in} B={B}] fwd {fwd} | bwd {rep.summary()} | wgrad {rep_w.summary()}")
+
+
+def _disc_state(c_d, seed=21):
+    from oracle import esrgan_oracle as O
+    return O.discriminator_init(c_d, NF, seed=seed)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp32x3"])
+@pytest.mark.parametrize("c_d,B", [(3, 32), (27, 4), (99, 4)])
+def test_discriminator_every_layer_at_baseline_shape(mode, c_d, B):
+    """SSR_UNetDiscriminatorSN(nf=64) on 128x128 inputs with 3 / 27 (feed_disc_lr, 8xS2 RGB) / 99 (12-band) input channels:
+    forward, full backward (dgrads incl. the input gradient with the fused L1-gradient residual) and every weight gradient."""
+    from oracle import layerwise as LW
+    from satlas_super_resolution_amd import engine, hip
+    if mode != "bf16" and B > 4:
+        B = 4
+    dt = _set_mode(mode)
+    lmode = "bf16" if mode == "bf16" else "fp32"
+    sd = _disc_state(c_d)
+    st = engine.ParamStore(engine.discriminator_specs(c_d, NF, in_hw=(128, 128)), dt)
+    st.load_state_dict(sd)
+    plan = engine.DiscriminatorPlan(st, B, 128, 128, num_in_ch=c_d, num_feat=NF, skip_connection=True)
+    tdt = hip.torch_dtype(dt)
+    torch.manual_seed(c_d)
+    x = torch.rand(B, c_d, 128, 128)
+    xb = torch.zeros(B, 128, 128, plan.cdp, dtype=tdt, device="cuda")
+    xb[..., :c_d] = x.permute(0, 2, 3, 1).to(tdt).cuda()
+    resid = torch.zeros_like(xb)
+    resid[..., :3] = (torch.randn(B, 128, 128, 3) * 1e-3).to(tdt).cuda()
+    st.spectral_norm(power_iter=True)
+    st.pack()
+    plan.forward_plan(xb).run()
+    dl = torch.randn(B, 128, 128, 1) * 1e-2
+    plan.d_logits.zero_()
+    plan.d_logits[..., :1] = dl.to(tdt).cuda()
+    st.grad.zero_()
+    st.grad_sn.zero_()
+    plan.backward_plan(xb, param_grads=True, input_grad=True, in_residual=resid).run()
+    torch.cuda.synchronize()
+    # the weights the convs see: W, or W_orig * (1 / sigma) with the device's sigma (fp32, before the packing's rounding)
+    wts = {"conv0": sd["conv0.weight"], "conv9": sd["conv9.weight"]}
+    for j, n in enumerate(st.sn_names):
+        inv = (torch.ones((), dtype=torch.float32) / st.sigma[j].cpu())
+        wts[n] = st.tensor(n + ".weight_orig").cpu() * inv
+    bias = {"conv0": sd["conv0.bias"], "conv9": sd["conv9.bias"]}
+    nf = NF
+    chans = {"x0": nf, "x1": 2 * nf, "x2": 4 * nf, "x3": 8 * nf, "u3": 8 * nf, "a4": 4 * nf, "u4": 4 * nf, "a5": 2 * nf, "u5": 2 * nf,
+             "a6": nf, "x6": nf, "o7": nf, "o8": nf, "logits": 1}
+    bufs = {k: _nchw(getattr(plan, k), 0, c) for k, c in chans.items()}
+    gch = {"d_logits": 1, "g_o8": nf, "g_o7": nf, "g_a6": nf, "g_x6": nf, "g_u5": 2 * nf, "g_a5": 2 * nf, "g_x5": 2 * nf, "g_u4": 4 * nf,
+           "g_a4": 4 * nf, "g_x4": 4 * nf, "g_u3": 8 * nf, "g3": 8 * nf, "g2": 4 * nf, "g1": 2 * nf, "g0": nf, "g_in": c_d}
+    gb = {k: _nchw(getattr(plan, k), 0, c) for k, c in gch.items()}
+    x_in = _nchw(xb, 0, c_d)
+    wgr = {n: st.tensor(st.wkey(n), st.grad_sn if st.specs[n].sn else st.grad).cpu() for n in wts}
+    (amax, amean), (wmax, wmean) = _tols(mode)
+    if mode == "fp32x3":
+        amax, amean, wmax, wmean = 2e-4, 2e-5, 2e-4, 2e-5
+    rep = LW.Report()
+    LW.discriminator_forward_layers(wts, bias, x_in, bufs, True, lmode, rep)
+    rep.check(amax, amean)
+    fwd = rep.summary()
+    rep = LW.Report()
+    LW.discriminator_backward_layers(wts, x_in, bufs, gb, wgr, True, lmode, rep, in_residual=_nchw(resid, 0, c_d))
+    rep_w = LW.Report()
+    rep_w.rows = [r for r in rep.rows if r[0].startswith("wgrad")]
+    rep.rows = [r for r in rep.rows if not r[0].startswith("wgrad")]
+    rep.check(amax, amean)
+    rep_w.check(wmax, wmean)
+    print(f"\n[layerwise D {mode} C_d={c_d} B={B}] fwd {fwd} | bwd {rep.summary()} | wgrad {rep_w.summary()}")
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# end to end
+# -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp32x3"])
+@pytest.mark.parametrize("c_in", [3, 24, 96])
+def test_generator_forward_full_depth_vs_oracle(mode, c_in):
+    """BASELINE.json configs[0] shape (B=4, nb=23) and its 24- / 96-channel siblings, inference plan (rotating buffers)."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd import engine
+    dt = _set_mode(mode)
+    kw, sd = _gen_state(c_in, 23, seed=5)
+    st = engine.ParamStore(engine.generator_specs(**kw), dt)
+    st.load_state_dict(sd)
+    plan = engine.GeneratorPlan(st, 4, 32, 32, training=False, **kw)
+    torch.manual_seed(1)
+    x = torch.rand(4, c_in, 32, 32)
+    st.pack()
+    plan.load_input(x.cuda())
+    plan.fwd.run()
+    y = plan.read_output().cpu()
+    with torch.no_grad():
+        ref = O.generator_forward(sd, x, 4, O.BF16 if mode == "bf16" else O.FP32)
+    if mode == "bf16":
+        # same precision model on both sides; what is left is the amplification of 1-ulp store differences through 351 layers
+        assert rel_err(y, ref) < 1e-2, rel_err(y, ref)
+        assert float((y - ref).abs().mean() / ref.abs().max()) < 1e-3
+    else:
+        assert parity_close(y, ref), rel_err(y, ref)          # north-star gate: 1e-3
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp32x3"])
+@pytest.mark.parametrize("c_in,feed_disc_lr", [(3, False), (24, False), (24, True), (96, False)])
+def test_train_step_full_depth_vs_oracle(mode, c_in, feed_disc_lr):
+    """One optimize_parameters() at nf=64/gc=32/nb=23, B=4, against the oracle in the same precision model: the six logged
+    scalars, every generator and discriminator parameter gradient, the generator output.  (24, True) feeds the 27-channel
+    discriminator of `feed_disc_lr`."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    dt_name = "bf16" if mode == "bf16" else "fp32"
+    _set_mode(mode)
+    c_d = 3 + (c_in if feed_disc_lr else 0)
+    kw, g0 = _gen_state(c_in, 23, seed=7)
+    d_kw = dict(num_in_ch=c_d, num_feat=NF, skip_connection=True)
+    d0 = _disc_state(c_d, seed=8)
+    torch.manual_seed(9)
+    B = 4
+    lr, gt = torch.rand(B, c_in, 32, 32), torch.rand(B, 3, 128, 128)
+    prec = O.BF16 if mode == "bf16" else O.FP32
+    orc = O.ESRGANOracle(g0, d0, O.StepConfig(feed_disc_lr=feed_disc_lr, prec=prec))
+    ref_log = orc.step(lr, gt, 1)
+    ts = ESRGANTrainStep(kw, d_kw, B, 32, 32, dt_name, StepConfig(feed_disc_lr=feed_disc_lr), use_graph=False)
+    ts.load_state(g0, d0)
+    ts.feed_data(lr.cuda(), gt.cuda())
+    ts.step(1)
+    log = ts.log()
+    # bf16 vs the bf16 oracle: the per-layer differences (<= 1 ulp of a stored value, test above) amplified by the depth
+    ltol, gtol, otol = (5e-3, 2e-2, 1e-2) if mode == "bf16" else (1e-3, 1e-3, 1e-3)
+    for k, v in ref_log.items():
+        assert abs(log[k] - v) <= ltol * max(1.0, abs(v)), (k, log[k], v)
+    worst = ("", 0.0)
+    for k, g in list(orc.g_grads.items()) + [("D." + k, g) for k, g in orc.d_grads.items()]:
+        store = ts.d_store if k.startswith("D.") else ts.g_store
+        got = store.tensor(k[2:] if k.startswith("D.") else k, store.grad)
+        e = rel_err(got, g)
+        if e > worst[1]:
+            worst = (k, e)
+        if mode != "bf16":
+            assert parity_close(got, g, rtol=gtol, atol_frac=gtol), (k, e)
+    assert worst[1] < (gtol if mode == "bf16" else 2e-3), worst
+    out = ts.output().cpu()
+    if mode == "bf16":
+        assert rel_err(out, orc.output) < otol, rel_err(out, orc.output)
+    else:
+        assert parity_close(out, orc.output), rel_err(out, orc.output)
+    print(f"\n[step {mode} C_in={c_in} C_d={c_d}] worst grad {worst}, out {rel_err(out, orc.output):.2e}")
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# whole-tile inference (BASELINE.json configs[4]): infer_grid.py:46-85 + infer_utils.py:6-60
+# -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
+def test_infer_grid_tile_end_to_end_vs_oracle(mode):
+    """One 16x16 grid of Sentinel-2 chunks -> format_s2naip_data -> SSR_RRDBNet plugin (8xS2 model, nb=23) in batches ->
+    truncating uint8 -> stitch: the 2048x2048x3 uint8 tile against the oracle's.  fp32 arithmetic differs in summation
+    order, so a value within ~1e-6 of an integer boundary may truncate to the neighbouring byte: at most 1 level, on a
+    vanishing fraction of the 12.6 M samples (counted and bounded), everything else bit-identical."""
+    import random
+
+    import numpy as np
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.archs.rrdbnet_arch import SSR_RRDBNet
+    from satlas_super_resolution_amd.utils import infer_utils as U
+    _set_mode(mode)
+    kw, sd = _gen_state(24, 23, seed=13)
+    net = SSR_RRDBNet(compute_dtype="fp32", **kw)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    rng = np.random.RandomState(4)
+    stacks = {}
+    for i in range(16):
+        for j in range(16):
+            s = rng.randint(1, 256, (12 * 32, 32, 3)).astype(np.uint8)       # 12 frames; a few of them partially black
+            for t in rng.choice(12, 3, replace=False):
+                s[t * 32 + 5, 7] = 0
+            stacks[(i, j)] = s
+    random.seed(99)
+    keys = [(i, j) for i in range(16) for j in range(16)]
+    inputs = [U.format_s2naip_data(stacks[k], 8, "cpu")[0] for k in keys]
+    with torch.no_grad():
+        got = U.infer_chunks(net, inputs, batch=64, device=torch.device("cuda"))
+        # two ranks' shares (sharded chunk loop, no collective) reproduce the same chunks
+        r1 = U.infer_chunks(net, inputs[:32], batch=8, rank=1, world=2, device=torch.device("cuda"))
+    assert sorted(r1) == list(range(1, 32, 2)) and all((r1[i] == got[i]).all() for i in r1)
+    tile = U.stitch_arrays({k: got[n] for n, k in enumerate(keys)}, 2048, grid_size=16)
+    assert tile.shape == (2048, 2048, 3) and tile.dtype == np.uint8
+    ref_chunks = {}
+    with torch.no_grad():
+        for b0 in range(0, 256, 32):
+            y = O.generator_forward(sd, torch.cat(inputs[b0:b0 + 32]), 4)
+            q = O.quantize_u8_truncate(y).permute(0, 2, 3, 1).numpy()
+            for n in range(32):
+                ref_chunks[keys[b0 + n]] = q[n]
+    ref = np.zeros((2048, 2048, 3), np.uint8)
+    for (i, j), c in ref_chunks.items():
+        a, b = O.stitch_offsets(16, 128)[i][j]
+        ref[a:a + 128, b:b + 128] = c
+    diff = np.abs(tile.astype(np.int16) - ref.astype(np.int16))
+    frac = float((diff > 0).mean())
+    assert diff.max() <= 1, int(diff.max())
+    assert frac < (2e-3 if mode == "fp32" else 5e-3), frac
+    print(f"\n[infer tile {mode}] samples differing by one level: {frac:.2e}")

@@ -1,0 +1,270 @@
+"""GPU: the drop-in boundary behaves like the reference loop expects (train.py:62-133), beyond the plain step:
+gated iterations (net_d_iters / net_d_init_iters) incl. EMA, `old_hr` discriminator input, BasicSR-shaped checkpoint
+files and resume before the first batch, learning-rate schedule across step rebuilds."""
+import copy
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import load_golden, parity_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(c_in=6, c_d=3, nb=1):
+    from oracle import esrgan_oracle as O
+    g_kw = dict(num_in_ch=c_in, num_out_ch=3, scale=4, num_feat=16, num_block=nb, num_grow_ch=8)
+    d_kw = dict(num_in_ch=c_d, num_feat=8, skip_connection=True)
+    return g_kw, d_kw, O.generator_init(seed=31, **g_kw), O.discriminator_init(c_d, 8, seed=32)
+
+
+def _close_update(got, ref, p0, what, frac=2e-2):
+    upd_ref, upd = ref - p0, got - p0
+    assert (upd - upd_ref).abs().max() <= frac * upd_ref.abs().max() + 3e-7 * ref.abs().max() + 1e-9, what
+
+
+def test_gated_iterations_follow_the_reference_incl_ema():
+    """net_d_iters=2, net_d_init_iters=1 (ssr_esrgan_model.py:144): G steps only on iterations 2 and 4 of 4, D on all of
+    them, the D forward of the G phase (and its power iteration) is skipped on gated iterations, model_ema runs on EVERY
+    iteration (:230-231).  Eager and hipGraph replay."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    g_kw, d_kw, g0, d0 = _tiny()
+    torch.manual_seed(5)
+    data = [(torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32)) for _ in range(4)]
+    for use_graph in (False, True):
+        orc = O.ESRGANOracle(g0, d0, O.StepConfig(net_d_iters=2, net_d_init_iters=1, ema_decay=0.9, lr_g=1e-3, lr_d=1e-3))
+        ts = ESRGANTrainStep(g_kw, d_kw, 2, 8, 8, "fp32",
+                             StepConfig(net_d_iters=2, net_d_init_iters=1, ema_decay=0.9, lr_g=1e-3, lr_d=1e-3), use_graph=use_graph)
+        ts.load_state(g0, d0)
+        # each graph is captured on its second use: run the schedule twice so that gated and full iterations both replay
+        for rep in range(2):
+            for it, (lr, gt) in enumerate(data, start=1 + 4 * rep):
+                cur = it if rep == 0 else it       # iterations 5..8: 6 and 8 are G iterations
+                ref_log = orc.step(lr, gt, cur)
+                ts.feed_data(lr.cuda(), gt.cuda())
+                ts.step(cur)
+                log = ts.log()
+                g_on = cur % 2 == 0 and cur > 1
+                assert ("l_g_pix" in ref_log) == g_on
+                for k, v in ref_log.items():
+                    assert abs(log[k] - v) <= 2e-3 * max(1.0, abs(v)), (use_graph, cur, k, log[k], v)
+                if not g_on:
+                    assert log["l_g_pix"] == 0.0 and log["l_g_gan"] == 0.0
+        ema = ts.ema_state_dict()
+        for k in g0:
+            _close_update(ts.g_store.tensor(k).cpu(), orc.g[k], g0[k], ("G", k), 5e-2)
+            _close_update(ema[k].cpu(), orc.g_ema[k], g0[k], ("EMA", k), 5e-2)
+        # 8 iterations: the EMA moved although G stepped on only 4 of them; u/v advanced 2 (D phases) + 1 (G phase) per full iteration
+        for n in O.SN_LAYERS:
+            assert rel_err(ts.d_store.u[n], orc.d[n + ".weight_u"]) < 2e-3, n
+
+
+@pytest.mark.parametrize("feed_disc_lr", [False, True])
+def test_old_hr_discriminator_input(feed_disc_lr):
+    """`old_hr` in the batch: D sees [img | lr_resized | old_hr] (ssr_esrgan_model.py:171-175, 202-207)."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    c_d = 3 + (6 if feed_disc_lr else 0) + 3
+    g_kw, d_kw, g0, d0 = _tiny(6, c_d)
+    torch.manual_seed(6)
+    lr, gt, old = torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32), torch.rand(2, 3, 32, 32)
+    orc = O.ESRGANOracle(g0, d0, O.StepConfig(feed_disc_lr=feed_disc_lr))
+    ref_log = orc.step(lr, gt, 1, old_hr=old)
+    ts = ESRGANTrainStep(g_kw, d_kw, 2, 8, 8, "fp32", StepConfig(feed_disc_lr=feed_disc_lr, old_hr=True), use_graph=False)
+    ts.load_state(g0, d0)
+    ts.feed_data(lr.cuda(), gt.cuda(), old_hr=old.cuda())
+    ts.step(1)
+    log = ts.log()
+    for k, v in ref_log.items():
+        assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, log[k], v)
+    for k, g in orc.g_grads.items():
+        assert parity_close(ts.g_store.tensor(k, ts.g_store.grad), g), ("g grad", k)
+    for k, g in orc.d_grads.items():
+        assert parity_close(ts.d_store.tensor(k, ts.d_store.grad), g), ("d grad", k)
+    with pytest.raises(AssertionError):
+        ts.feed_data(lr.cuda(), gt.cuda())            # a batch without old_hr cannot feed a D built for it
+
+
+def _opt(tmp_path, fx, **over):
+    opt = {
+        "model_type": "SSRESRGANModel", "scale": 4, "manual_seed": 0, "is_train": True, "dist": False, "name": "t",
+        "l1_gt_usm": False, "percep_gt_usm": False, "gan_gt_usm": False, "feed_disc_lr": False,
+        "network_g": dict(type="SSR_RRDBNet", **fx["g_kwargs"]),
+        "network_d": dict(type="SSR_UNetDiscriminatorSN", **fx["d_kwargs"]),
+        "path": {"models": str(tmp_path / "models"), "training_states": str(tmp_path / "states"),
+                 "visualization": str(tmp_path / "vis")},
+        "train": {"ema_decay": 0.999, "optim_g": {"type": "Adam", "lr": 1e-4, "weight_decay": 0, "betas": [0.9, 0.99]},
+                  "optim_d": {"type": "Adam", "lr": 2e-4, "weight_decay": 0, "betas": [0.5, 0.9]},
+                  "scheduler": {"type": "MultiStepLR", "milestones": [3], "gamma": 0.5},
+                  "pixel_opt": {"type": "L1Loss", "loss_weight": 1.0, "reduction": "mean"},
+                  "gan_opt": {"type": "GANLoss", "gan_type": "vanilla", "real_label_val": 1.0, "fake_label_val": 0.0, "loss_weight": 0.1},
+                  "net_d_iters": 1, "net_d_init_iters": 0},
+        "val": {"val_freq": 2, "save_img": True,
+                "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 4, "test_y_channel": False},
+                            "ssim": {"type": "calculate_ssim", "crop_border": 4, "test_y_channel": False},
+                            "cpsnr": {"type": "calculate_cpsnr", "crop_border": 4, "test_y_channel": False}}},
+    }
+    opt.update(over)
+    return opt
+
+
+def _batch(lr, gt):
+    return {"lr": (lr * 255).round().to(torch.uint8), "hr": (gt * 255).round().to(torch.uint8)}
+
+
+def test_save_resume_round_trip_before_first_batch(tmp_path):
+    """train.py:62-65: build_model(opt) then model.resume_training(state) BEFORE any feed_data.  A run that is saved after
+    2 iterations, rebuilt from its files and resumed must continue exactly like the uninterrupted run (parameters, Adam
+    moments, step count, EMA from 'params_ema', learning-rate schedule); the .state file has BasicSR's shape."""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden("step_tiny")
+    data = list(fx["data"]) * 2          # 4 iterations
+    opt = _opt(tmp_path, fx)
+    a = build_model(opt)
+    for it in (1, 2):
+        a.update_learning_rate(it)
+        a.feed_data(_batch(*data[it - 1]))
+        a.optimize_parameters(it)
+    a.save(0, 2)
+    state = torch.load(tmp_path / "states" / "2.state", weights_only=False)
+    assert set(state) == {"epoch", "iter", "optimizers", "schedulers"} and state["iter"] == 2
+    assert len(state["optimizers"]) == 2 and len(state["schedulers"]) == 2
+    og = state["optimizers"][0]
+    assert set(og) == {"state", "param_groups"} and og["param_groups"][0]["betas"] == (0.9, 0.99)
+    assert state["optimizers"][1]["param_groups"][0]["betas"] == (0.5, 0.9)          # optim_d's own betas
+    n_g = len(a.ts.g_store.offsets)
+    assert og["param_groups"][0]["params"] == list(range(n_g)) and set(og["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(og["state"][n_g - 1]["step"]) == 2.0
+    assert og["state"][0]["exp_avg"].shape == a.ts.g_store.tensor("conv_first.weight").shape
+    assert state["schedulers"][0]["last_epoch"] == 1 and state["schedulers"][0]["milestones"] == {3: 1}
+    # torch's own Adam accepts the optimizer state (that is what BasicSR's resume_training does)
+    plist = [torch.nn.Parameter(a.ts.g_store.tensor(k).cpu().clone()) for k in a.ts.g_store.offsets]
+    torch.optim.Adam(plist, lr=1e-4, betas=(0.9, 0.99)).load_state_dict(og)
+    for it in (3, 4):
+        a.update_learning_rate(it)
+        a.feed_data(_batch(*data[it - 1]))
+        a.optimize_parameters(it)
+    # ---- second process: rebuild from the files, resume before the first batch
+    opt_b = copy.deepcopy(opt)
+    opt_b["path"]["pretrain_network_g"] = str(tmp_path / "models" / "net_g_2.pth")
+    opt_b["path"]["pretrain_network_d"] = str(tmp_path / "models" / "net_d_2.pth")
+    b = build_model(opt_b)
+    b.resume_training(state)
+    assert b.ts is None
+    for it in (3, 4):
+        b.update_learning_rate(it)
+        b.feed_data(_batch(*data[it - 1]))
+        b.optimize_parameters(it)
+        la, lb = a.get_current_log(), b.get_current_log()
+    assert b.get_current_learning_rate() == a.get_current_learning_rate() == [0.5e-4]     # milestone 3 reached at iteration 4
+    assert float(b.ts.opt_d.lr.item()) == pytest.approx(1e-4)
+    assert int(b.ts.opt_g.step.item()) == 4
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    for sa, sb, what in ((a.ts.g_store.data, b.ts.g_store.data, "G"), (a.ts.d_store.data, b.ts.d_store.data, "D"),
+                         (a.ts.opt_g.ema, b.ts.opt_g.ema, "EMA"), (a.ts.opt_g.exp_avg, b.ts.opt_g.exp_avg, "m"),
+                         (a.ts.opt_d.exp_avg_sq, b.ts.opt_d.exp_avg_sq, "v")):
+        assert rel_err(sb, sa) < 1e-4, what
+    assert (a.ts.opt_g.ema - a.ts.g_store.data).abs().max() > 0        # the EMA history really differs from the weights
+
+
+def test_learning_rate_survives_a_step_rebuild(tmp_path):
+    """update_learning_rate() precedes feed_data() in the loop (train.py:106-108): the device LR must be the scheduled one on
+    the very first iteration (warm-up) and after a rebuild for another batch shape (ragged last batch)."""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden("step_tiny")
+    lr, gt = fx["data"][0]
+    m = build_model(_opt(tmp_path, fx))
+    m.update_learning_rate(1, warmup_iter=10)
+    m.feed_data(_batch(lr, gt))
+    assert float(m.ts.opt_g.lr.item()) == pytest.approx(1e-5) and float(m.ts.opt_d.lr.item()) == pytest.approx(2e-5)
+    m.optimize_parameters(1)
+    m.update_learning_rate(5, warmup_iter=-1)            # past milestone 3
+    m.feed_data(_batch(lr[:1], gt[:1]))                  # batch of 1: the step is rebuilt
+    assert m.ts.B == 1 and float(m.ts.opt_g.lr.item()) == pytest.approx(0.5e-4)
+    assert int(m.ts.opt_g.step.item()) == 1              # optimizer state carried over
+    m.optimize_parameters(5)
+    assert all(v == v for v in m.get_current_log().values())
+
+
+def test_validation_runs_metrics_and_writes_images(tmp_path):
+    """nondist_validation (ssr_esrgan_model.py:269-352) with psnr / ssim / cpsnr on device and PNG output."""
+    import numpy as np
+    from PIL import Image
+    from oracle import metrics_oracle as MO
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden("step_tiny")
+    lr, gt = fx["data"][0]
+    m = build_model(_opt(tmp_path, fx))
+    m.update_learning_rate(1)
+    m.feed_data(_batch(lr, gt))
+    m.ts.load_state(fx["g0"], fx["d0"])
+    m.optimize_parameters(1)
+
+    class DS:
+        opt = {"name": "val"}
+
+    class Loader(list):
+        dataset = DS()
+
+    loader = Loader([_batch(lr[:1], gt[:1]), _batch(lr[1:], gt[1:])])
+    res = m.validation(loader, 1, None, save_img=True) or m.metric_results
+    assert set(res) == {"psnr", "ssim", "cpsnr"}
+    # reference values from the CPU restatement on the images the model wrote
+    vals = {"psnr": [], "ssim": [], "cpsnr": []}
+    for idx in range(2):
+        sr = np.asarray(Image.open(tmp_path / "vis" / str(idx) / f"{idx}_1.png"))
+        g = np.asarray(Image.open(tmp_path / "vis" / str(idx) / f"{idx}_1_gt.png"))
+        assert sr.shape == (32, 32, 3) and g.shape == (32, 32, 3)
+        assert (g == (gt[idx] * 255).round().permute(1, 2, 0).numpy().astype(np.uint8)).all()
+        vals["psnr"].append(MO.calculate_psnr(sr, g, 4))
+        vals["ssim"].append(MO.calculate_ssim(sr, g, 4))
+        vals["cpsnr"].append(MO.calculate_cpsnr(sr, g, 4))
+    for k in vals:
+        assert res[k] == pytest.approx(sum(vals[k]) / 2, rel=1e-6, abs=1e-6), k
+    assert m.best_metric_results["val"]["psnr"]["iter"] == 1
+
+
+def test_device_metrics_match_the_cpu_restatement():
+    """csrc/metrics.hip through the C ABI: psnr / ssim / cpsnr on uint8 images vs oracle/metrics_oracle.py (cpsnr additionally
+    vs the values the unmodified reference function produced, tests/golden/cpsnr.pt); ragged sizes, crop 0 and 4."""
+    import numpy as np
+    from oracle import metrics_oracle as MO
+    from satlas_super_resolution_amd import metrics as M
+    cases = [(c["img"].numpy(), c["img2"].numpy(), c["crop_border"], c["value"]) for c in load_golden("cpsnr")]
+    rng = np.random.RandomState(3)
+    for (h, w, crop) in [(128, 128, 4), (37, 53, 0), (32, 32, 4)]:
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.randint(-9, 10, a.shape), 0, 255).astype(np.uint8)
+        cases.append((a, b, crop, None))
+    for a, b, crop, ref_cpsnr in cases:
+        ta, tb = torch.from_numpy(a).cuda()[None], torch.from_numpy(b).cuda()[None]
+        assert M.calculate_psnr(ta, tb, crop) == pytest.approx(MO.calculate_psnr(a, b, crop), rel=1e-12)
+        assert M.calculate_ssim(ta, tb, crop) == pytest.approx(MO.calculate_ssim(a, b, crop), rel=1e-9)
+        v = M.calculate_cpsnr(ta, tb, crop)
+        assert v == pytest.approx(MO.calculate_cpsnr(a, b, crop), rel=1e-10)
+        if ref_cpsnr is not None:
+            assert v == pytest.approx(ref_cpsnr, rel=1e-10)
+    same = torch.from_numpy(cases[0][0]).cuda()[None]
+    assert M.calculate_psnr(same, same, 4) == float("inf") and M.calculate_cpsnr(same, same, 4) == float("inf")
+    with pytest.raises(NotImplementedError):
+        M.calculate_psnr(same, same, 4, test_y_channel=True)
+
+
+def test_quantize_u8_round_and_truncate_bit_exact():
+    """tensor2img's round-half-even and infer_grid.py's truncating astype(uint8), bit for bit against numpy."""
+    import numpy as np
+    from satlas_super_resolution_amd import metrics as M
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 17, 23) * 1.2 - 0.1
+    x[0, 0, 0, :8] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 1.0, 0.0, -3.0, 7.0])
+    xn = np.clip(x.numpy(), 0, 1)
+    ref_round = (xn * np.float32(255.0)).round().astype(np.uint8).transpose(0, 2, 3, 1)
+    ref_trunc = (xn * np.float32(255)).astype(np.uint8).transpose(0, 2, 3, 1)
+    assert (M.tensor2img_u8(x.cuda()).cpu().numpy() == ref_round).all()
+    assert (M.tensor2img_u8(x.cuda(), truncate=True).cpu().numpy() == ref_trunc).all()

@@ -132,3 +132,51 @@ def test_discriminator_specs_steer_the_space_to_depth_path_by_grid_size():
     assert flags((256, 96)) == {"conv1": None, "conv2": None, "conv3": False}       # min side decides: 48, 24, 12
     names = [s.name for s in engine.discriminator_specs(3, 64)]
     assert names == ["conv%d" % i for i in range(10)]
+
+
+def test_every_shipped_option_file_constructs_or_names_what_it_lacks():
+    """/root/reference/ssr/options/*.yml (dumped by oracle/make_option_fixtures.py): every file either yields a StepConfig
+    or raises NotImplementedError naming the out-of-scope key/type — nothing is silently dropped.  (GPU-free: the model
+    constructor runs exactly this function on `opt`.)"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from satlas_super_resolution_amd.models.ssr_esrgan_model import _arch_kwargs, step_config_from_opt
+    opts = json.load(open(os.path.join(GOLDEN, "ssr_options.json")))
+    assert len(opts) == 12
+    outcome = {}
+    for name, opt in sorted(opts.items()):
+        try:
+            if opt.get("model_type") != "SSRESRGANModel":
+                raise NotImplementedError(f"model_type {opt.get('model_type')}")
+            _arch_kwargs(opt["network_g"], "SSR_RRDBNet")
+            if "network_d" in opt:
+                _arch_kwargs(opt["network_d"], "SSR_UNetDiscriminatorSN")
+            cfg = step_config_from_opt(opt)
+            outcome[name] = cfg
+        except NotImplementedError as e:
+            outcome[name] = str(e)
+    runs = {k for k, v in outcome.items() if not isinstance(v, str)}
+    assert runs == {"allbands_esrgan_s2naip_urban.yml", "esrgan_s2naip_full.yml", "esrgan_s2naip_urban.yml",
+                    "old-naip_esrgan_s2naip_urban.yml", "rand_crop_esrgan_s2naip_urban.yml", "infer_example.yml",
+                    "infer_grid_example.yml"}, outcome
+    assert "clip_opt" in outcome["cliploss_esrgan_s2naip_urban.yml"]
+    assert "ssim_opt" in outcome["ssimloss_esrgan_s2naip_urban.yml"]
+    for k in ("highresnet_s2naip_urban.yml", "srcnn_s2naip_urban.yml", "osm_obj_esrgan.yml"):
+        assert "model_type" in outcome[k]
+    cfg = outcome["esrgan_s2naip_urban.yml"]
+    assert (cfg.l1_weight, cfg.gan_weight, cfg.lr_g, cfg.lr_d, cfg.betas, cfg.ema_decay) == (1.0, 0.1, 1e-4, 1e-4, (0.9, 0.99), 0.999)
+    assert cfg.l1_gt_usm and cfg.percep_gt_usm and not cfg.gan_gt_usm and cfg.feed_disc_lr
+    assert cfg.perceptual["type"] == "PerceptualLoss" and cfg.perceptual["layer_weights"]["conv5_4"] == 1
+    # options this path cannot honour are rejected by name
+    import copy
+    for path, val, key in ((("train", "optim_g", "type"), "SGD", "optim_g.type"), (("train", "optim_d", "weight_decay"), 0.1, "weight_decay"),
+                           (("train", "scheduler", "type"), "CosineAnnealingRestartLR", "scheduler.type"),
+                           (("train", "gan_opt", "gan_type"), "wgan", "gan_opt"), (("train", "pixel_opt", "type"), "MSELoss", "pixel_opt")):
+        o = copy.deepcopy(opts["esrgan_s2naip_urban.yml"])
+        d = o
+        for p in path[:-1]:
+            d = d[p]
+        d[path[-1]] = val
+        with pytest.raises(NotImplementedError, match=key.replace(".", r"\.")):
+            step_config_from_opt(o)

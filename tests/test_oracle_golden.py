@@ -129,3 +129,24 @@ def test_usm_sharp_oracle_properties():
     assert float(out[0, 0, 32, 33]) > 0.8 + 0.05            # overshoot on the bright side of the edge
     assert float(out[0, 0, 32, 30]) == 0.0                  # dark side: sharp value clipped at 0
     assert torch.allclose(out[0, 0, :, 0], edge[0, 0, :, 0])   # far from the edge: residual below threshold
+
+
+def test_metrics_oracle_cpsnr_matches_reference_golden():
+    """oracle/metrics_oracle.calculate_cpsnr against values of the unmodified /root/reference/ssr/metrics/cpsnr.py
+    (oracle/make_metric_golden.py); PSNR / SSIM known answers (BasicSR pieces: parity unpinned by the reference)."""
+    import numpy as np
+    from oracle import metrics_oracle as MO
+    for c in load_golden("cpsnr"):
+        a, b = c["img"].numpy(), c["img2"].numpy()
+        v = MO.calculate_cpsnr(a, b, c["crop_border"])
+        assert abs(v - c["value"]) <= 1e-9 * max(1.0, abs(c["value"])), (v, c["value"])
+    rng = np.random.RandomState(0)
+    a = rng.randint(0, 256, (32, 32, 3)).astype(np.uint8)
+    assert MO.calculate_psnr(a, a, 4) == float("inf") and abs(MO.calculate_ssim(a, a, 4) - 1.0) < 1e-12
+    b = a.copy()
+    b[4:-4, 4:-4] = np.clip(a[4:-4, 4:-4].astype(int) + 5, 0, 255).astype(np.uint8)   # +5 wherever it does not saturate
+    d = (a[4:-4, 4:-4].astype(float) - b[4:-4, 4:-4]) ** 2
+    assert abs(MO.calculate_psnr(a, b, 4) - 10 * np.log10(255.0 ** 2 / d.mean())) < 1e-12
+    assert 0.9 < MO.calculate_ssim(a, b, 4) < 1.0
+    g = MO._gauss()
+    assert abs(g.sum() - 1) < 1e-15 and abs(g[5] / g[4] - np.exp(1 / (2 * 1.5 ** 2))) < 1e-12

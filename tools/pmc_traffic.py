@@ -46,6 +46,13 @@ def main():
         res[s] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
                   "launches_sampled": [nf.get(s, 0), nw.get(s, 0)],
                   "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, separate --pmc passes"}
+    # which build / configuration the counters belong to: bench.py reports roofline.traffic only for a matching run
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from satlas_super_resolution_amd import build as bld
+    import datetime
+    res["_meta"] = {"source_hash": bld.source_hash(), "batch": int(os.environ.get("SSR_PMC_BATCH", "32")),
+                    "frames": int(os.environ.get("SSR_PMC_FRAMES", "8")), "dtype": os.environ.get("SSR_PMC_DTYPE", "bf16"),
+                    "collected": datetime.date.today().isoformat()}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

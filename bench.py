@@ -32,7 +32,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL ac
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3}   # split operands: three bf16 MFMAs per product   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
 
 
 def parse():
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[2]: 32; configs[1]: 16)")
     ap.add_argument("--frames", type=int, default=8, help="Sentinel-2 frames (x3 RGB channels); configs[2]: 8, configs[1]: 1")
     ap.add_argument("--feed-disc-lr", action="store_true")
@@ -160,19 +160,44 @@ def wgrad_flops(ts):
     return tot
 
 
+T0 = time.perf_counter()
+
+
+def trace(msg):
+    """phase progress on stderr (the JSON line on stdout stays alone)"""
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    machine's CPUs even inside a container limited to a few, and oversubscribing those stalls PyTorch's thread pool)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, c_in, c_d):
     from oracle import esrgan_oracle as O
     torch.manual_seed(0)
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     torch.set_num_threads(ncores if args.cpu_threads <= 0 else max(1, min(args.cpu_threads, ncores)))
     B = args.cpu_batch
     g0 = O.generator_init(num_in_ch=c_in, num_block=args.blocks, seed=0)
     d0 = O.discriminator_init(c_d, 64, seed=1)
     orc = O.ESRGANOracle(g0, d0, O.StepConfig(feed_disc_lr=args.feed_disc_lr))
     lr, gt = torch.rand(B, c_in, 32, 32), torch.rand(B, 3, 128, 128)
+    tw = time.perf_counter()
     orc.step(lr, gt, 1)  # warm-up
+    tw = time.perf_counter() - tw
+    trace(f"cpu baseline warm-up step {tw:.1f}s on {torch.get_num_threads()} threads")
+    n_steps = max(1, min(args.cpu_steps, int(25.0 / max(tw, 1e-3))))     # bounded sample: ~25 s of CPU work
     ts = []
-    for it in range(args.cpu_steps):
+    for it in range(n_steps):
         t0 = time.perf_counter()
         orc.step(lr, gt, it + 2)
         ts.append(time.perf_counter() - t0)
@@ -187,9 +212,52 @@ def cpu_baseline(args, c_in, c_d):
     except OSError:
         pass
     return {"value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": ncores, "kind": "port",
-            "sample": f"{args.cpu_steps} timed G+D steps (median) at batch {B}, fp32, same architecture/shapes, "
+            "sample": f"{n_steps} timed G+D steps (median) at batch {B}, fp32, same architecture/shapes, "
                       f"after 1 warm-up, torch.set_num_threads({torch.get_num_threads()}) of {ncores} host cores; host CPU: {cpu}; "
                       f"oracle/esrgan_oracle.py (PyTorch CPU restatement; the reference itself is not on this box)"}
+
+
+def parity_mode_leg(args, g_kw, d_kw, c_in, c_d, B, lr, gt):
+    """The same train step in the arithmetic that meets the north-star 1e-3 gate (fp32 tensors, split-bf16 matrix math:
+    SSR_F32X3), timed in the same run at the same configuration, plus its measured error against the CPU oracle on a B=4
+    full-depth generator forward (the oracle is the checker here, never the thing measured)."""
+    import gc
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd import engine, hip
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
+    ts = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, "fp32x3", StepConfig(feed_disc_lr=args.feed_disc_lr), use_graph=not args.no_graph)
+    g0 = O.generator_init(seed=0, **g_kw)
+    ts.load_state(g0, O.discriminator_init(c_d, 64, seed=1))
+    ts.feed_data(lr, gt)
+    for _ in range(3):
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.parity_steps):
+        ts.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.parity_steps
+    finite = all(v == v and abs(v) < 1e30 for v in ts.log().values())
+    del ts
+    gc.collect()
+    torch.cuda.empty_cache()
+    st = engine.ParamStore(engine.generator_specs(**g_kw), hip.F32X3)
+    st.load_state_dict(g0)
+    plan = engine.GeneratorPlan(st, 4, 32, 32, training=False, **g_kw)
+    x = torch.rand(4, c_in, 32, 32, generator=torch.Generator().manual_seed(123))
+    st.pack()
+    plan.load_input(x.cuda())
+    plan.fwd.run()
+    y = plan.read_output().cpu()
+    with torch.no_grad():
+        ref = O.generator_forward(g0, x, 4)
+    err = float(((y - ref).abs() / (1e-3 * ref.abs().max() + 1e-3 * ref.abs())).max()) * 1e-3   # in units of the gate's bound
+    return {"dtype": "fp32x3", "arithmetic": "fp32 tensors in HBM; bf16 MFMA on split operands (hi+lo, 3 MFMAs per product), fp32 accumulate; "
+                                          "4x4 stride-2 layers on the exact fp32 MFMA",
+            "ms_per_step": 1e3 * dt, "value": B / dt, "unit": "images/s", "steps": args.parity_steps, "losses_finite": finite,
+            "max_rel_err_vs_oracle": err,
+            "err_definition": "max over outputs of |y - ref| / (max|ref| + |ref|): <= 1e-3 is the north-star gate; SSR_RRDBNet(nb=23) "
+                              "forward, B=4, vs oracle/esrgan_oracle.py (fp32 CPU)"}
 
 
 def main():
@@ -217,8 +285,11 @@ def main():
     gt = torch.rand(B, 3, 128, 128, device="cuda")
     ts.feed_data(lr, gt)
 
+    trace("plans built, data resident")
     for _ in range(max(args.warmup, 2)):   # >= 2: first touch + graph capture happen outside the timed region
         ts.step()
+    torch.cuda.synchronize()
+    trace("warm-up done")
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -248,6 +319,7 @@ def main():
         blocks.append(1e3 * float(tb.item()) / args.steps)
     log = ts.log()
     finite = all(v == v and abs(v) < 1e30 for v in log.values())
+    trace(f"timed {args.steps} steps + {len(blocks)} blocks: {1e3 * dt / args.steps:.2f} ms/step")
 
     value = ctx.world * B * args.steps / dt
     gflop_img = O.step_gflop_per_image(c_in, c_d)
@@ -271,6 +343,7 @@ def main():
     }
     # the instrumented step contains the gradient exchanges: every rank runs it (collectives must match), rank 0 reports
     agg = instrumented_step(ts, args) if not args.no_roofline else None
+    trace("instrumented step done")
     if ctx.rank == 0 and agg is not None:
         conv = {k: v for k, v in agg.items() if v[2] > 0}      # MFMA kernels (algorithmic FLOPs known)
         dom = max(conv, key=lambda k: conv[k][1])
@@ -304,6 +377,13 @@ def main():
             out["roofline"]["traffic_note"] = traffic_note
         out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in
                                            sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
+    if ctx.world == 1 and not args.no_parity_mode and args.dtype != "fp32x3" and args.blocks == 23:
+        del ts
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["parity_mode"] = parity_mode_leg(args, g_kw, d_kw, c_in, c_d, B, lr, gt)
+        trace("parity-mode leg done")
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, c_in, c_d)
     if ctx.rank == 0:

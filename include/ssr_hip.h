@@ -28,6 +28,10 @@ extern "C" {
 
 #define SSR_F32 0
 #define SSR_BF16 1
+/* fp32 tensors in HBM, bf16 matrix cores on split operands (hi + lo, three MFMAs per product, fp32 accumulation): the
+ * arithmetic mode that meets the 1e-3 parity gate at matrix-core speed.  Storage, packing and every non-MFMA entry point
+ * treat it exactly as SSR_F32. */
+#define SSR_F32X3 2
 
 #define SSR_OK 0
 #define SSR_EINVAL (-1)   /* bad descriptor (unsupported geometry / alignment) */
@@ -35,6 +39,7 @@ extern "C" {
 
 #define SSR_ACT_NONE 0
 #define SSR_ACT_LRELU 1   /* LeakyReLU(0.2): rrdbnet_arch.py:32, discriminator_arch.py:44-68 */
+#define SSR_ACT_RELU 2    /* ReLU: the VGG19 feature extractor of the perceptual loss (ssr_esrgan_model.py:153-160) */
 
 /* A channel-sliced NHWC view. */
 typedef struct ssr_view {
@@ -91,6 +96,8 @@ typedef struct ssr_conv_desc {
      * big-tile kernel gathers while staging — nothing is materialised.  `w` must then be packed with
      * ssr_pack_item.fwd_s2d = 1: [q*Cin/32 + chunk][2x2 taps (dy,dx)][CoutPad][32], tap (ky,kx) = (2dy + (q>>1), 2dx + (q&1)). */
     int32_t s2d;
+    /* 0: the mask `m` is LeakyReLU' (1 | 0.2 by the sign of m); 1: ReLU' (1 | 0) — backward through the VGG19 layers */
+    int32_t m_relu;
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
@@ -301,6 +308,22 @@ int ssr_quantize_u8(const float* src_nchw, uint8_t* dst_nhwc, int32_t N, int32_t
 int ssr_metric_shift_sums(const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, int32_t C, int32_t crop, int32_t max_offset,
                           int64_t* out, void* stream);
 int ssr_metric_ssim_sums(const uint8_t* a, const uint8_t* b, int32_t H, int32_t W, int32_t C, int32_t crop, double* out, void* stream);
+
+/* ---- VGG19 perceptual loss glue (csrc/vgg.hip; the convolutions run through ssr_conv2d with SSR_ACT_RELU / m_relu) ----
+ * ssr_channel_affine: y[p, c] (+)= x[p, c] * scale[c] + shift[c] for c < C <= 8 (host float arrays, copied into the launch):
+ *   the input normalisation (x - mean) / std of the feature extractor and, with accumulate = 1, its adjoint.
+ * ssr_relu_maxpool2_fwd: P[N, H/2, W/2, C] = maxpool2x2(relu(F[N, H, W, C])), H and W even.
+ * ssr_relu_maxpool2_bwd: gF (+)= the adjoint: each window's gradient goes to its first maximum (row-major) if F there is > 0. */
+typedef struct ssr_vec8 { float v[8]; } ssr_vec8;
+int ssr_channel_affine(ssr_view x, ssr_view y, int32_t dtype, int64_t npix, int32_t C, const float* scale, const float* shift,
+                       int32_t accumulate, void* stream);
+int ssr_relu_maxpool2_fwd(ssr_view f, ssr_view p, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int ssr_relu_maxpool2_bwd(ssr_view f, ssr_view gp, ssr_view gf, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                          int32_t accumulate, void* stream);
+
+/* SSR_F32X3 weight gradients: split an fp32 buffer (n % 4 == 0 elements) into bf16 planes hi = bf16(x), lo = bf16(x - hi); the
+ * bf16 wgrad kernel then accumulates (x_hi, dy_hi) + (x_hi, dy_lo) + (x_lo, dy_hi) into the fp32 gradient. */
+int ssr_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
 /* library / device info: writes "gfx950 CUs=256 ..." style text */
 int ssr_device_info(char* buf, int32_t buflen);

@@ -95,6 +95,9 @@ class Prec:
     def act(self, pre):  # LeakyReLU output stored in HBM; its gradient buffer holds the PRE-activation gradient
         return F.leaky_relu(pre, LRELU_SLOPE)
 
+    def act_relu(self, pre):  # same for the ReLU layers of the VGG19 feature extractor
+        return F.relu(pre)
+
 
 class _PrecBF16(Prec):
     name = "bf16"
@@ -112,6 +115,9 @@ class _PrecBF16(Prec):
         # forward: round(lrelu(acc)) in the producer's epilogue; backward: the consumer-side epilogue applies the
         # LeakyReLU mask to the fp32 gradient sum and THEN rounds (the buffers hold pre-activation gradients)
         return _RoundFwd.apply(F.leaky_relu(_RoundBwd.apply(pre), LRELU_SLOPE))
+
+    def act_relu(self, pre):
+        return _RoundFwd.apply(F.relu(_RoundBwd.apply(pre)))
 
 
 FP32 = Prec()
@@ -402,6 +408,86 @@ def usm_sharp(img: torch.Tensor, weight: float = 0.5, threshold: float = 10.0, r
     return soft * sharp + (1 - soft) * img
 
 
+# ----------------------------------------------------------------------------
+# Perceptual loss: basicsr PerceptualLoss + VGGFeatureExtractor (basicsr==1.4.2, basicsr/losses/basic_loss.py and
+# basicsr/archs/vgg_arch.py; not on disk: restated from the published source, parity unpinned by the reference) as configured
+# by ssr/options/esrgan_s2naip_urban.yml:123-137 and called at ssr/models/ssr_esrgan_model.py:153-160.
+# The network is torchvision's vgg19().features (requirements.txt:12 torchvision==0.16.0): 16 3x3 convolutions with ReLU,
+# 2x2 max-pooling after conv1_2 / conv2_2 / conv3_4 / conv4_4; features are read at the NAMED layer ('convX_Y' = before the ReLU).
+# ----------------------------------------------------------------------------
+VGG19_LAYERS = []            # [(name, kind, torchvision features index)]
+_idx = 0
+for _blk, _n in enumerate((2, 2, 4, 4, 4), start=1):
+    for _j in range(1, _n + 1):
+        VGG19_LAYERS.append((f"conv{_blk}_{_j}", "conv", _idx)); _idx += 1
+        VGG19_LAYERS.append((f"relu{_blk}_{_j}", "relu", _idx)); _idx += 1
+    if _blk < 5:
+        VGG19_LAYERS.append((f"pool{_blk}", "pool", _idx)); _idx += 1
+VGG19_WIDTHS = {1: 64, 2: 128, 3: 256, 4: 512, 5: 512}
+VGG_MEAN = (0.485, 0.456, 0.406)     # VGGFeatureExtractor.use_input_norm: the ImageNet statistics, image in [0, 1]
+VGG_STD = (0.229, 0.224, 0.225)
+
+
+def vgg19_init(seed: Optional[int] = None):
+    """torchvision VGG._initialize_weights: kaiming_normal_(mode='fan_out', nonlinearity='relu'), zero bias; keys as in the
+    torchvision checkpoint (`features.{idx}.weight`).  (The published weights vgg19-dcbb9e9d.pth cannot be fetched here:
+    random weights of the same architecture for throughput and parity.)"""
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    sd = OrderedDict()
+    cin = 3
+    for name, kind, idx in VGG19_LAYERS:
+        if kind != "conv":
+            continue
+        cout = VGG19_WIDTHS[int(name[4])]
+        sd[f"features.{idx}.weight"] = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cout * 9))
+        sd[f"features.{idx}.bias"] = torch.zeros(cout)
+        cin = cout
+    return sd
+
+
+def vgg19_features(sd, x: torch.Tensor, layer_names, use_input_norm: bool = True, range_norm: bool = False,
+                   prec: Prec = FP32) -> Dict[str, torch.Tensor]:
+    """VGGFeatureExtractor.forward: {name: activation at that layer} for the requested names."""
+    if range_norm:
+        x = (x + 1) / 2
+    if use_input_norm:
+        mean = torch.tensor(VGG_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+        std = torch.tensor(VGG_STD, dtype=x.dtype).view(1, 3, 1, 1)
+        x = (x - mean) / std
+    x = prec.a(x)
+    want, out = set(layer_names), {}
+    last = max(i for i, (n, _, _) in enumerate(VGG19_LAYERS) if n in want)
+    pre = None
+    for name, kind, idx in VGG19_LAYERS[:last + 1]:
+        if kind == "conv":
+            pre = F.conv2d(x, prec.w(sd[f"features.{idx}.weight"]), sd[f"features.{idx}.bias"], padding=1)
+            if name in want:                      # a tapped conv output is stored as it is; its ReLU is applied by the consumer
+                pre = prec.a(pre)
+                out[name] = pre
+                x = pre
+            else:
+                x = None
+        elif kind == "relu":
+            x = F.relu(x) if x is not None else prec.act_relu(pre)
+            if name in want:
+                out[name] = x
+        else:
+            x = prec.a(F.max_pool2d(x, 2, 2))
+    return out
+
+
+def perceptual_loss(vgg_sd, x, gt, layer_weights: Dict[str, float], perceptual_weight: float = 1.0, use_input_norm=True,
+                    range_norm=False, prec: Prec = FP32):
+    """PerceptualLoss.forward with criterion 'l1', style_weight 0: sum_k w_k * mean|vgg_k(x) - vgg_k(gt)| * perceptual_weight."""
+    fx = vgg19_features(vgg_sd, x, layer_weights.keys(), use_input_norm, range_norm, prec)
+    with torch.no_grad():
+        fg = vgg19_features(vgg_sd, gt.detach(), layer_weights.keys(), use_input_norm, range_norm, prec)
+    loss = 0
+    for k, w in layer_weights.items():
+        loss = loss + F.l1_loss(prec.g(fx[k]), fg[k]) * w
+    return loss * perceptual_weight
+
+
 def l1_loss(pred, target, weight=1.0):
     """basicsr L1Loss(loss_weight, reduction='mean'); call site ssr_esrgan_model.py:148."""
     return weight * F.l1_loss(pred, target, reduction="mean")
@@ -465,6 +551,8 @@ class StepConfig:
     l1_gt_usm: bool = False        # ssr_esrgan_model.py:121-129 (the measured configuration uses the plain gt)
     gan_gt_usm: bool = False
     prec: Prec = FP32              # FP32 = the reference's arithmetic; BF16 = model of the HIP throughput mode
+    percep_gt_usm: bool = False
+    perceptual: Optional[Dict] = None   # train.perceptual_opt (layer_weights, perceptual_weight, use_input_norm, range_norm)
 
 
 class ESRGANOracle:
@@ -473,8 +561,10 @@ class ESRGANOracle:
 
     State is held as plain dicts in the reference's state_dict layout."""
 
-    def __init__(self, g_sd, d_sd, cfg: StepConfig = StepConfig()):
+    def __init__(self, g_sd, d_sd, cfg: StepConfig = StepConfig(), vgg_sd=None):
         self.cfg = cfg
+        self.vgg = None if vgg_sd is None else OrderedDict((k, v.detach().clone().float()) for k, v in vgg_sd.items())
+        assert not cfg.perceptual or self.vgg is not None, "perceptual_opt needs VGG19 weights"
         self.g = OrderedDict((k, v.detach().clone().float()) for k, v in g_sd.items())
         self.d = OrderedDict((k, v.detach().clone().float()) for k, v in d_sd.items())
         self.g_ema = OrderedDict((k, v.clone()) for k, v in self.g.items())  # model_ema(0), :49
@@ -498,9 +588,10 @@ class ESRGANOracle:
         log = OrderedDict()
         with torch.no_grad():
             lr = prec.a(lr)
-            gt_usm = usm_sharp(gt) if (cfg.l1_gt_usm or cfg.gan_gt_usm) else None   # :109
+            gt_usm = usm_sharp(gt) if (cfg.l1_gt_usm or cfg.gan_gt_usm or (cfg.perceptual and cfg.percep_gt_usm)) else None   # :109
             l1_gt = prec.a(gt_usm if cfg.l1_gt_usm else gt)                          # :121-129
             gan_gt = prec.a(gt_usm if cfg.gan_gt_usm else gt)
+            percep_gt = prec.a(gt_usm if cfg.percep_gt_usm else gt) if cfg.perceptual else None
             old_hr = prec.a(old_hr) if old_hr is not None else None
             gt = gan_gt
         lr_resized = F.interpolate(lr, scale_factor=4)  # :133 (nearest)
@@ -514,6 +605,12 @@ class ESRGANOracle:
                                                 prec=prec)
             l_g_gan = gan_loss_vanilla(fake_g_pred, True, is_disc=False, loss_weight=cfg.gan_weight)
             l_g_total = l_g_pix + l_g_gan
+            if cfg.perceptual:                                                           # :153-160
+                po = cfg.perceptual
+                l_g_percep = perceptual_loss(self.vgg, output, percep_gt, po["layer_weights"], float(po.get("perceptual_weight", 1.0)),
+                                             po.get("use_input_norm", True), po.get("range_norm", False), prec)
+                l_g_total = l_g_total + l_g_percep
+                log["l_g_percep"] = l_g_percep.item()
             grads = torch.autograd.grad(l_g_total, list(gp.values()))
             log["l_g_pix"], log["l_g_gan"] = l_g_pix.item(), l_g_gan.item()
             self.g_grads = OrderedDict(zip(gp.keys(), grads))

@@ -79,8 +79,15 @@ def conv_dw(x, dy, wshape, stride=1, pad=1):
     return conv2d_weight(x, wshape, dy, stride=stride, padding=pad)
 
 
+def bf16_ulp(v: torch.Tensor) -> torch.Tensor:
+    """spacing of bfloat16 (8 significant bits) at |v|"""
+    return torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(1e-38))) - 7)
+
+
 class Report:
-    """Collects per-layer errors: err = max|dev - ref| / max|ref|, and the fraction of elements that differ at all."""
+    """Collects per-layer errors.  Row = (layer, max|dev - ref| / max|ref|, mean|dev - ref| / max|ref|, fraction of elements
+    that differ at all, largest difference in bf16 ulps of the element — ignoring differences below 1e-5 * max|ref|, where
+    fp32 cancellation noise of a near-zero sum can exceed the element's own ulp)."""
 
     def __init__(self):
         self.rows: List[tuple] = []
@@ -90,7 +97,16 @@ class Report:
         assert dev.shape == ref.shape, (what, dev.shape, ref.shape)
         scale = float(ref.abs().max()) + 1e-30
         d = (dev - ref).abs()
-        self.rows.append((what, float(d.max()) / scale, float(d.mean()) / scale, float((d > 0).float().mean())))
+        big = d > 1e-5 * scale
+        ulps = float((d[big] / bf16_ulp(torch.maximum(ref.abs(), dev.abs())[big])).max()) if bool(big.any()) else 0.0
+        self.rows.append((what, float(d.max()) / scale, float(d.mean()) / scale, float((d > 0).float().mean()), ulps))
+
+    def check_bf16(self, max_ulps: float = 1.0, max_frac: float = 2e-3, tol_mean: float = 1e-5):
+        """bf16 storage: a stored value may land on the adjacent bf16 value (the fp32 sum it rounds was accumulated in another
+        order) — never further, only on a small fraction of the elements, and without any systematic component."""
+        bad = [r for r in self.rows if r[4] > max_ulps or r[3] > max_frac or r[2] > tol_mean]
+        assert not bad, f"{len(bad)} of {len(self.rows)} layers out of tolerance (ulps {max_ulps}, differing fraction {max_frac}, " \
+                        f"mean {tol_mean}); worst: {sorted(bad, key=lambda r: -r[4])[:6]}"
 
     def worst(self, prefix: str = ""):
         rows = [r for r in self.rows if r[0].startswith(prefix)]
@@ -103,7 +119,8 @@ class Report:
 
     def summary(self) -> Dict[str, float]:
         return {"layers": len(self.rows), "worst_max": max(r[1] for r in self.rows),
-                "worst_mean": max(r[2] for r in self.rows), "worst_layer": max(self.rows, key=lambda r: r[1])[0]}
+                "worst_mean": max(r[2] for r in self.rows), "worst_frac_differing": max(r[3] for r in self.rows),
+                "worst_ulps": max(r[4] for r in self.rows), "worst_layer": max(self.rows, key=lambda r: r[1])[0]}
 
 
 # ---------------------------------------------------------------------------------------------------------

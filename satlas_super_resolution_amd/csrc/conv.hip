@@ -305,6 +305,240 @@ int dispatch_geom(const ssr_conv_desc& d, hipStream_t st) {
     return SSR_EUNSUP;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SSR_F32X3: fp32 tensors in HBM, bf16 matrix cores with split operands.  There is no TF32 on gfx950 and the fp32-input
+// MFMA runs at 1/16 of the bf16 rate; an fp32 value x is split as x = hi + lo + O(2^-17 x) with hi = bf16(x), lo = bf16(x - hi)
+// and a product is formed as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  (three v_mfma_f32_32x32x16_bf16 into the same fp32
+// accumulator; the dropped lo*lo term is 2^-16 relative).  The split happens ONCE per staged element, when the register-staged
+// chunk is written to LDS: a 16-channel chunk of a pixel (64 B of fp32) becomes 16 hi + 16 lo bf16 (the same 64 B), rows keep
+// the conflict-free 80-byte pitch.  Everything else (pipelining, epilogue, packed-weight format [chunk][tap][co][16] fp32)
+// is the fp32 kernel's.  KS = 2 splits the taps of a chunk by parity between the two waves of a pixel group.
+// Stride-1 2x2 / 3x3 layers; the 4x4 stride-2 layers keep the exact fp32 kernel (two 20 KB-per-row-block stages of their
+// 18x34 patch would not fit the LDS at 16 channels per chunk).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const u32x4& v, uint2& hi, uint2& lo) {
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    bf16x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = (__bf16)f[k];
+        l[k] = (__bf16)(f[k] - (float)h[k]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+template <int KH, int KW, int NT, int MW, int KS>
+__device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
+    constexpr int VEC = 4, CK = 16, VPR = 4, ROWB = 80, BN = 32 * NT, S = 1;
+    constexpr int TH = 2 * MW, TW = 16;
+    constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+    constexpr int NTHR = 64 * MW * KS;
+    constexpr int PVEC = PH * PW * VPR, WVEC = KH * KW * BN * VPR;
+    constexpr int NPV = (PVEC + NTHR - 1) / NTHR, NWV = (WVEC + NTHR - 1) / NTHR;
+    constexpr int STAGE = (PH * PW + KH * KW * BN) * ROWB;   // bytes per LDS stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MW, kh = wave / MW;
+    const int tiles_x = (d.Gw + TW - 1) / TW, tiles_y = (d.Gh + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * TH, gx0 = tx_i * TW;
+    const int co0 = blockIdx.y * BN;
+
+    const float* __restrict__ xg = reinterpret_cast<const float*>(d.x.p);
+    const float* __restrict__ wg = reinterpret_cast<const float*>(d.w);
+    const float* __restrict__ x2g = reinterpret_cast<const float*>(d.x2.p);
+    const int upshift = d.up == 2 ? 1 : 0;
+    const int LH = d.Hi << upshift, LW = d.Wi << upshift;
+    const int Ktot = d.Cin + d.Cin2;
+    const int nchunks = (Ktot + CK - 1) / CK;
+    const size_t wchunk = (size_t)KH * KW * d.CoutPad * CK;
+
+    int pgo[NPV], pgo2[NPV], plo[NPV], pch[NPV];
+    int wgo[NWV], wlo[NWV];
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) {
+        const int v = tid + q * NTHR;
+        const int pix = v / VPR, part = v - pix * VPR;
+        const int py = pix / PW, px = pix - py * PW;
+        const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
+        const bool ok = v < PVEC && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+        pgo[q] = ok ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * VEC) : -1;
+        pgo2[q] = (ok && x2g) ? (int)(((size_t)(n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift)) * d.x2.cs + d.x2.coff + part * VEC)
+                              : -1;
+        plo[q] = v < PVEC ? pix * ROWB + part * 8 : -1;          // hi half of the row; lo half 32 bytes further
+        pch[q] = part * VEC;
+    }
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) {
+        const int v = tid + q * NTHR;
+        const int row = v / VPR, part = v - row * VPR;
+        const int tap = row / BN, co = row - tap * BN;
+        wgo[q] = v < WVEC ? (tap * d.CoutPad + co0 + co) * CK + part * VEC : -1;
+        wlo[q] = (PH * PW + row) * ROWB + part * 8;
+    }
+    u32x4 rp[NPV], rw[NWV];
+    auto load_chunk = [&](int c) {
+        const int c0 = c * CK;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            u32x4 val = {0u, 0u, 0u, 0u};
+            const int k0 = c0 + pch[q];
+            if (pgo[q] >= 0) {
+                if (k0 < d.Cin) val = *reinterpret_cast<const u32x4*>(xg + (size_t)pgo[q] + c0);
+                else if (k0 < Ktot) val = *reinterpret_cast<const u32x4*>(x2g + (size_t)pgo2[q] + (c0 - d.Cin));
+            }
+            rp[q] = val;
+        }
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            if (wgo[q] >= 0) rw[q] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[q]);
+    };
+    auto store_chunk = [&](int stage) {
+        char* base = smem + stage * STAGE;
+        uint2 hi, lo;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q)
+            if (plo[q] >= 0) {
+                split4(rp[q], hi, lo);
+                *reinterpret_cast<uint2*>(base + plo[q]) = hi;
+                *reinterpret_cast<uint2*>(base + plo[q] + 32) = lo;
+            }
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            if (wgo[q] >= 0) {
+                split4(rw[q], hi, lo);
+                *reinterpret_cast<uint2*>(base + wlo[q]) = hi;
+                *reinterpret_cast<uint2*>(base + wlo[q] + 32) = lo;
+            }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int i = lane & 31, g = lane >> 5;
+    const int ty = 2 * wm + (i >> 4), tx = i & 15;
+    const int a_off = (ty * PW + tx) * ROWB + g * 16;               // lane (i, g): channels g*8 .. g*8+7 of pixel i
+    const int b_off = (PH * PW + i) * ROWB + g * 16;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next = c + 1 < nchunks;
+        if (has_next) load_chunk(c + 1);
+        const char* ab = smem + (c & 1) * STAGE + a_off;
+        const char* bb = smem + (c & 1) * STAGE + b_off;
+#pragma unroll
+        for (int tap = 0; tap < KH * KW; ++tap) {
+            if (KS == 2 && (tap & 1) != kh) continue;                // wave-uniform: the two k-halves take alternate taps
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(ab + (ky * PW + kx) * ROWB);
+            const bf16x8 alo = *reinterpret_cast<const bf16x8*>(ab + (ky * PW + kx) * ROWB + 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(bb + (tap * BN + t * 32) * ROWB);
+                const bf16x8 blo = *reinterpret_cast<const bf16x8*>(bb + (tap * BN + t * 32) * ROWB + 32);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[t], 0, 0, 0);
+            }
+        }
+        if (has_next) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+
+    char* slab = smem + (size_t)MW * 16 * 64 * sizeof(float) + (size_t)wave * EPI_STAGE_BYTES;
+    auto epilogue = [&](const f32x16& a, int t) {
+        conv_epilogue<float>(d, a, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+    };
+    if (KS == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) epilogue(acc[t], t);
+    } else {
+        // combine the two tap halves through LDS; with NT == 2 each half finishes one of the two output tiles
+        float* red = reinterpret_cast<float*>(smem);          // [MW][16][64]
+        float* mine = red + (wm * 16) * 64 + lane;
+        if (NT == 2) {
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[1][r];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][r] += mine[r * 64];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            } else {
+                epilogue(acc[1], 1);
+            }
+        } else {
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            }
+        }
+    }
+}
+
+template <int KH, int KW, int NT, int MW, int KS>
+__global__ __launch_bounds__(64 * MW * KS) void conv_x3_kernel(const ssr_conv_desc d) {
+    conv_body_x3<KH, KW, NT, MW, KS>(d);
+}
+
+template <int KH, int KW, int NT, int MW, int KS>
+int launch_conv_x3(const ssr_conv_desc& d, hipStream_t st) {
+    constexpr int BN = 32 * NT, TH = 2 * MW, TW = 16, PH = TH - 1 + KH, PW = TW - 1 + KW;
+    constexpr size_t stage = (size_t)(PH * PW + KH * KW * BN) * 80;
+    constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
+    constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_x3_kernel<KH, KW, NT, MW, KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, 1), dim3(64 * MW * KS), lds, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+template <int KH, int KW>
+int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
+    bool nt2, small;
+    pick_tile(d, nt2, small);
+    if (nt2) return small ? launch_conv_x3<KH, KW, 2, 2, 2>(d, st) : launch_conv_x3<KH, KW, 2, 4, 2>(d, st);
+    return small ? launch_conv_x3<KH, KW, 1, 2, 2>(d, st) : launch_conv_x3<KH, KW, 1, 4, 2>(d, st);
+}
+
 bool view_ok(const ssr_view& v, bool required) {
     if (!v.p) return !required;
     return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0;
@@ -345,13 +579,14 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
 }
 
 extern "C" int ssr_conv2d_ck(int32_t dtype, int32_t KH) {
-    const int vec = dtype == SSR_F32 ? 4 : 8;
+    const int vec = dtype == SSR_BF16 ? 8 : 4;      // SSR_F32X3 packs like SSR_F32
     return (KH == 4 ? 1 : 2) * 2 * vec;
 }
 
 static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     if (!dp) return SSR_EINVAL;
     const ssr_conv_desc& d = *dp;
+    if (d.act < SSR_ACT_NONE || d.act > SSR_ACT_RELU) return SSR_EINVAL;
     if (!view_ok(d.x, true) || !d.w || ((uintptr_t)d.w % 16) != 0) return SSR_EINVAL;
     if (!d.y.p || d.y.cs <= 0) return SSR_EINVAL;
     if (d.Cin <= 0 || (d.Cin % 8) != 0 || d.CoutPad <= 0 || (d.CoutPad % 32) != 0 || d.Cout > d.CoutPad)
@@ -369,6 +604,14 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
         e.KH = e.KW = 2; e.stride = 1; e.pad_y = e.pad_x = 0; e.Cin = 4 * d.Cin;
         return ssr_conv_big_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
     }
+    if (d.dtype == SSR_F32X3) {   // fp32 storage, split-bf16 matrix math (stride-1 2x2 / 3x3); 4x4 stride 2: the exact fp32 kernel
+        if (d.KH == 3 && d.KW == 3 && d.stride == 1) return dispatch_tile_x3<3, 3>(d, st);
+        if (d.KH == 2 && d.KW == 2 && d.stride == 1) return dispatch_tile_x3<2, 2>(d, st);
+        ssr_conv_desc e = d;
+        e.dtype = SSR_F32;
+        return dispatch_geom<float>(e, st);
+    }
+    if (d.act == SSR_ACT_RELU || d.m_relu) impl = 3;   // ReLU epilogues exist only in the pipelined kernel (conv_epilogue.h)
     if (impl == 1) return ssr_conv_ws_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
     if (impl == 4) return ssr_conv_big_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
     if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;

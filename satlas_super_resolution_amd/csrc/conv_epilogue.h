@@ -70,11 +70,12 @@ __device__ __forceinline__ void conv_epilogue(const ssr_conv_desc& d, const f32x
     for (int r = 0; r < 16; ++r) {
         float v = acc[r] + bv;
         if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+        else if (d.act == SSR_ACT_RELU) v = fmaxf(v, 0.f);
         v *= d.alpha;
         s0[r] = v;
         v += (has_r1 ? d.beta1 * q1[r] : 0.f) + (has_r2 ? d.beta2 * q2[r] : 0.f) + (has_acc ? qa[r] : 0.f);
         s1[r] = v;
-        if (has_m) v *= lrelu_grad_from_out(qm[r]);
+        if (has_m) v *= d.m_relu ? (qm[r] > 0.f ? 1.f : 0.f) : lrelu_grad_from_out(qm[r]);
         s2[r] = v;
     }
     // ---- phase 3: stores ----

@@ -562,6 +562,7 @@ inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
     // a table of a few large layers (the discriminator: conv3 alone is 131k (co, ci) pairs x 16 taps) needs more than 64
     // workgroups per layer to fill the chip (r01 rocprofv3: 42 us for 35 MB); the generator's 351 small layers do not
@@ -574,6 +575,7 @@ extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items,
 }
 
 extern "C" int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_items, int32_t dtype, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
     dim3 grid(8, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_seg_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
@@ -584,6 +586,7 @@ extern "C" int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_it
 }
 
 extern "C" int ssr_add_views(ssr_view dst, ssr_view src, int32_t dtype, int64_t npix, int32_t C, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!dst.p || !src.p || npix <= 0 || C <= 0) return SSR_EINVAL;
     const int g = grid_for(npix * C, 256 * 4, 2048);
     if (dtype == SSR_F32)
@@ -597,6 +600,7 @@ extern "C" int ssr_add_views(ssr_view dst, ssr_view src, int32_t dtype, int64_t 
 
 extern "C" int ssr_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, ssr_view dst,
                                 int32_t dtype, int32_t unshuffle, int32_t up, float scale, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!src || !dst.p || unshuffle < 1 || up < 1 || H % unshuffle || W % unshuffle) return SSR_EINVAL;
     const long total = (long)N * C * H * W * up * up;
     if (dtype == SSR_F32)
@@ -612,6 +616,7 @@ extern "C" int ssr_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t 
 
 extern "C" int ssr_nhwc_to_nchw(ssr_view src, int32_t dtype, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
                                 void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!src.p || !dst) return SSR_EINVAL;
     const long total = (long)N * C * H * W;
     if (dtype == SSR_F32)
@@ -626,6 +631,7 @@ extern "C" int ssr_nhwc_to_nchw(ssr_view src, int32_t dtype, float* dst, int32_t
 }
 
 extern "C" int ssr_fill(void* p, int64_t n, int32_t dtype, float value, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!p || n < 0) return SSR_EINVAL;
     if (n == 0) return SSR_OK;
     if (dtype == SSR_F32)
@@ -639,6 +645,7 @@ extern "C" int ssr_fill(void* p, int64_t n, int32_t dtype, float value, void* st
 
 extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_t N, int32_t H, int32_t W,
                                   int32_t C, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!a.p || !y.p || (C % 8) != 0 || (a.cs % 8) || (a.coff % 8) || (y.cs % 8) || (y.coff % 8) ||
         (b.p && ((b.cs % 8) || (b.coff % 8))))
         return SSR_EINVAL;
@@ -658,6 +665,7 @@ extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dt
 template <int MODE>
 static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N, int32_t H,
                     int32_t W, int32_t C, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!dy.p || (!y.p && !y1.p) || (C % 8) != 0 || (dy.cs % 8) || (dy.coff % 8)) return SSR_EINVAL;
     const long total = (long)N * H * W * C / 4;
     if (total >= (1L << 31)) return SSR_EINVAL;               // the kernel indexes in 32 bits
@@ -673,10 +681,12 @@ static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m
 }
 extern "C" int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,
                                   int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     return up2x_bwd<0>(dy, r, y1, y, m, dtype, N, H, W, C, stream);
 }
 extern "C" int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,
                                  int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     return up2x_bwd<1>(dy, r, y1, y, m, dtype, N, H, W, C, stream);
 }
 
@@ -786,6 +796,7 @@ extern "C" int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32
 
 extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
                            float* loss_out, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!a.p || !b.p || npix <= 0 || C <= 0) return SSR_EINVAL;
     const int g = grid_for(npix * C, 256 * 4, 1024);
     if (dtype == SSR_F32)
@@ -801,6 +812,7 @@ extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype,
 
 extern "C" int ssr_bce_logits_loss(ssr_view x, ssr_view grad, int32_t dtype, int64_t npix, float target, float weight,
                                    float* loss_out, float* mean_out, void* stream) {
+    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!x.p || npix <= 0) return SSR_EINVAL;
     const int g = grid_for(npix, 256 * 4, 1024);
     if (dtype == SSR_F32)
@@ -844,4 +856,30 @@ extern "C" int ssr_device_info(char* buf, int32_t buflen) {
     return SSR_OK;
 }
 
-extern "C" int ssr_abi_version(void) { return 1; }
+// x -> (hi, lo) bf16 planes with x = hi + lo + O(2^-17 x): operands of the split-bf16 weight-gradient passes (SSR_F32X3)
+namespace {
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                         long n4) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[e];
+        bf16x4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (__bf16)v[k];
+            l[k] = (__bf16)(v[k] - (float)h[k]);
+        }
+        reinterpret_cast<bf16x4*>(hi)[e] = h;
+        reinterpret_cast<bf16x4*>(lo)[e] = l;
+    }
+}
+}  // namespace
+
+extern "C" int ssr_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    if (!x || !hi || !lo || n <= 0 || (n % 4) != 0) return SSR_EINVAL;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, ST(stream), x,
+                       reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), (long)(n / 4));
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+extern "C" int ssr_abi_version(void) { return 2; }

@@ -29,7 +29,7 @@ def rup(a: int, b: int) -> int:
 
 
 def ck_of(dt: int) -> int:
-    return 16 if dt == hip.F32 else 32
+    return 32 if dt == hip.BF16 else 16
 
 
 @dataclass
@@ -319,13 +319,13 @@ class _ConvBuilder:
     def dgrad(self, L: Launcher, name: str, dy: View, gh: int, gw: int, y: View, *, cout: Optional[int] = None,
               alpha=1.0, y1: View = hip.NULL_VIEW, r1: View = hip.NULL_VIEW, r1_nc=0, beta1=0.0,
               r2: View = hip.NULL_VIEW, r2_nc=0, beta2=0.0, accumulate=0, m: View = hip.NULL_VIEW, m_c0=0, m_c1=0,
-              cin_dy: Optional[int] = None):
+              cin_dy: Optional[int] = None, m_relu=0):
         """Gradient w.r.t. the conv input.  `dy` lives on the forward output grid (gh x gw).
         stride 1: one 3x3 conv with rotated weights; stride 2 (4x4): four 2x2 parity-class launches."""
         s = self.store.specs[name]
         _, _, cin_pad_o, cout_pad_i = self.store.pad[name]
         wbase = self.store.packed_dgrad[name].data_ptr()
-        esz = 4 if self.dt == hip.F32 else 2
+        esz = 2 if self.dt == hip.BF16 else 4
         classes = [(0, 0)] if s.stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
         arr = (ConvDesc * len(classes))()
         for ic, (py, px) in enumerate(classes):
@@ -355,6 +355,7 @@ class _ConvBuilder:
             d.r2, d.r2_nc, d.beta2 = r2, r2_nc, beta2
             d.accumulate = accumulate
             d.m, d.m_c0, d.m_c1 = m, m_c0, m_c1
+            d.m_relu = m_relu
         self.keep.append(arr)
         if len(classes) == 1:
             L.add(hip.lib().ssr_conv2d, C.byref(arr[0]), what=f"conv dgrad {name}")
@@ -392,40 +393,77 @@ def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View,
 
 
 class WgradBatch:
-    """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride)."""
+    """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride).
+
+    hip.F32X3 (fp32 storage, split-bf16 matrix math): the bf16 transpose-read kernel runs three times over bf16 hi/lo planes
+    of the fp32 buffers — (x_hi, dy_hi) + (x_hi, dy_lo) + (x_lo, dy_hi), accumulated in the fp32 gradient arena — after one
+    ssr_split_bf16 pass per distinct parent buffer (x = hi + lo to 2^-17; the dropped lo*lo term is 2^-16 relative)."""
 
     MAX_TILES_PER_ITEM = {3: 128, 4: 64}   # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits
 
     def __init__(self, dtype: int, k: int, stride: int):
         self.dtype, self.k, self.stride = dtype, k, stride
+        self.kdt = hip.BF16 if dtype == hip.F32X3 else dtype      # element type the wgrad kernel reads
         self.layers: List[WgradLayer] = []
         self.items: List[WgradItem] = []
         self.layer_tab = self.item_tab = None
+        self.split_tabs: List[torch.Tensor] = []
+        self.splits: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
 
     def add(self, x: View, dy: View, N, hi, wi, up, cin, cout, gh, gw, alpha, dw_ptr, cin_w, db_ptr):
         li = len(self.layers)
         self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, dw_ptr, cin_w, db_ptr))
-        tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.dtype, self.k)
+        tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.kdt, self.k)
         splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
         per = -(-tiles // splits)
         for co0 in range(0, cout, 32):
-            for ci0 in range(0, cin_w, hip.lib().ssr_wgrad_ci_tile(self.dtype, self.k)):
+            for ci0 in range(0, cin_w, hip.lib().ssr_wgrad_ci_tile(self.kdt, self.k)):
                 for sp in range(splits):
                     b, e = sp * per, min(tiles, (sp + 1) * per)
                     if b < e:
                         self.items.append(WgradItem(li, co0, ci0, b, e, 1 if splits > 1 else 0))
 
+    def _twin(self, v: View, which: int) -> View:
+        parent = hip.parent_of(v)
+        tw = getattr(parent, "_ssr_bf16_planes", None)     # the planes live and die with the buffer they mirror
+        if tw is None:
+            tw = (torch.empty_like(parent, dtype=torch.bfloat16), torch.empty_like(parent, dtype=torch.bfloat16))
+            parent._ssr_bf16_planes = tw
+        if all(parent is not e[0] for e in self.splits):
+            self.splits.append((parent, tw[0], tw[1]))
+        return View(tw[which].data_ptr(), v.cs, v.coff)
+
     def finalize(self):
-        if self.layers:
-            # heavy items first: better tail behaviour on 256 CUs
-            self.items.sort(key=lambda it: -(it.tile_end - it.tile_begin))
+        if not self.layers:
+            return
+        # heavy items first: better tail behaviour on 256 CUs
+        self.items.sort(key=lambda it: -(it.tile_end - it.tile_begin))
+        self.item_tab = hip.device_table(self.items)
+        if self.dtype != hip.F32X3:
             self.layer_tab = hip.device_table(self.layers)
-            self.item_tab = hip.device_table(self.items)
+            return
+        # three passes over hi/lo planes; the bias gradient (sum of dy) comes out of the first two (dy_hi + dy_lo)
+        for xi, dyi, with_bias in ((0, 0, True), (0, 1, True), (1, 0, False)):
+            tab = []
+            for L in self.layers:
+                tab.append(WgradLayer(self._twin(L.x, xi), self._twin(L.dy, dyi), L.N, L.Hi, L.Wi, L.up, L.Cin, L.Cout, L.pad_y,
+                                      L.pad_x, L.Gh, L.Gw, L.alpha, L.dw, L.Cin_w, L.db if with_bias else None))
+            self.split_tabs.append(hip.device_table(tab))
+        self.layer_tab = self.split_tabs[0]
 
     def launch(self, L: Launcher):
-        if self.layers:
-            L.add(hip.lib().ssr_conv2d_wgrad, self.layer_tab.data_ptr(), self.item_tab.data_ptr(), len(self.items),
-                  self.dtype, self.k, self.k, self.stride, what="wgrad batch")
+        if not self.layers:
+            return
+        lib = hip.lib()
+        if self.dtype == hip.F32X3:
+            for parent, hi_t, lo_t in self.splits:
+                L.add(lib.ssr_split_bf16, parent.data_ptr(), hi_t.data_ptr(), lo_t.data_ptr(), parent.numel(), what="split bf16")
+            for tab in self.split_tabs:
+                L.add(lib.ssr_conv2d_wgrad, tab.data_ptr(), self.item_tab.data_ptr(), len(self.items), hip.BF16, self.k, self.k,
+                      self.stride, what="wgrad batch (split pass)")
+            return
+        L.add(lib.ssr_conv2d_wgrad, self.layer_tab.data_ptr(), self.item_tab.data_ptr(), len(self.items),
+              self.dtype, self.k, self.k, self.stride, what="wgrad batch")
 
 
 # =====================================================================================================

@@ -15,8 +15,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssr_hip.so")
 
-F32, BF16 = 0, 1
-ACT_NONE, ACT_LRELU = 0, 1
+F32, BF16, F32X3 = 0, 1, 2    # F32X3: fp32 storage, split-bf16 matrix math (include/ssr_hip.h)
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 
 
 class HipLibraryError(RuntimeError):
@@ -46,7 +46,7 @@ class ConvDesc(C.Structure):
         ("r2", View), ("r2_nc", C.c_int32), ("beta2", C.c_float),
         ("accumulate", C.c_int32),
         ("m", View), ("m_c0", C.c_int32), ("m_c1", C.c_int32),
-        ("s2d", C.c_int32),
+        ("s2d", C.c_int32), ("m_relu", C.c_int32),
     ]
 
 
@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
-    "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums",
+    "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
     "ssr_device_info", "ssr_abi_version",
 ]
 
@@ -159,6 +159,10 @@ def lib() -> C.CDLL:
     l.ssr_quantize_u8.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     l.ssr_metric_shift_sums.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     l.ssr_metric_ssim_sums.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    l.ssr_split_bf16.argtypes = [vp, vp, vp, i64, vp]
+    l.ssr_channel_affine.argtypes = [View, View, i32, i64, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp]
+    l.ssr_relu_maxpool2_fwd.argtypes = [View, View, i32, i32, i32, i32, i32, vp]
+    l.ssr_relu_maxpool2_bwd.argtypes = [View, View, View, i32, i32, i32, i32, i32, i32, vp]
     l.ssr_device_info.argtypes = [C.c_char_p, i32]
     l.ssr_abi_version.argtypes = []
     for s in ABI_SYMBOLS:
@@ -178,15 +182,33 @@ def stream_ptr() -> int:
 
 
 def torch_dtype(dt: int):
-    return torch.float32 if dt == F32 else torch.bfloat16
+    return torch.bfloat16 if dt == BF16 else torch.float32
 
 
 def dtype_code(dt) -> int:
-    if dt in (F32, "fp32", "float32", torch.float32):
+    if isinstance(dt, str):
+        try:
+            return {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp32x3": F32X3, "bf16x3": F32X3}[dt]
+        except KeyError:
+            raise ValueError(f"unsupported compute dtype {dt!r}") from None
+    if dt is torch.float32:
         return F32
-    if dt in (BF16, "bf16", "bfloat16", torch.bfloat16):
+    if dt is torch.bfloat16:
         return BF16
+    if dt in (F32, BF16, F32X3):
+        return int(dt)
     raise ValueError(f"unsupported compute dtype {dt!r}")
+
+
+# NHWC parent tensors by base address: lets a consumer of channel views (the split-bf16 weight-gradient passes) find the
+# whole buffer a view points into
+import weakref  # noqa: E402
+
+_PARENTS = weakref.WeakValueDictionary()
+
+
+def parent_of(v: "View") -> torch.Tensor:
+    return _PARENTS[v.p]
 
 
 def view(t: Optional[torch.Tensor], coff: int = 0) -> View:
@@ -194,6 +216,7 @@ def view(t: Optional[torch.Tensor], coff: int = 0) -> View:
     if t is None:
         return View(None, 0, 0)
     assert t.is_contiguous()
+    _PARENTS[t.data_ptr()] = t
     return View(t.data_ptr(), t.shape[-1], coff)
 
 

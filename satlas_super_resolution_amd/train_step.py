@@ -73,10 +73,9 @@ class ESRGANTrainStep:
 
     def __init__(self, g_kwargs: Dict, d_kwargs: Dict, B: int, h: int, w: int, dtype="fp32",
                  cfg: StepConfig = StepConfig(), dp: Optional[DPContext] = None, use_graph: bool = True,
-                 g_store: Optional[engine.ParamStore] = None, d_store: Optional[engine.ParamStore] = None):
+                 g_store: Optional[engine.ParamStore] = None, d_store: Optional[engine.ParamStore] = None,
+                 vgg_state: Optional[Dict[str, torch.Tensor]] = None):
         assert g_kwargs.get("scale", 4) == 4, "the train step is defined for scale 4 (all shipped configs)"
-        if cfg.perceptual:
-            raise NotImplementedError("train.perceptual_opt (VGG19 perceptual loss): not built yet (SURVEY.md §8f rank 2)")
         self.cfg, self.B, self.h, self.w = cfg, B, h, w
         self.dt = hip.dtype_code(dtype)
         self.dp = dp if dp is not None else DPContext(None, 0, 1)
@@ -98,8 +97,17 @@ class ESRGANTrainStep:
         self.fake_in = z(B, H, W, cdp)      # [G output | lr_resized | old_hr]   (ssr_esrgan_model.py:171-178)
         self.real_in = z(B, H, W, cdp)      # [gt       | lr_resized | old_hr]   (:202-213)
         self.grad_l1 = z(B, H, W, cdp)
-        # L1 target: the D-real buffer unless exactly one of the two is USM-sharpened (ssr_esrgan_model.py:121-129)
-        self.l1_tgt = self.real_in if cfg.l1_gt_usm == cfg.gan_gt_usm else z(B, H, W, cdp)
+        # targets (ssr_esrgan_model.py:121-129): each of the L1 / perceptual / GAN-real targets is the ground truth or its
+        # USM-sharpened version; at most two distinct images exist, the D-real buffer holds the GAN one
+        by_flag = {bool(cfg.gan_gt_usm): self.real_in}
+
+        def target_for(flag: bool) -> torch.Tensor:
+            if flag not in by_flag:
+                by_flag[flag] = z(B, H, W, cdp)
+            return by_flag[flag]
+        self.l1_tgt = target_for(bool(cfg.l1_gt_usm))
+        self.percep_tgt = target_for(bool(cfg.percep_gt_usm)) if cfg.perceptual else None
+        self._tgt_by_flag = by_flag
         self._gt_usm = None   # fp32 NCHW scratch for ssr_usm_sharp
         self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
         self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
@@ -107,6 +115,12 @@ class ESRGANTrainStep:
                                                skip_connection=d_kwargs.get("skip_connection", True))
         self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in,
                                            d_out_buf=self.d_plan.g_in, **g_kwargs)
+        self.p_plan = None
+        if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
+            from .perceptual import PerceptualPlan
+            self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.dt, self.fake_in, self.percep_tgt, self.grad_l1,
+                                         self.losses.data_ptr() + 4 * 6, num_ch=cout, state=vgg_state)
+            self.p_plan.pack()
         self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
         self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas_d or cfg.betas, cfg.eps, 0.0)
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
@@ -147,19 +161,16 @@ class ESRGANTrainStep:
         gt = gt.contiguous()
         self.g_plan.load_input(lr, scale)
         gt_usm = None
-        if self.cfg.l1_gt_usm or self.cfg.gan_gt_usm:   # self.gt_usm = self.usm_sharpener(self.gt)  (:109)
+        if True in self._tgt_by_flag:   # self.gt_usm = self.usm_sharpener(self.gt)  (:109)
             if self._gt_usm is None:
                 self._gt_usm = torch.empty(self.B, self.cout, self.H, self.W, dtype=torch.float32, device=gt.device)
             hip.check(L.ssr_usm_sharp(gt.data_ptr(), self._gt_usm.data_ptr(), self.B * self.cout, self.H, self.W, scale,
                                       0.5, 10.0, st), "ssr_usm_sharp")
             gt_usm = self._gt_usm
-        gan_src, gan_scale = (gt_usm, 1.0) if self.cfg.gan_gt_usm else (gt, scale)
-        hip.check(L.ssr_nchw_to_nhwc(gan_src.data_ptr(), self.B, self.cout, self.H, self.W, view(self.real_in), self.dt, 1,
-                                     1, gan_scale, st), "gt->nhwc")
-        if self.l1_tgt is not self.real_in:
-            l1_src, l1_scale = (gt_usm, 1.0) if self.cfg.l1_gt_usm else (gt, scale)
-            hip.check(L.ssr_nchw_to_nhwc(l1_src.data_ptr(), self.B, self.cout, self.H, self.W, view(self.l1_tgt), self.dt, 1,
-                                         1, l1_scale, st), "l1 target->nhwc")
+        for flag, buf in self._tgt_by_flag.items():      # one NHWC copy per distinct target image
+            src, sc = (gt_usm, 1.0) if flag else (gt, scale)
+            hip.check(L.ssr_nchw_to_nhwc(src.data_ptr(), self.B, self.cout, self.H, self.W, view(buf), self.dt, 1, 1, sc, st),
+                      "target->nhwc")
         if self.cfg.feed_disc_lr:   # lr_resized = F.interpolate(lr, scale_factor=4) (nearest), :133
             for buf in (self.real_in, self.fake_in):
                 hip.check(L.ssr_nchw_to_nhwc(lr.data_ptr(), self.B, self.cin, self.h, self.w,
@@ -195,6 +206,10 @@ class ESRGANTrainStep:
         hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.dt,
                                         self.B * self.H * self.W, self.cout, cfg.l1_weight, self.losses.data_ptr(),
                                         hip.stream_ptr()), "ssr_l1_loss")   # :147-150
+        if self.p_plan is not None:                                        # :153-160
+            self.p_plan.fwd_target.run()
+            self.p_plan.fwd.run()
+            self.p_plan.bwd.run()
         self._d_forward(self.fake_in)                                      # :181
         self._bce(cfg.real_label, cfg.gan_weight, 1, None)                 # :182 (is_disc=False)
         self.d_plan.backward_plan(self.fake_in, param_grads=False, input_grad=True,
@@ -295,7 +310,10 @@ class ESRGANTrainStep:
     def log(self) -> "OrderedDict[str, float]":
         """get_current_log(): one host sync, only when the caller logs (train.py:116-121)."""
         vals = self.dp.reduce_scalars(self.losses).tolist()
-        return OrderedDict((k, vals[i]) for i, k in enumerate(LOSS_KEYS))
+        out = OrderedDict((k, vals[i]) for i, k in enumerate(LOSS_KEYS))
+        if self.p_plan is not None:
+            out["l_g_percep"] = vals[6]
+        return out
 
     def output(self) -> torch.Tensor:
         """self.output (NCHW fp32) of the last generator forward."""

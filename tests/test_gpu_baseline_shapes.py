@@ -7,8 +7,12 @@ Two kinds of check, both against the CPU oracle (never kernel against kernel):
    stored activation, every gradient buffer and every parameter gradient of a full forward + backward is recomputed
    on the CPU from the device's own inputs of that layer.  This is what holds each kernel family (fused dense block
    forward/backward, weight-stationary, big-tile 3x3 / 2x2-parity / space-to-depth, thin-output, K-resident, pipelined;
-   bf16 transpose-read wgrad) to <= 4e-3 * max|ref| per layer in bf16 mode (the only legitimate difference: a bf16 store
-   on the other side of a rounding boundary) and to 1e-4 in the fp32 modes — at the batch and depth of the benchmark.
+   bf16 transpose-read wgrad) in bf16 mode to: every stored value within ONE bf16 ulp of the reference (the only
+   legitimate difference: a store on the other side of a rounding boundary because fp32 partial sums were added in another
+   order), at most 0.2 % of a layer's values differing at all (measured: 0.015 %), mean error <= 1e-5 * max|ref| (measured:
+   3e-8; a 1 % bug in any layer is 1e-2) — and to 1e-4 * max|ref| in the fp32 modes (measured 2e-6), at the batch and depth
+   of the benchmark.  (A single bf16 ulp at a layer's largest value is up to 2^-7 = 7.8e-3 of max|ref|, so a plain
+   max-norm bound cannot go below that without being violated by rounding alone: r02a measured 4-6e-3 on 28 of 351 layers.)
  * end-to-end: generator forward and one whole optimize_parameters() against the oracle in the same precision model
    (fp32 modes: the north-star 1e-3 gate; bf16: the bf16 oracle, tolerance stated at the assert).
 """
@@ -36,21 +40,10 @@ def _tols(mode):
 
 
 def _set_mode(mode):
-    """'fp32' = exact fp32 MFMA; 'fp32x3' = fp32 storage, three bf16 MFMAs per product (split operands)."""
+    """'bf16' = bf16 storage + MFMA; 'fp32' = exact fp32 MFMA; 'fp32x3' = fp32 storage, three bf16 MFMAs per product (split
+    operands, include/ssr_hip.h SSR_F32X3).  The arithmetic is a property of the plan (its dtype code)."""
     from satlas_super_resolution_amd import hip
-    if hasattr(hip, "set_fp32_math"):
-        hip.set_fp32_math("x3" if mode == "fp32x3" else "exact")
-    elif mode == "fp32x3":
-        pytest.skip("split-bf16 fp32 mode not built")
-    return hip.dtype_code("bf16" if mode == "bf16" else "fp32")
-
-
-@pytest.fixture(autouse=True)
-def _restore_math_mode():
-    yield
-    from satlas_super_resolution_amd import hip
-    if hasattr(hip, "set_fp32_math"):
-        hip.set_fp32_math("exact")
+    return hip.dtype_code(mode)
 
 
 def _gen_state(c_in, nb, seed=11):
@@ -101,10 +94,11 @@ def test_generator_every_layer_at_baseline_shape(mode, c_in, B):
     (amax, amean), (wmax, wmean) = _tols(mode)
     if mode == "fp32x3":
         amax, amean, wmax, wmean = 2e-4, 2e-5, 2e-4, 2e-5     # split operands: ~2^-16 relative per product
+    chk = (lambda r: r.check_bf16()) if mode == "bf16" else (lambda r: r.check(amax, amean))
     rep = LW.Report()
     LW.generator_forward_layers(sd, bufs, NF, GC, nb, lmode, rep)
     assert len(rep.rows) == 1 + 5 * 69 + 1 + 2 + 2
-    rep.check(amax, amean)
+    chk(rep)
     fwd = rep.summary()
     rep = LW.Report()
     LW.generator_backward_layers(sd, bufs, gb, grads, NF, GC, nb, lmode, rep, fused_bwd_weights=plan.fused_rdb)
@@ -112,7 +106,7 @@ def test_generator_every_layer_at_baseline_shape(mode, c_in, B):
     rep_w.rows = [r for r in rep.rows if r[0].startswith(("wgrad", "bgrad"))]
     rep.rows = [r for r in rep.rows if not r[0].startswith(("wgrad", "bgrad"))]
     assert len(rep.rows) == 5 * 69 + 2 + 4 + 1 and len(rep_w.rows) >= 351
-    rep.check(amax, amean)
+    chk(rep)
     rep_w.check(wmax, wmean)
     print(f"\n[layerwise G {mode} C_in={c_in} B={B}] fwd {fwd} | bwd {rep.summary()} | wgrad {rep_w.summary()}")
 
@@ -172,16 +166,17 @@ def test_discriminator_every_layer_at_baseline_shape(mode, c_d, B):
     (amax, amean), (wmax, wmean) = _tols(mode)
     if mode == "fp32x3":
         amax, amean, wmax, wmean = 2e-4, 2e-5, 2e-4, 2e-5
+    chk = (lambda r: r.check_bf16()) if mode == "bf16" else (lambda r: r.check(amax, amean))
     rep = LW.Report()
     LW.discriminator_forward_layers(wts, bias, x_in, bufs, True, lmode, rep)
-    rep.check(amax, amean)
+    chk(rep)
     fwd = rep.summary()
     rep = LW.Report()
     LW.discriminator_backward_layers(wts, x_in, bufs, gb, wgr, True, lmode, rep, in_residual=_nchw(resid, 0, c_d))
     rep_w = LW.Report()
     rep_w.rows = [r for r in rep.rows if r[0].startswith("wgrad")]
     rep.rows = [r for r in rep.rows if not r[0].startswith("wgrad")]
-    rep.check(amax, amean)
+    chk(rep)
     rep_w.check(wmax, wmean)
     print(f"\n[layerwise D {mode} C_d={c_d} B={B}] fwd {fwd} | bwd {rep.summary()} | wgrad {rep_w.summary()}")
 
@@ -224,8 +219,7 @@ def test_train_step_full_depth_vs_oracle(mode, c_in, feed_disc_lr):
     discriminator of `feed_disc_lr`."""
     from oracle import esrgan_oracle as O
     from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
-    dt_name = "bf16" if mode == "bf16" else "fp32"
-    _set_mode(mode)
+    dt_name = mode
     c_d = 3 + (c_in if feed_disc_lr else 0)
     kw, g0 = _gen_state(c_in, 23, seed=7)
     d_kw = dict(num_in_ch=c_d, num_feat=NF, skip_connection=True)
@@ -278,9 +272,8 @@ def test_infer_grid_tile_end_to_end_vs_oracle(mode):
     from oracle import esrgan_oracle as O
     from satlas_super_resolution_amd.archs.rrdbnet_arch import SSR_RRDBNet
     from satlas_super_resolution_amd.utils import infer_utils as U
-    _set_mode(mode)
     kw, sd = _gen_state(24, 23, seed=13)
-    net = SSR_RRDBNet(compute_dtype="fp32", **kw)
+    net = SSR_RRDBNet(compute_dtype=mode, **kw)
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
     rng = np.random.RandomState(4)

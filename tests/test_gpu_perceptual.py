@@ -1,0 +1,133 @@
+"""GPU: VGG19 perceptual loss (perceptual.py + csrc/vgg.hip + the ReLU epilogues of the conv kernels) against the oracle's
+restatement of BasicSR's PerceptualLoss (oracle/esrgan_oracle.py: vgg19_features / perceptual_loss), and the train step with the
+shipped option file's loss block."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, parity_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LW = {"conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1, "conv4_4": 1, "conv5_4": 1}       # esrgan_s2naip_urban.yml:125-131
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_relu_maxpool2_matches_torch(mode):
+    from satlas_super_resolution_amd import hip
+    dt = hip.dtype_code(mode)
+    tdt = hip.torch_dtype(dt)
+    torch.manual_seed(0)
+    f = torch.randn(2, 64, 12, 20)
+    f[0, :, 0:2, 0:2] = 0.75                       # ties: the first element of the window must receive the gradient
+    f[1, :, 2:4, 2:4] = -1.0                       # all negative: nothing passes
+    f = f.to(tdt).float()
+    gp = torch.randn(2, 64, 6, 10).to(tdt).float()
+    fr = f.clone().requires_grad_(True)
+    p_ref = F.max_pool2d(F.relu(fr), 2, 2)
+    (g_ref,) = torch.autograd.grad(p_ref, fr, gp)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(tdt).cuda()
+    fb, gpb = nhwc(f), nhwc(gp)
+    pb = torch.zeros(2, 6, 10, 64, dtype=tdt, device="cuda")
+    old = torch.randn(2, 12, 20, 64).to(tdt).cuda()
+    gfb = old.clone()
+    L = hip.lib()
+    hip.check(L.ssr_relu_maxpool2_fwd(hip.view(fb), hip.view(pb), dt, 2, 12, 20, 64, hip.stream_ptr()), "fwd")
+    hip.check(L.ssr_relu_maxpool2_bwd(hip.view(fb), hip.view(gpb), hip.view(gfb), dt, 2, 12, 20, 64, 1, hip.stream_ptr()), "bwd")
+    assert torch.equal(pb.float().cpu().permute(0, 3, 1, 2), p_ref.detach())
+    want = (old.float().cpu().permute(0, 3, 1, 2) + g_ref).to(tdt).float()
+    assert torch.equal(gfb.float().cpu().permute(0, 3, 1, 2), want)
+
+
+def _run_plan(mode, B, H, W, sd, x, gt):
+    from satlas_super_resolution_amd import hip
+    from satlas_super_resolution_amd.perceptual import PerceptualPlan
+    dt = hip.dtype_code(mode)
+    tdt = hip.torch_dtype(dt)
+    nhwc = lambda t: F.pad(t.permute(0, 2, 3, 1), (0, 5)).contiguous().to(tdt).cuda()
+    xb, tb = nhwc(x), nhwc(gt)
+    gbuf = torch.zeros_like(xb)
+    loss = torch.zeros(2, device="cuda")
+    opt = {"type": "PerceptualLoss", "layer_weights": LW, "vgg_type": "vgg19", "use_input_norm": True, "perceptual_weight": 1.0,
+           "style_weight": 0, "range_norm": False, "criterion": "l1"}
+    plan = PerceptualPlan(opt, B, H, W, dt, xb, tb, gbuf, loss.data_ptr(), state=sd)
+    plan.pack()
+    plan.fwd_target.run()
+    plan.fwd.run()
+    plan.bwd.run()
+    torch.cuda.synchronize()
+    return plan, float(loss[0]), gbuf[..., :3].float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("mode,B,H,W", [("fp32", 2, 32, 48), ("fp32x3", 2, 32, 48), ("bf16", 2, 128, 128)])
+def test_perceptual_plan_matches_oracle(mode, B, H, W):
+    """loss value, every tapped feature, and d loss / d image; bf16 at the 128x128 size of the train step against the bf16
+    precision model of the oracle."""
+    from oracle import esrgan_oracle as O
+    sd = O.vgg19_init(seed=3)
+    g = torch.Generator().manual_seed(4)
+    for k in sd:
+        if k.endswith(".bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+    torch.manual_seed(5)
+    x, gt = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W)
+    prec = O.BF16 if mode == "bf16" else O.FP32
+    xr = prec.a(x).detach().requires_grad_(True)
+    ref = O.perceptual_loss(sd, xr, prec.a(gt), LW, prec=prec)
+    (gref,) = torch.autograd.grad(ref, xr)
+    plan, loss, gx = _run_plan(mode, B, H, W, sd, x, gt)
+    feats = O.vgg19_features(sd, prec.a(x), LW.keys(), prec=prec)
+    ftol, ltol, gtol = (2e-2, 5e-3, 3e-2) if mode == "bf16" else (1e-3, 1e-4, 1e-3)
+    for k in LW:
+        got = plan.acts[k].float().cpu().permute(0, 3, 1, 2)
+        assert rel_err(got, feats[k]) < ftol, (k, rel_err(got, feats[k]))
+    assert abs(loss - float(ref)) <= ltol * abs(float(ref)), (loss, float(ref))
+    if mode == "bf16":
+        assert rel_err(gx, gref) < gtol, rel_err(gx, gref)
+    else:
+        assert parity_close(gx, gref), rel_err(gx, gref)
+
+
+def test_train_step_with_shipped_loss_block_matches_oracle():
+    """`train:` of /root/reference/ssr/options/esrgan_s2naip_urban.yml (tests/golden/ssr_options.json) — L1 + VGG19 perceptual +
+    vanilla GAN, l1_gt_usm / percep_gt_usm true, gan_gt_usm false — on consistent tiny networks: logs (incl. l_g_percep) and
+    every generator gradient against the oracle.  This is the loss configuration every shipped ESRGAN option file uses."""
+    from oracle import esrgan_oracle as O
+    from satlas_super_resolution_amd.models.ssr_esrgan_model import step_config_from_opt
+    from satlas_super_resolution_amd.train_step import ESRGANTrainStep
+    opt = json.load(open(os.path.join(GOLDEN, "ssr_options.json")))["esrgan_s2naip_urban.yml"]
+    opt["feed_disc_lr"] = False
+    cfg = step_config_from_opt(opt)
+    assert cfg.perceptual and cfg.l1_gt_usm and cfg.percep_gt_usm and not cfg.gan_gt_usm
+    g_kw = dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
+    d_kw = dict(num_in_ch=3, num_feat=8, skip_connection=True)
+    g0, d0 = O.generator_init(seed=41, **g_kw), O.discriminator_init(3, 8, seed=42)
+    vgg = O.vgg19_init(seed=43)
+    torch.manual_seed(44)
+    lr, gt = torch.rand(2, 6, 16, 16), torch.rand(2, 3, 64, 64)
+    ocfg = O.StepConfig(l1_weight=cfg.l1_weight, gan_weight=cfg.gan_weight, lr_g=cfg.lr_g, lr_d=cfg.lr_d, betas=cfg.betas,
+                        ema_decay=cfg.ema_decay, l1_gt_usm=True, gan_gt_usm=False, percep_gt_usm=True, perceptual=cfg.perceptual)
+    orc = O.ESRGANOracle(g0, d0, ocfg, vgg_sd=vgg)
+    ref_log = orc.step(lr, gt, 1)
+    assert "l_g_percep" in ref_log
+    ts = ESRGANTrainStep(g_kw, d_kw, 2, 16, 16, "fp32", cfg, use_graph=False, vgg_state=vgg)
+    ts.load_state(g0, d0)
+    ts.feed_data(lr.cuda(), gt.cuda())
+    ts.step(1)
+    log = ts.log()
+    assert set(log) == set(ref_log) | {"l_g_percep"}
+    for k, v in ref_log.items():
+        assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, log[k], v)
+    for k, g in orc.g_grads.items():
+        got = ts.g_store.tensor(k, ts.g_store.grad)
+        assert parity_close(got, g, rtol=2e-3, atol_frac=2e-3), (k, rel_err(got, g))
+    # hipGraph replay of the same step
+    ts2 = ESRGANTrainStep(g_kw, d_kw, 2, 16, 16, "fp32", cfg, use_graph=True, vgg_state=vgg)
+    ts2.load_state(g0, d0)
+    ts2.feed_data(lr.cuda(), gt.cuda())
+    for it in (1, 2, 3):
+        ts2.step(it)
+    assert all(v == v for v in ts2.log().values())

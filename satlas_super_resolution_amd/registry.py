@@ -45,12 +45,13 @@ class Registry:
 
 
 try:  # pragma: no cover - BasicSR is not installed in the build image
-    from basicsr.utils.registry import ARCH_REGISTRY, MODEL_REGISTRY  # type: ignore
+    from basicsr.utils.registry import ARCH_REGISTRY, DATASET_REGISTRY, MODEL_REGISTRY  # type: ignore
     if not hasattr(ARCH_REGISTRY, "register"):
         raise ImportError
 except Exception:
     ARCH_REGISTRY = Registry("arch")
     MODEL_REGISTRY = Registry("model")
+    DATASET_REGISTRY = Registry("dataset")
 
 
 def build_network(opt: dict):
@@ -62,3 +63,8 @@ def build_network(opt: dict):
 def build_model(opt: dict):
     """basicsr.models.build_model (train.py:62)."""
     return MODEL_REGISTRY.get(opt["model_type"])(opt)
+
+
+def build_dataset(dataset_opt: dict):
+    """basicsr.data.build_dataset: `type` selects the class, the whole dict is its `opt`."""
+    return DATASET_REGISTRY.get(dataset_opt["type"])(dataset_opt)

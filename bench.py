@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[2]: 32; configs[1]: 16)")
     ap.add_argument("--frames", type=int, default=8, help="Sentinel-2 frames (x3 RGB channels); configs[2]: 8, configs[1]: 1")
     ap.add_argument("--feed-disc-lr", action="store_true")
+    ap.add_argument("--perceptual", action="store_true",
+                    help="add the VGG19 perceptual loss of the shipped option files (esrgan_s2naip_urban.yml:123-137; random VGG weights: "
+                         "no network here) — NOT part of the headline metric's FLOP model (SURVEY.md 8d), reported as its own workload")
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,8 +279,15 @@ def main():
     B = args.batch
     g_kw = dict(num_in_ch=c_in, num_out_ch=3, scale=4, num_feat=64, num_block=args.blocks, num_grow_ch=32)
     d_kw = dict(num_in_ch=c_d, num_feat=64, skip_connection=True)
-    ts = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, args.dtype, StepConfig(feed_disc_lr=args.feed_disc_lr), dp=ctx,
-                         use_graph=not args.no_graph)
+    percep = None
+    vgg_state = None
+    if args.perceptual:
+        from satlas_super_resolution_amd import perceptual as P
+        percep = {"type": "PerceptualLoss", "layer_weights": {"conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1, "conv4_4": 1, "conv5_4": 1},
+                  "vgg_type": "vgg19", "use_input_norm": True, "perceptual_weight": 1.0, "style_weight": 0, "range_norm": False, "criterion": "l1"}
+        vgg_state = P.vgg19_random_state(P.vgg19_specs("conv5_4"), seed=2)
+    ts = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, args.dtype, StepConfig(feed_disc_lr=args.feed_disc_lr, perceptual=percep), dp=ctx,
+                         use_graph=not args.no_graph, vgg_state=vgg_state)
     # random-init weights of the named architecture (reference init distributions), identical on all ranks
     ts.load_state(O.generator_init(seed=0, **g_kw), O.discriminator_init(c_d, 64, seed=1))
     ts.sync_params_from_rank0()
@@ -333,7 +343,8 @@ def main():
                                + ("configs[2] (the metric's configuration)" if (args.frames, B) == (8, 32) else
                                   "configs[1]" if (args.frames, B) == (1, 16) else "non-headline") + " shape",
                    "per_gpu_batch": B, "global_batch": B * ctx.world, "parallelism": f"dp{ctx.world}",
-                   "hip_graph": not args.no_graph, "feed_disc_lr": args.feed_disc_lr},
+                   "hip_graph": not args.no_graph, "feed_disc_lr": args.feed_disc_lr,
+                   "perceptual_vgg19": bool(args.perceptual), "overlap_d": bool(getattr(ts, "overlap_d", False))},
         "step_gflop_per_image": gflop_img,
         "step_tflops": value * gflop_img / 1e3,
         "frac_of_mfma_peak_whole_step": value * gflop_img / 1e3 / (PEAK_TFLOPS[args.dtype] * ctx.world),
@@ -377,7 +388,7 @@ def main():
             out["roofline"]["traffic_note"] = traffic_note
         out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in
                                            sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
-    if ctx.world == 1 and not args.no_parity_mode and args.dtype != "fp32x3" and args.blocks == 23:
+    if ctx.world == 1 and not args.no_parity_mode and args.dtype != "fp32x3" and args.blocks == 23 and not args.perceptual:
         del ts
         import gc
         gc.collect()

@@ -399,7 +399,8 @@ class WgradBatch:
     of the fp32 buffers — (x_hi, dy_hi) + (x_hi, dy_lo) + (x_lo, dy_hi), accumulated in the fp32 gradient arena — after one
     ssr_split_bf16 pass per distinct parent buffer (x = hi + lo to 2^-17; the dropped lo*lo term is 2^-16 relative)."""
 
-    MAX_TILES_PER_ITEM = {3: 128, 4: 64}   # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits
+    # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits (SSR_WGRAD_T3 / _T4: tuning hooks)
+    MAX_TILES_PER_ITEM = {3: int(os.environ.get("SSR_WGRAD_T3", "128")), 4: int(os.environ.get("SSR_WGRAD_T4", "64"))}
 
     def __init__(self, dtype: int, k: int, stride: int):
         self.dtype, self.k, self.stride = dtype, k, stride

@@ -27,4 +27,12 @@ with torch.no_grad():
     torch.cuda.synchronize()
     t_run = (time.perf_counter() - t0) / 20
 assert y.shape == (B, 3, 128, 128) and bool(torch.isfinite(y).all())
+import json
+gflop = 36.739   # algorithmic GFLOP per 32x32 chunk, 24-channel input
+rec = {"workload": "SSR_RRDBNet(nf=64,nb=23,gc=32) inference, 8xS2 (24-ch) 32x32 -> 128x128 chunks, bf16, inputs resident in HBM "
+                   "(BASELINE.json configs[4] per-GPU share: 256 chunks per 16x16 tile)", "batch": B,
+       "module_call": {"chunks_per_s": B / t_mod, "ms_per_batch": 1e3 * t_mod, "tiles_per_s": B / t_mod / 256},
+       "launch_list": {"chunks_per_s": B / t_run, "ms_per_batch": 1e3 * t_run},
+       "gflop_per_chunk": gflop, "tflops_launch_list": B / t_run * gflop / 1e3, "frac_of_bf16_mfma_peak": B / t_run * gflop / 1e3 / 2500.0}
+print(json.dumps(rec))
 print(f"generator inference, B={B}: module call {B / t_mod:.0f} img/s ({1e3 * t_mod:.2f} ms), launch list {B / t_run:.0f} img/s ({1e3 * t_run:.2f} ms)")

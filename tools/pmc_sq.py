@@ -6,9 +6,11 @@
               SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d <dir> -- python bench.py ...
     python tools/pmc_sq.py <dir> out.json
 
-mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)   (the gfx94x MfmaUtil formula; ROCm 7.2 has no gfx950
-derived-counter section — MI355X_MICROARCH.md "rocprofv3 PMC slots").  SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per
-v_mfma_f32_32x32x16_bf16), SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (same guide), GRBM_GUI_ACTIVE shader-clock cycles of the launch."""
+mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 256 CUs * 4 SIMDs)   (the gfx94x MfmaUtil formula; ROCm 7.2 has
+no gfx950 derived-counter section — MI355X_MICROARCH.md "rocprofv3 PMC slots").  Units, checked on this pool (r02b): rocprofv3 reports
+GRBM_GUI_ACTIVE summed over the 8 XCDs (894,498 per rdb_kernel launch = 8 x 111.8 k cycles = 8 x 46.6 us x 2.4 GHz), and
+SQ_VALU_MFMA_BUSY_CYCLES is exactly 32 x the number of issued v_mfma_f32_32x32x16_bf16 (29,786,112 = 32 x 1818 MFMAs x 512 workgroups per
+dense-block launch, the count derived from the source).  SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (same guide)."""
 import csv, glob, json, os, re, sys
 
 
@@ -35,6 +37,7 @@ def main():
         m = {n: v[0] / v[1] for n, v in a.items()}
         row = {"launches": max(v[1] for v in a.values()), "per_launch": m}
         gui = m.get("GRBM_GUI_ACTIVE")
+        gui = gui / 8.0 if gui else gui          # summed over the 8 XCDs (see the module docstring)
         if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             row["mfma_util"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4)
         if gui and "SQ_BUSY_CU_CYCLES" in m:

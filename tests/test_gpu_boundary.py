@@ -268,3 +268,47 @@ def test_quantize_u8_round_and_truncate_bit_exact():
     ref_trunc = (xn * np.float32(255)).astype(np.uint8).transpose(0, 2, 3, 1)
     assert (M.tensor2img_u8(x.cuda()).cpu().numpy() == ref_round).all()
     assert (M.tensor2img_u8(x.cuda(), truncate=True).cpu().numpy() == ref_trunc).all()
+
+
+@pytest.mark.parametrize("compute_dtype", ["fp32x3", "bf16"])
+def test_shipped_option_file_builds_and_trains(tmp_path, monkeypatch, compute_dtype):
+    """/root/reference/ssr/options/esrgan_s2naip_urban.yml as shipped (tests/golden/ssr_options.json) driven like train.py does:
+    full-size networks (nf=64, nb=23; 36-channel generator input as the file says), L1 + VGG19 perceptual + GAN, USM targets,
+    feed_disc_lr, MultiStepLR, EMA.  Only what options.parse_options adds at run time is added (is_train, dist, paths), plus
+    network_d.num_in_ch = 3 + 36: the file as shipped pairs `feed_disc_lr: True` with a 3-channel discriminator, which the
+    reference cannot run either (torch.cat of 39 channels into conv0 of 3).  VGG19 weights come from a file in
+    torchvision's layout (random values here: no network)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from satlas_super_resolution_amd import models, perceptual as P  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    opt = json.load(open(os.path.join(GOLDEN, "ssr_options.json")))["esrgan_s2naip_urban.yml"]
+    opt.update(is_train=True, dist=False, rank=0, world_size=1, compute_dtype=compute_dtype)
+    opt["path"].update(models=str(tmp_path / "models"), training_states=str(tmp_path / "states"), visualization=str(tmp_path / "vis"))
+    with pytest.raises(AssertionError, match="feed_disc_lr"):      # as shipped: the D input width does not match
+        bad = build_model(json.loads(json.dumps(opt)))
+        bad.feed_data({"lr": torch.zeros(1, 36, 32, 32, dtype=torch.uint8), "hr": torch.zeros(1, 3, 128, 128, dtype=torch.uint8)})
+    opt["network_d"]["num_in_ch"] = 3 + opt["network_g"]["num_in_ch"]
+    with pytest.raises(FileNotFoundError, match="vgg19"):          # no silent random perceptual network
+        m0 = build_model(json.loads(json.dumps(opt)))
+        m0.feed_data({"lr": torch.zeros(1, 36, 32, 32, dtype=torch.uint8), "hr": torch.zeros(1, 3, 128, 128, dtype=torch.uint8)})
+    wfile = tmp_path / "vgg19-dcbb9e9d.pth"
+    torch.save(P.vgg19_random_state(P.vgg19_specs("conv5_4"), seed=1), wfile)
+    monkeypatch.setenv("SSR_VGG19_WEIGHTS", str(wfile))
+    model = build_model(opt)
+    g = torch.Generator().manual_seed(0)
+    for it in (1, 2, 3):
+        model.update_learning_rate(it, warmup_iter=opt["train"].get("warmup_iter", -1))
+        model.feed_data({"lr": torch.randint(0, 256, (2, 36, 32, 32), generator=g, dtype=torch.uint8),
+                         "hr": torch.randint(0, 256, (2, 3, 128, 128), generator=g, dtype=torch.uint8)})
+        model.optimize_parameters(it)
+    log = model.get_current_log()
+    assert set(log) == {"l_g_pix", "l_g_percep", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake"}
+    assert all(v == v and abs(v) < 1e4 for v in log.values()) and log["l_g_percep"] > 0
+    assert model.ts.cfg.l1_gt_usm and model.ts.percep_tgt is model.ts.l1_tgt and model.ts.percep_tgt is not model.ts.real_in
+    assert model.get_current_learning_rate() == [1e-4]
+    model.save(0, 3)
+    assert os.path.exists(tmp_path / "models" / "net_g_3.pth") and os.path.exists(tmp_path / "states" / "3.state")
+    model.test()
+    assert model.get_current_visuals()["result"].shape == (2, 3, 128, 128)

@@ -86,7 +86,7 @@ def instrumented_step(ts, args):
     records = []  # (symbol, flops, ev0, ev1)
 
     def wrap(L):
-        for fn, a, what in L.calls:
+        for fn, a, what in L.flat_calls():
             name = getattr(fn, "__name__", str(fn))
             sym, fl = name, 0.0
             if name == "ssr_conv2d":
@@ -153,14 +153,6 @@ def instrumented_step(ts, args):
             for r in rows:
                 f.write(f"{r[0]} | {r[1]} | {r[2]} | {r[3]:.2f} | {r[4]:.3f} | {r[5]:.1f}\n")
     return agg
-
-
-def wgrad_flops(ts):
-    tot = 0.0
-    for batch in [ts.g_plan._wg]:
-        for L in batch.layers:
-            tot += 2.0 * L.N * L.Gh * L.Gw * L.Cout * 9 * L.Cin_w
-    return tot
 
 
 T0 = time.perf_counter()

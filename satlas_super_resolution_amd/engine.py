@@ -260,17 +260,48 @@ class ParamStore:
 
 
 class Launcher:
-    """An ordered list of prepared C-ABI calls."""
+    """An ordered list of prepared C-ABI calls.  `fork(sub)` runs another launcher on a side stream from this point on (the side
+    stream first waits for everything issued so far; capturable: a fork / join inside a hipGraph), `join()` makes the main stream
+    wait for the side stream."""
+
+    FORK, JOIN = object(), object()
 
     def __init__(self):
         self.calls = []
+        self._sides = {}          # fork index -> its own side stream (forks of one launcher run concurrently)
 
     def add(self, fn, *args, what=""):
         self.calls.append((fn, args, what))
 
+    def fork(self, sub: "Launcher", what=""):
+        self.calls.append((Launcher.FORK, (sub,), what))
+
+    def join(self):
+        self.calls.append((Launcher.JOIN, (), "join"))
+
+    def flat_calls(self):
+        """every C-ABI call in issue order, forks inlined (instrumentation)"""
+        for fn, args, what in self.calls:
+            if fn is Launcher.FORK:
+                yield from args[0].flat_calls()
+            elif fn is not Launcher.JOIN:
+                yield fn, args, what
+
     def run(self):
         st = hip.stream_ptr()
         for fn, args, what in self.calls:
+            if fn is Launcher.FORK:
+                side = self._sides.get(id(args[0]))
+                if side is None:
+                    side = self._sides[id(args[0])] = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    args[0].run()
+                continue
+            if fn is Launcher.JOIN:
+                for side in self._sides.values():
+                    torch.cuda.current_stream().wait_stream(side)
+                continue
             rc = fn(*args, st)
             if rc != 0:
                 hip.check(rc, what or getattr(fn, "__name__", "call"))
@@ -402,8 +433,9 @@ class WgradBatch:
     # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits (SSR_WGRAD_T3 / _T4: tuning hooks)
     MAX_TILES_PER_ITEM = {3: int(os.environ.get("SSR_WGRAD_T3", "128")), 4: int(os.environ.get("SSR_WGRAD_T4", "64"))}
 
-    def __init__(self, dtype: int, k: int, stride: int):
+    def __init__(self, dtype: int, k: int, stride: int, force_atomic: bool = False):
         self.dtype, self.k, self.stride = dtype, k, stride
+        self.force_atomic = force_atomic       # another launch accumulates into the same gradients concurrently
         self.kdt = hip.BF16 if dtype == hip.F32X3 else dtype      # element type the wgrad kernel reads
         self.layers: List[WgradLayer] = []
         self.items: List[WgradItem] = []
@@ -422,7 +454,7 @@ class WgradBatch:
                 for sp in range(splits):
                     b, e = sp * per, min(tiles, (sp + 1) * per)
                     if b < e:
-                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if splits > 1 else 0))
+                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if (splits > 1 or self.force_atomic) else 0))
 
     def _twin(self, v: View, which: int) -> View:
         parent = hip.parent_of(v)
@@ -513,7 +545,7 @@ class GeneratorPlan:
 
     def __init__(self, store: ParamStore, B: int, H: int, W: int, *, num_in_ch, num_out_ch=3, scale=4, num_feat=64,
                  num_block=23, num_grow_ch=32, training=True, out_buf: Optional[torch.Tensor] = None,
-                 d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False):
+                 d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False, wgrad_atomic: bool = False):
         self.store, self.B, self.dt = store, B, store.dtype
         self.scale, self.nf, self.nb, self.gc = scale, num_feat, num_block, num_grow_ch
         self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
@@ -608,13 +640,25 @@ class GeneratorPlan:
         self.dbufs = [z(B, H, W, cd) for _ in range(n_rdb)]
         self.g_xin = z(B, H, W, self.xin.shape[-1]) if need_input_grad else None
         Bk = Launcher()
-        wg = WgradBatch(self.dt, 3, 1)
         st = store
+        # weight gradients: ONE batched launch after the last dgrad (default), or SSR_WGRAD_CHUNKS = n batches, each forked onto
+        # a side stream as soon as the gradient buffers it reads are final, beside the remaining (strictly sequential) dgrad chain
+        n_chunks = max(1, int(os.environ.get("SSR_WGRAD_CHUNKS", "1")))
+        cuts = {round(n_rdb * q / n_chunks) for q in range(1, n_chunks)}     # close a batch before RDB index r in `cuts`
+        batches = [WgradBatch(self.dt, 3, 1, wgrad_atomic)]
 
         def add_wg(name, x: View, dy: View, hi, wi, up, gh, gw, alpha=1.0, cin=None):
             s = st.specs[name]
-            wg.add(x, dy, B, hi, wi, up, rup(s.cin, 8) if cin is None else cin, s.cout, gh, gw, alpha,
-                   st.ptr(name + ".weight", st.grad), s.cin, st.ptr(name + ".bias", st.grad) if s.bias else None)
+            batches[-1].add(x, dy, B, hi, wi, up, rup(s.cin, 8) if cin is None else cin, s.cout, gh, gw, alpha,
+                            st.ptr(name + ".weight", st.grad), s.cin, st.ptr(name + ".bias", st.grad) if s.bias else None)
+
+        def close_batch():
+            wgb = batches[-1]
+            wgb.finalize()
+            sub = Launcher()
+            wgb.launch(sub)
+            Bk.fork(sub, what="wgrad chunk")
+            batches.append(WgradBatch(self.dt, 3, 1, wgrad_atomic))
 
         Ho, Wo = self.Ho, self.Wo
         last_up = self.ups[-1]
@@ -654,6 +698,8 @@ class GeneratorPlan:
                 d_rrdb = view(self.g_body_out) if rr == n_rdb - 1 else view(self.dbufs[rr + 1], 0)
                 a5, b5 = 0.2, 1.0
             fused_bwd = self.fused_rdb and os.environ.get("SSR_FUSED_RDB_BWD", "1") != "0"
+            if n_chunks > 1 and (r + 1) in cuts:      # everything recorded so far reads buffers of blocks > r: final by now
+                close_batch()
             store.add_rdb_gather(p, nf, gc, a5, ck0=16 if fused_bwd else 0)
             add_wg(f"{p}.conv5", view(cur, 0), d_out_r, H, W, 1, H, W, alpha=a5, cin=cd)
             for k in (4, 3, 2, 1):
@@ -691,9 +737,14 @@ class GeneratorPlan:
         if need_input_grad:
             cb.dgrad(Bk, "conv_first", view(self.dbufs[0], 0), H, W, view(self.g_xin), cout=self.xin.shape[-1],
                      cin_dy=nf)
-        wg.finalize()
-        wg.launch(Bk)
-        self._wg = wg
+        if n_chunks > 1:
+            close_batch()
+            Bk.join()
+            batches.pop()
+        else:
+            batches[0].finalize()
+            batches[0].launch(Bk)
+        self._wg_batches = batches
         self.bwd = Bk
 
     # ---- boundary: NCHW fp32 tensors of the reference API ----
@@ -722,6 +773,47 @@ class GeneratorPlan:
         hip.check(hip.lib().ssr_nhwc_to_nchw(view(self.g_xin), self.dt, g.data_ptr(), self.B, self.cin_eff, self.H,
                                              self.W, hip.stream_ptr()), "ssr_nhwc_to_nchw")
         return g
+
+
+class SplitGeneratorPlan:
+    """Two GeneratorPlans over the two halves of the batch, run as two concurrent launch chains (fork / join, capturable).
+
+    Why: the generator is a chain of ~150 strictly dependent launches, and a fused dense-block launch at B = 32 is 512 workgroups
+    on 256 CUs with ONE workgroup per CU (161 KB of LDS): the CUs idle through every launch's ramp and tail — 22 % of the
+    dense-block time (SQ_BUSY_CU_CYCLES, profiles/r02b_pmc_sq.json).  Samples are independent, so the two half-batches form two
+    independent chains; each launch is then one full round of 256 workgroups and the workgroups of one chain fill the ramps and
+    tails of the other.  The halves share the parameter store; their weight-gradient launches accumulate into the same fp32
+    gradients concurrently, so every work item uses the atomic write-out (WgradBatch.force_atomic).
+    Same arithmetic per sample; only the summation order of the weight gradients over samples differs."""
+
+    def __init__(self, store: ParamStore, B: int, H: int, W: int, *, out_buf: torch.Tensor, d_out_buf: torch.Tensor, parts: int = 2,
+                 **kw):
+        assert B % parts == 0 and kw.get("training", True)
+        h = B // parts
+        self.B, self.half, self.store = B, h, store
+        self.parts = [GeneratorPlan(store, h, H, W, out_buf=out_buf[i * h:(i + 1) * h], d_out_buf=d_out_buf[i * h:(i + 1) * h],
+                                    wgrad_atomic=True, **kw) for i in range(parts)]
+        a = self.parts[0]
+        self.fused_rdb, self.unshuffle = a.fused_rdb, a.unshuffle
+        self.num_in_ch, self.num_out_ch, self.Hin, self.Win, self.Ho, self.Wo = a.num_in_ch, a.num_out_ch, a.Hin, a.Win, a.Ho, a.Wo
+        self.out, self.dt = out_buf, a.dt
+        self.fwd, self.bwd = Launcher(), Launcher()
+        for L, which in ((self.fwd, "fwd"), (self.bwd, "bwd")):
+            for p in self.parts[1:]:
+                L.fork(getattr(p, which), what="another part of the batch")
+            L.calls.extend(getattr(a, which).calls)
+            L.join()
+
+    def load_input(self, x_nchw: torch.Tensor, scale: float = 1.0):
+        for i, p in enumerate(self.parts):
+            p.load_input(x_nchw[i * self.half:(i + 1) * self.half], scale)
+
+    def read_output(self, out_nchw: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out_nchw is None:
+            out_nchw = torch.empty(self.B, self.num_out_ch, self.Ho, self.Wo, device=self.store.device)
+        for i, p in enumerate(self.parts):
+            p.read_output(out_nchw[i * self.half:(i + 1) * self.half])
+        return out_nchw
 
 
 # =====================================================================================================

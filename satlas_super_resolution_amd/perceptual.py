@@ -196,7 +196,7 @@ class PerceptualPlan:
         self._gscale = (C.c_float * 8)(*[float(self._scale[c]) for c in range(3)], *([0.0] * 5))
         Bk.add(lib.ssr_channel_affine, view(self.g_xn), view(grad_buf), dtype, npix, 3, self._gscale, self._zero, 1, what="vgg normalise bwd")
         self.bwd = Bk
-        self._keep = (pooled, g_pooled)
+        self.layers, self.dims, self.pooled, self.g_pooled = layers, dims, pooled, g_pooled
 
     def pack(self):
         self.store.pack()

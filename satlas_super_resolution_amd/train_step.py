@@ -113,8 +113,20 @@ class ESRGANTrainStep:
         self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
                                                num_feat=d_kwargs.get("num_feat", 64),
                                                skip_connection=d_kwargs.get("skip_connection", True))
-        self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in,
-                                           d_out_buf=self.d_plan.g_in, **g_kwargs)
+        import os
+        # the generator as two half-batch launch chains (engine.SplitGeneratorPlan) where its launches are latency chains of
+        # single-wave-per-CU kernels: the fused dense blocks (bf16, nf = 64, gc = 32) at batches of two full rounds or more
+        # r02g, two boxes, B = 32 8xS2 bf16: 14.40 -> 13.97 ms and 13.78 -> 13.53 ms per step with two chains; four chains
+        # (half-chip launches): 14.9 ms — slower; B = 16 (one round per launch already): no difference
+        n_split = int(os.environ.get("SSR_G_SPLIT", "2"))
+        split = n_split > 1 and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
+            and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
+        if split:
+            self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
+                                                    parts=n_split, **g_kwargs)
+        else:
+            self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
+                                               **g_kwargs)
         self.p_plan = None
         if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
             from .perceptual import PerceptualPlan

@@ -12,7 +12,7 @@ from conftest import GOLDEN, parity_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
-LW = {"conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1, "conv4_4": 1, "conv5_4": 1}       # esrgan_s2naip_urban.yml:125-131
+LW_WEIGHTS = {"conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1, "conv4_4": 1, "conv5_4": 1}       # esrgan_s2naip_urban.yml:125-131
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -51,7 +51,7 @@ def _run_plan(mode, B, H, W, sd, x, gt):
     xb, tb = nhwc(x), nhwc(gt)
     gbuf = torch.zeros_like(xb)
     loss = torch.zeros(2, device="cuda")
-    opt = {"type": "PerceptualLoss", "layer_weights": LW, "vgg_type": "vgg19", "use_input_norm": True, "perceptual_weight": 1.0,
+    opt = {"type": "PerceptualLoss", "layer_weights": LW_WEIGHTS, "vgg_type": "vgg19", "use_input_norm": True, "perceptual_weight": 1.0,
            "style_weight": 0, "range_norm": False, "criterion": "l1"}
     plan = PerceptualPlan(opt, B, H, W, dt, xb, tb, gbuf, loss.data_ptr(), state=sd)
     plan.pack()
@@ -76,36 +76,54 @@ def test_perceptual_plan_matches_oracle(mode, B, H, W):
     x, gt = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W)
     prec = O.BF16 if mode == "bf16" else O.FP32
     xr = prec.a(x).detach().requires_grad_(True)
-    ref = O.perceptual_loss(sd, xr, prec.a(gt), LW, prec=prec)
+    ref = O.perceptual_loss(sd, xr, prec.a(gt), LW_WEIGHTS, prec=prec)
     plan, loss, gx = _run_plan(mode, B, H, W, sd, x, gt)
-    feats = O.vgg19_features(sd, xr, LW.keys(), prec=prec)
+    feats = O.vgg19_features(sd, xr, LW_WEIGHTS.keys(), prec=prec)
     ftol, ltol = (2e-2, 5e-3) if mode == "bf16" else (1e-3, 1e-4)
-    for k in LW:
+    for k in LW_WEIGHTS:
         got = plan.acts[k].float().cpu().permute(0, 3, 1, 2)
         assert rel_err(got, feats[k]) < ftol, (k, rel_err(got, feats[k]))
     assert abs(loss - float(ref)) <= ltol * abs(float(ref)), (loss, float(ref))
-    # Gradient.  d|a - b| = sign(a - b) is discontinuous: wherever a feature difference is at rounding level its sign — a
-    # full-size change of that element's gradient — is noise in ANY arithmetic (fp32 vs fp64 on the CPU included), so the
-    # backward chain is checked with the sign pattern the device saw: loss_lin = sum_k w_k * mean(S_k * F_k(x)).
-    lin = 0
-    for k, w in LW.items():
-        sgn = torch.sign(plan.acts[k].float() - plan.feats_t[k].float()).cpu().permute(0, 3, 1, 2)
-        lin = lin + w * (prec.g(feats[k]) * sgn).sum() / sgn.numel()
-    (gref,) = torch.autograd.grad(lin, xr)
-    if mode != "bf16":
-        # The remaining discontinuities are the ReLU / max-pool decisions of elements at rounding level (1e-6 exact fp32, 1e-5
-        # split-bf16): ONE flipped ReLU in conv1_1 changes the gradient of the ~9 pixels under it by one of their ~576 path terms
-        # (~4 % of a pixel's gradient; r02c: max-norm 2.3e-2 with split-bf16, < 1e-3 with exact fp32 on the same data).  So: all
-        # but a handful of pixels within the 1e-3 gate (x3 of it for split-bf16), and no systematic error.
-        err = (gx - gref).abs()
-        lim = (1e-3 if mode == "fp32" else 3e-3) * (gref.abs().max() + gref.abs())
-        assert float((err > lim).float().mean()) < 2e-3, float((err > lim).float().mean())
-        assert float(err.mean() / gref.abs().mean()) < 2e-3, float(err.mean() / gref.abs().mean())
-        assert rel_err(gx, gref) < 0.1
+    # Backward, layer by layer.  The end-to-end image gradient is not a usable parity target: d|a - b| = sign(a - b) and the
+    # ReLU / max-pool decisions are discontinuous, every feature element at rounding level flips one of them, and a flipped
+    # unit in conv4_x / conv5_x moves the gradient of the whole image (measured vs autograd, same data: mean error 0.2 % exact
+    # fp32, 1.7 % split-bf16, 21 % bf16 — ordered like the rounding levels 1e-6 / 1e-5 / 4e-3, in ANY implementation).  So every
+    # gradient buffer is recomputed on the CPU from the device's own neighbouring buffers, decisions taken from the device's
+    # stored activations — the same layer-local method as tests/test_gpu_baseline_shapes.py.
+    from oracle import layerwise as LW
+    lmode = "bf16" if mode == "bf16" else "fp32"
+    nchw = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+    wq = lambda idx: LW.rnd(sd[f"features.{idx}.weight"], lmode)
+    rep = LW.Report()
+    acts = {k: nchw(v) for k, v in plan.acts.items()}
+    g_acts = {k: nchw(v) for k, v in plan.g_acts.items()}
+    layers = plan.layers
+    last = layers[-1][0]
+    l1g = {k: LW.rnd(float(w) * torch.sign(acts[k] - nchw(plan.feats_t[k])) / acts[k].numel(), lmode) for k, w in LW_WEIGHTS.items()}
+    rep.add(f"bwd L1 {last}", g_acts[last], l1g[last])
+    for li in reversed(range(1, len(layers))):
+        name, idx, cin, cout, pooled_before = layers[li]
+        pname = layers[li - 1][0]
+        gin = LW.conv_T(wq(idx), g_acts[name], (plan.dims[name][0], plan.dims[name][1]))
+        if pooled_before:
+            gp_dev = nchw(plan.g_pooled[pname])
+            rep.add(f"bwd {name} dgrad", gp_dev, LW.rnd(gin, lmode))
+            f = acts[pname].clone().requires_grad_(True)          # adjoint of maxpool2x2(relu(F)) at the device's F
+            (routed,) = torch.autograd.grad(F.max_pool2d(F.relu(f), 2, 2), f, gp_dev)
+            rep.add(f"bwd relu+pool {pname}", g_acts[pname], LW.rnd(l1g[pname] + routed, lmode))
+        else:
+            rep.add(f"bwd {name} dgrad", g_acts[pname], LW.rnd(gin * (acts[pname] > 0).float(), lmode))
+    name, idx = layers[0][0], layers[0][1]
+    g_xn = LW.conv_T(wq(idx), g_acts[name], (H, W))
+    rep.add("bwd conv1_1 dgrad", nchw(plan.g_xn)[:, :3], LW.rnd(g_xn, lmode))
+    std = torch.tensor(O.VGG_STD).view(1, 3, 1, 1)
+    rep.add("bwd normalise", gx, LW.rnd(nchw(plan.g_xn)[:, :3] / std, lmode))
+    assert len(rep.rows) == 1 + 15 + 4 + 2
+    if mode == "bf16":
+        rep.check_bf16()
     else:
-        # bf16: 16 layers of 1-ulp stores move ReLU / pooling decisions of near-zero / near-tie elements; bound the bulk
-        assert float((gx - gref).abs().mean() / gref.abs().mean()) < 0.1, float((gx - gref).abs().mean() / gref.abs().mean())
-        assert rel_err(gx, gref) < 0.5
+        tol = 1e-4 if mode == "fp32" else 2e-4
+        rep.check(tol, tol / 10)
 
 
 def test_train_step_with_shipped_loss_block_matches_oracle():

@@ -125,12 +125,18 @@ def instrumented_step(ts, args):
     orig = engine.Launcher.run
     engine.Launcher.run = lambda self: wrap(self)
     use_graph, ts.use_graph = ts.use_graph, False
+    # per-kernel durations are only meaningful for launches that have the chip to themselves: the forks of the real step (two
+    # half-batch generator chains, discriminator phases beside G's backward) are inlined / switched off here, so every launch is
+    # timed alone, back to back on one stream.  (In the overlapped step the same kernels share the CUs: their individual
+    # durations in a rocprofv3 trace of the real step are longer while the step is shorter.)
+    overlap, ts.overlap_d = getattr(ts, "overlap_d", False), False
     register_wgrad_flops(ts)
     try:
         ts.step()
     finally:
         engine.Launcher.run = orig
         ts.use_graph = use_graph
+        ts.overlap_d = overlap
     torch.cuda.synchronize()
     agg, per_layer = {}, {}
 
@@ -378,8 +384,33 @@ def main():
                            "frac": fl / secs / 1e12 / PEAK_TFLOPS[args.dtype], "traffic": traffic}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
+        out["roofline"]["note"] = ("launch durations from an instrumented step in which every launch runs alone (forks inlined, HIP events "
+                                   "around each C-ABI call on the launch stream); compare with a rocprofv3 trace taken with "
+                                   "SSR_OVERLAP_D=0 SSR_G_SPLIT=0 (profiles/*_kernel_stats_serial*.csv) — in the overlapped step the "
+                                   "kernels share the CUs")
         out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in
                                            sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
+    if ctx.rank == 0 and ctx.world == 1 and "roofline" in out and args.dtype == "bf16" and hasattr(ts.g_plan, "parts"):
+        # The step runs the generator as two half-batch chains, so the launches timed above are 16-image launches (one round
+        # of 256 workgroups each).  For the kernel itself, also time it at the whole per-GPU batch in one launch (two rounds),
+        # the launch size of a single-chain step: same kernel, same data layout, forward dense blocks of a non-split plan.
+        from satlas_super_resolution_amd import engine
+        fp = engine.GeneratorPlan(ts.g_store, B, 32, 32, training=False, **g_kw)
+        fp.load_input(lr)
+        calls = [(fn, a) for fn, a, _ in fp.fwd.calls if getattr(fn, "__name__", "") == "ssr_rdb_forward"]
+        for fn, a in calls:
+            fn(*a, hip.stream_ptr())
+        evs = []
+        for fn, a in calls:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(*a, hip.stream_ptr()); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        us = sorted(1e3 * a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+        fl = 2.0 * 9 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) * B * 32 * 32
+        out["roofline"]["full_batch_launch"] = {"kernel": "rdb_kernel<false>", "images_per_launch": B, "median_launch_us": us,
+                                                "flops_per_launch": fl, "achieved": fl / us / 1e6, "frac": fl / us / 1e6 / PEAK_TFLOPS["bf16"]}
+        del fp
     if ctx.world == 1 and not args.no_parity_mode and args.dtype != "fp32x3" and args.blocks == 23 and not args.perceptual:
         del ts
         import gc

@@ -334,8 +334,11 @@ def test_infer_grid_tile_end_to_end_vs_oracle(mode):
 
 def test_split_generator_chains_match_the_single_chain(monkeypatch):
     """engine.SplitGeneratorPlan (SSR_G_SPLIT=2: the generator as two concurrent half-batch launch chains) against the single
-    chain on the same data: per-sample arithmetic is identical, so the generator output is bit-identical; the parameter
-    gradients are sums over samples accumulated in another order (fp32)."""
+    chain on the same data.  Samples are independent, so the result is the same up to bf16 rounding: a few layers outside the
+    dense blocks pick another tile shape / k-split for a 16-image launch than for a 32-image one (csrc/conv.hip pick_tile,
+    conv_res / conv_ws qualification by grid size), i.e. another fp32 summation order in front of a bf16 store, and the weight
+    gradients are accumulated over the samples in another order.  (At B = 16 vs 2 x 8, where the same variants are picked, the
+    output was bit-identical: r02g.)"""
     from oracle import esrgan_oracle as O
     from satlas_super_resolution_amd import engine
     from satlas_super_resolution_amd.train_step import ESRGANTrainStep, StepConfig
@@ -364,7 +367,9 @@ def test_split_generator_chains_match_the_single_chain(monkeypatch):
     ref = res[("0", False)]
     for key in (("2", False), ("2", True)):
         out, gg, dg, log = res[key]
-        assert torch.equal(out, ref[0]), key
-        assert rel_err(gg, ref[1]) < 1e-4 and rel_err(dg, ref[2]) < 1e-4, (key, rel_err(gg, ref[1]), rel_err(dg, ref[2]))
+        assert rel_err(out, ref[0]) < 1e-2 and float((out - ref[0]).abs().mean() / ref[0].abs().max()) < 2e-4, (key, rel_err(out, ref[0]))
+        assert rel_err(gg, ref[1]) < 3e-2 and rel_err(dg, ref[2]) < 3e-2, (key, rel_err(gg, ref[1]), rel_err(dg, ref[2]))
         for k, v in ref[3].items():
-            assert abs(log[k] - v) <= 1e-5 * max(1.0, abs(v)), (key, k)
+            assert abs(log[k] - v) <= 2e-3 * max(1.0, abs(v)), (key, k)
+    a, b = res[("2", False)], res[("2", True)]          # eager vs hipGraph replay of the forked chains: the same launches
+    assert rel_err(a[0], b[0]) < 1e-6 and rel_err(a[1], b[1]) < 1e-4

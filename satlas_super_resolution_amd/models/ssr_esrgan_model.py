@@ -96,6 +96,7 @@ class SSRESRGANModel:
         self.ts = None
         self._pending_state = None         # resume_training() before the first batch built the step (train.py:64-65)
         self._infer = None                 # (store, plan) of test()
+        self._validating = False
         self.log_dict = OrderedDict()
         self.lr = self.gt = self.output = None
         self.current_lrs = [self.cfg.lr_g, self.cfg.lr_d]
@@ -165,6 +166,11 @@ class SSRESRGANModel:
         """ssr_esrgan_model.py:104-117: uint8 tensors -> float/255 on the device."""
         lr = data["lr"].to(self.device, non_blocking=True).float()
         B, _, h, w = lr.shape
+        if self._validating and self.ts is not None:
+            # validation batches (usually of another size) only feed test(): the train step, its plans and graphs stay as they are
+            self.lr = lr / 255
+            self.gt = data["hr"].to(self.device, non_blocking=True).float() / 255 if "hr" in data else None
+            return
         has_old = "old_hr" in data and "hr" in data
         if self.ts is None:
             self.cfg.old_hr = has_old      # the D input width is static: decided by the first training batch
@@ -209,10 +215,11 @@ class SSRESRGANModel:
         """:235-244 — forward with the EMA weights (net_g_ema) under no_grad."""
         from .. import engine
         ts = self.ts
-        key = (ts.B, ts.h, ts.w)
+        B, _, h, w = self.lr.shape
+        key = (B, h, w)
         if self._infer is None or self._infer[0] != key:
-            st = engine.ParamStore(engine.generator_specs(**self.g_kwargs), ts.dt)
-            self._infer = (key, st, engine.GeneratorPlan(st, ts.B, ts.h, ts.w, training=False, **self.g_kwargs))
+            st = self._infer[1] if self._infer is not None else engine.ParamStore(engine.generator_specs(**self.g_kwargs), ts.dt)
+            self._infer = (key, st, engine.GeneratorPlan(st, B, h, w, training=False, **self.g_kwargs))
         _, st, plan = self._infer
         st.data.copy_(ts.opt_g.ema if ts.opt_g.ema is not None else ts.g_store.data)
         st.pack()
@@ -326,6 +333,7 @@ class SSRESRGANModel:
             better = mo.get("better", "higher")
             rec.setdefault(m, dict(better=better, val=float("-inf") if better == "higher" else float("inf"), iter=-1))
         n = 0
+        self._validating = True
         for idx, val_data in enumerate(dataloader):
             self.feed_data(val_data)
             self.test()
@@ -345,6 +353,7 @@ class SSRESRGANModel:
                     self.metric_results[name] += float(M.METRICS[mo["type"]](sr[:1], gt[:1], **kw))
             n += 1
             self.gt = self.output = None
+        self._validating = False
         for name in self.metric_results:
             self.metric_results[name] /= max(n, 1)
             r = rec[name]

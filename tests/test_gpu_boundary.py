@@ -312,3 +312,49 @@ def test_shipped_option_file_builds_and_trains(tmp_path, monkeypatch, compute_dt
     assert os.path.exists(tmp_path / "models" / "net_g_3.pth") and os.path.exists(tmp_path / "states" / "3.state")
     model.test()
     assert model.get_current_visuals()["result"].shape == (2, 3, 128, 128)
+
+
+def test_training_loop_on_the_miniature_dataset(tmp_path, monkeypatch):
+    """satlas_super_resolution_amd.train.train (the control flow of /root/reference/ssr/train.py:52-140 without BasicSR) end to
+    end: S2NAIPDataset (committed miniature set, tile-weight sampler off) -> DataLoader (uint8 batches) -> SSRESRGANModel
+    (L1 + VGG19 perceptual + GAN, USM targets, feed_disc_lr) -> logging, checkpoint, validation with psnr / ssim / cpsnr."""
+    import os
+    from conftest import GOLDEN
+    from satlas_super_resolution_amd import perceptual as P
+    from satlas_super_resolution_amd.train import train
+    mini = os.path.join(GOLDEN, "s2naip_mini")
+    ds = {"name": "mini", "type": "S2NAIPDataset", "sentinel2_path": os.path.join(mini, "sentinel2"), "naip_path": os.path.join(mini, "naip"),
+          "use_shuffle": False, "num_worker_per_gpu": 0, "batch_size_per_gpu": 2, "n_s2_images": 8}
+    wfile = tmp_path / "vgg19.pth"
+    torch.save(P.vgg19_random_state(P.vgg19_specs("conv5_4"), seed=1), wfile)
+    monkeypatch.setenv("SSR_VGG19_WEIGHTS", str(wfile))
+    opt = {
+        "name": "mini", "model_type": "SSRESRGANModel", "scale": 4, "manual_seed": 0, "is_train": True, "dist": False,
+        "l1_gt_usm": True, "percep_gt_usm": True, "gan_gt_usm": False, "feed_disc_lr": True, "compute_dtype": "bf16",
+        "datasets": {"train": dict(ds), "val": dict(ds, name="validation")},
+        "network_g": {"type": "SSR_RRDBNet", "num_in_ch": 24, "num_out_ch": 3, "num_feat": 64, "num_block": 2, "num_grow_ch": 32},
+        "network_d": {"type": "SSR_UNetDiscriminatorSN", "num_in_ch": 27, "num_feat": 64, "skip_connection": True},
+        "path": {"models": str(tmp_path / "models"), "training_states": str(tmp_path / "states"), "visualization": str(tmp_path / "vis")},
+        "train": {"ema_decay": 0.999, "optim_g": {"type": "Adam", "lr": 1e-4, "weight_decay": 0, "betas": [0.9, 0.99]},
+                  "optim_d": {"type": "Adam", "lr": 1e-4, "weight_decay": 0, "betas": [0.9, 0.99]},
+                  "scheduler": {"type": "MultiStepLR", "milestones": [400000], "gamma": 0.5}, "total_iter": 4, "warmup_iter": -1,
+                  "pixel_opt": {"type": "L1Loss", "loss_weight": 1.0, "reduction": "mean"},
+                  "perceptual_opt": {"type": "PerceptualLoss", "layer_weights": {"conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1, "conv4_4": 1, "conv5_4": 1},
+                                     "vgg_type": "vgg19", "use_input_norm": True, "perceptual_weight": 1.0, "style_weight": 0,
+                                     "range_norm": False, "criterion": "l1"},
+                  "gan_opt": {"type": "GANLoss", "gan_type": "vanilla", "real_label_val": 1.0, "fake_label_val": 0.0, "loss_weight": 0.1},
+                  "net_d_iters": 1, "net_d_init_iters": 0},
+        "val": {"val_freq": 4, "save_img": True, "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 4, "test_y_channel": False},
+                                                             "ssim": {"type": "calculate_ssim", "crop_border": 4, "test_y_channel": False},
+                                                             "cpsnr": {"type": "calculate_cpsnr", "crop_border": 4, "test_y_channel": False}}},
+        "logger": {"print_freq": 2, "save_checkpoint_freq": 4},
+    }
+    lines = []
+    res = train(opt, log=lines.append)
+    assert res["iters"] == 4 and set(res["metrics"]) == {"psnr", "ssim", "cpsnr"}
+    assert all(v == v for v in res["log"].values()) and "l_g_percep" in res["log"]
+    assert 0 < res["metrics"]["psnr"] < 60 and -1 <= res["metrics"]["ssim"] <= 1
+    assert any('"iter": 2' in ln for ln in lines) and any('"validation"' in ln for ln in lines)
+    for f in ("models/net_g_4.pth", "models/net_d_4.pth", "states/4.state", "models/net_g_latest.pth"):
+        assert os.path.exists(tmp_path / f), f
+    assert len(os.listdir(tmp_path / "vis")) == 5            # one directory per validation image (5 datapoints in the mini set)

@@ -237,3 +237,42 @@ def test_s2naip_dataset_matches_reference_samples():
     assert seen == len(fx) == 14
     w = ds.get_tile_weight_sampler({"100_200": 5.0})
     assert sorted(w.weights.tolist()) == [1.0, 1.0, 1.0, 1.0, 5.0] and len(list(iter(w))) == 5
+
+
+def test_infer_grid_driver_io_and_sharding(tmp_path):
+    """satlas_super_resolution_amd.infer_grid.run_infer_grid (the reference's infer_grid.py flow: PNG chunks in, 128x128 PNG chunks
+    + stitched tiles out) with a stand-in model on the CPU: two ranks write disjoint chunk files that together equal the
+    one-rank run, file names keep tile / index, a complete 16x16 tile is stitched (2048x2048 SR, 512x512 Sentinel-2), an incomplete
+    one is skipped."""
+    import numpy as np
+    from PIL import Image
+    from satlas_super_resolution_amd.infer_grid import run_infer_grid
+    rng = np.random.RandomState(0)
+    data = tmp_path / "sentinel2"
+    for tile, n in (("7_9", 256), ("8_9", 5)):
+        (data / tile).mkdir(parents=True)
+        for k in range(n):
+            i, j = divmod(k, 16)
+            Image.fromarray(rng.randint(1, 256, (10 * 32, 32, 3)).astype(np.uint8)).save(data / tile / f"{i}_{j}.png")
+    model = lambda x: x[:, :3].repeat_interleave(4, 2).repeat_interleave(4, 3)       # first picked frame, nearest x4
+    import random
+    outs = {}
+    for tag, world in (("one", 1), ("two", 2)):
+        save = tmp_path / f"out_{tag}"
+        opt = {"data_dir": str(data), "n_lr_images": 8, "save_path": str(save), "batch": 37}
+        for rank in reversed(range(world)):       # sequential stand-in for the barrier: rank 0 (which stitches) runs last
+            random.seed(3)
+            res = run_infer_grid(opt, model=model, rank=rank, world=world, device=torch.device("cpu"))
+            if rank == 1:
+                assert res == {"chunks": 130, "tiles_stitched": 0}
+        outs[tag] = save
+        assert (save / "7_9" / "stitched_sr.png").exists() and (save / "7_9" / "stitched_s2.png").exists()
+        assert not (save / "8_9" / "stitched_sr.png").exists() and len(list((save / "8_9").glob("*.png"))) == 5
+        sr = np.asarray(Image.open(save / "7_9" / "stitched_sr.png"))
+        s2 = np.asarray(Image.open(save / "7_9" / "stitched_s2.png"))
+        assert sr.shape == (2048, 2048, 3) and s2.shape == (512, 512, 3)
+        first = np.asarray(Image.open(data / "7_9" / "3_5.png")).reshape(-1, 32, 32, 3)[0]
+        assert (s2[96:128, 160:192] == first).all()                                   # cell (3, 5) of the Sentinel-2 mosaic
+        assert (sr[384:512, 640:768] == np.asarray(Image.open(save / "7_9" / "3_5.png"))).all()
+    assert res == {"chunks": 131, "tiles_stitched": 1}
+    assert len(list((outs["two"] / "7_9").glob("[0-9]*_[0-9]*.png"))) == 256

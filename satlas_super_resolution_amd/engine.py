@@ -24,11 +24,6 @@ from . import hip
 from .hip import ConvDesc, View, WgradItem, WgradLayer, PackItem, SNItem, SNBwdItem, view
 
 
-# SSR_DETERMINISTIC=1: every weight-gradient element has exactly one writer (no pixel splits, no half-batch generator chains), so
-# a step is bit-reproducible run to run; the default trades that for balance (fp32 atomics: sums differ in the last bits)
-DETERMINISTIC = os.environ.get("SSR_DETERMINISTIC", "0") == "1"
-
-
 def rup(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
@@ -511,8 +506,6 @@ class WgradBatch:
         self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, dw_ptr, cin_w, db_ptr))
         tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.kdt, self.k)
         splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
-        if DETERMINISTIC:        # one writer per gradient element: no atomics, bit-reproducible sums (slower: coarse items)
-            splits = 1
         per = -(-tiles // splits)
         for co0 in range(0, cout, 32):
             for ci0 in range(0, cin_w, hip.lib().ssr_wgrad_ci_tile(self.kdt, self.k)):

@@ -118,7 +118,7 @@ class ESRGANTrainStep:
         # single-wave-per-CU kernels: the fused dense blocks (bf16, nf = 64, gc = 32) at batches of two full rounds or more
         # r02g, two boxes, B = 32 8xS2 bf16: 14.40 -> 13.97 ms and 13.78 -> 13.53 ms per step with two chains; four chains
         # (half-chip launches): 14.9 ms — slower; B = 16 (one round per launch already): no difference
-        n_split = 0 if engine.DETERMINISTIC else int(os.environ.get("SSR_G_SPLIT", "2"))
+        n_split = int(os.environ.get("SSR_G_SPLIT", "2"))
         split = n_split > 1 and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
             and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
         if split:

@@ -535,6 +535,12 @@ template <int KH, int KW>
 int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
     bool nt2, small;
     pick_tile(d, nt2, small);
+    // The split kernel always takes the 8x16-pixel workgroup tile: its weight slab (hi + lo planes, converted by every workgroup)
+    // costs as much to stage as 288 pixel rows, so halving the pixels per workgroup the way the plain kernels do for small
+    // grids doubles that share.  r02m, whole fp32x3 step at B = 32: 45.3 ms with the plain kernels' threshold (384 tiles),
+    // 38.1 ms without small tiles, 60.0 ms with small tiles everywhere.  SSR_X3_SMALL = threshold in 8x16 tiles (tuning hook).
+    static const long thr = [] { const char* e = getenv("SSR_X3_SMALL"); return e ? atol(e) : 0L; }();
+    small = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32)) < thr;
     if (nt2) return small ? launch_conv_x3<KH, KW, 2, 2, 2>(d, st) : launch_conv_x3<KH, KW, 2, 4, 2>(d, st);
     return small ? launch_conv_x3<KH, KW, 1, 2, 2>(d, st) : launch_conv_x3<KH, KW, 1, 4, 2>(d, st);
 }

@@ -59,11 +59,12 @@ def _gen_state(c_in, nb, seed=11):
 
 # (mode, C_in, B): bf16 — the benchmarked arithmetic — at every input width; the fp32 modes run the same kernels for any C_in
 # beyond conv_first, so they are checked at the headline width (and C_in 3 / 96 end to end further down)
-@pytest.mark.parametrize("mode,c_in,B", [("bf16", 24, 32), ("bf16", 3, 4), ("bf16", 96, 4), ("fp32", 24, 32), ("fp32x3", 24, 32),
-                                         ("fp32x3", 96, 4)])
+@pytest.mark.parametrize("mode,c_in,B", [("bf16", 24, 32), ("bf16", 24, 16), ("bf16", 3, 4), ("bf16", 96, 4), ("fp32", 24, 4),
+                                         ("fp32x3", 24, 32)])
 def test_generator_every_layer_at_baseline_shape(mode, c_in, B):
     """SSR_RRDBNet(nf=64, nb=23, gc=32) forward + backward, 32x32 tiles: 351 convs forward, their dgrads, 351 weight and
-    bias gradients, layer by layer.  (24, 32) is the benchmarked configuration exactly."""
+    bias gradients, layer by layer.  (24, 32) is the benchmarked configuration exactly, (24, 16) the launch size of its two
+    half-batch chains (kernel variants are chosen by grid size)."""
     from oracle import layerwise as LW
     from satlas_super_resolution_amd import engine
     if mode != "bf16" and B > 4:
@@ -284,7 +285,7 @@ def test_infer_grid_tile_end_to_end_vs_oracle(mode):
     """One 16x16 grid of Sentinel-2 chunks -> format_s2naip_data -> SSR_RRDBNet plugin (8xS2 model, nb=23) in batches ->
     truncating uint8 -> stitch: the 2048x2048x3 uint8 tile against the oracle's.  fp32 arithmetic differs in summation
     order, so a value within ~1e-6 of an integer boundary may truncate to the neighbouring byte: at most 1 level, on a
-    vanishing fraction of the 12.6 M samples (counted and bounded), everything else bit-identical.  Run in the parity mode
+    vanishing fraction of the samples (counted and bounded), everything else bit-identical.  Run in the parity mode
     (fp32x3; measured 6.3e-4 of the samples, exact fp32: 4.9e-5 in r02a)."""
     import random
 
@@ -314,18 +315,19 @@ def test_infer_grid_tile_end_to_end_vs_oracle(mode):
     assert sorted(r1) == list(range(1, 32, 2)) and all((r1[i] == got[i]).all() for i in r1)
     tile = U.stitch_arrays({k: got[n] for n, k in enumerate(keys)}, 2048, grid_size=16)
     assert tile.shape == (2048, 2048, 3) and tile.dtype == np.uint8
-    ref_chunks = {}
+    # the oracle recomputes every 4th chunk (64 of the 256; 3.1 M samples) and each is compared at ITS place in the stitched tile
+    sel = list(range(0, 256, 4))
+    diffs = []
     with torch.no_grad():
-        for b0 in range(0, 256, 32):
-            y = O.generator_forward(sd, torch.cat(inputs[b0:b0 + 32]), 4)
+        for b0 in range(0, len(sel), 32):
+            idx = sel[b0:b0 + 32]
+            y = O.generator_forward(sd, torch.cat([inputs[n] for n in idx]), 4)
             q = O.quantize_u8_truncate(y).permute(0, 2, 3, 1).numpy()
-            for n in range(32):
-                ref_chunks[keys[b0 + n]] = q[n]
-    ref = np.zeros((2048, 2048, 3), np.uint8)
-    for (i, j), c in ref_chunks.items():
-        a, b = O.stitch_offsets(16, 128)[i][j]
-        ref[a:a + 128, b:b + 128] = c
-    diff = np.abs(tile.astype(np.int16) - ref.astype(np.int16))
+            for k, n in enumerate(idx):
+                i, j = keys[n]
+                a, b = O.stitch_offsets(16, 128)[i][j]
+                diffs.append(np.abs(tile[a:a + 128, b:b + 128].astype(np.int16) - q[k].astype(np.int16)))
+    diff = np.stack(diffs)
     frac = float((diff > 0).mean())
     assert diff.max() <= 1, int(diff.max())
     assert frac < (2e-3 if mode == "fp32" else 5e-3), frac

@@ -381,7 +381,7 @@ __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
         const int row = v / VPR, part = v - row * VPR;
         const int tap = row / BN, co = row - tap * BN;
         wgo[q] = v < WVEC ? (tap * d.CoutPad + co0 + co) * CK + part * VEC : -1;
-        wlo[q] = (PH * PW + row) * ROWB + part * 8;
+        wlo[q] = (PH * PW + row) * ROWB + part * 16;            // packed rows arrive pre-split [16 hi | 16 lo] (misc.hip put_packed)
     }
     u32x4 rp[NPV], rw[NWV];
     auto load_chunk = [&](int c) {
@@ -412,11 +412,7 @@ __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
             }
 #pragma unroll
         for (int q = 0; q < NWV; ++q)
-            if (wgo[q] >= 0) {
-                split4(rw[q], hi, lo);
-                *reinterpret_cast<uint2*>(base + wlo[q]) = hi;
-                *reinterpret_cast<uint2*>(base + wlo[q] + 32) = lo;
-            }
+            if (wgo[q] >= 0) *reinterpret_cast<u32x4*>(base + wlo[q]) = rw[q];
     };
 
     f32x16 acc[NT];

@@ -34,7 +34,23 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // taps of a pair are contiguous (36 / 64 bytes) and for a fixed tap consecutive threads write consecutive packed
 // elements.  (r01 rocprofv3: the element-per-thread version with 64-bit div/mod per element and stride-KK gathers
 // took 110 us per launch, 4 launches per step.)
-template <typename T>
+// SSR_F32X3: packed rows of 16 input channels are stored pre-split — [16 x hi = bf16(w) | 16 x lo = bf16(w - hi)], the same 64
+// bytes as 16 floats — so the split-bf16 conv kernel copies weight rows to LDS as they are (the weight slab is 60-75 % of what
+// a workgroup stages per chunk, and every workgroup would otherwise repeat the same conversion).  Rows of 8 (the 4x4 stride-2
+// forward layers, which run on the exact fp32 kernel) stay plain fp32.
+template <typename T, bool X3>
+__device__ __forceinline__ void put_packed(T* __restrict__ dst, size_t idx, int ck, float v) {
+    if (X3 && ck == 16) {
+        __bf16* row = reinterpret_cast<__bf16*>(dst) + (idx >> 4) * 32;
+        const __bf16 h = (__bf16)v;
+        row[idx & 15] = h;
+        row[16 + (idx & 15)] = (__bf16)(v - (float)h);
+    } else {
+        dst[idx] = from_f32<T>(v);
+    }
+}
+
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restrict__ items) {
     const ssr_pack_item it = items[blockIdx.y];
     const int KK = it.KH * it.KW;
@@ -56,12 +72,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
                 const int nch = it.CinPad / ck;
                 for (int tap = 0; tap < 16; ++tap) {
                     const int ky = tap >> 2, kx = tap & 3, q = (ky & 1) * 2 + (kx & 1), tt = (ky >> 1) * 2 + (kx >> 1);
-                    dst[((((size_t)q * nch + chunk) * 4 + tt) * it.CoutPad + co) * ck + cc] = from_f32<T>(ok ? sp[tap] * inv : 0.f);
+                    put_packed<T, X3>(dst, ((((size_t)q * nch + chunk) * 4 + tt) * it.CoutPad + co) * ck + cc, ck, ok ? sp[tap] * inv : 0.f);
                 }
                 continue;
             }
-            T* dp = dst + ((size_t)chunk * KK * it.CoutPad + co) * ck + cc;
-            for (int tap = 0; tap < KK; ++tap) dp[(size_t)tap * it.CoutPad * ck] = from_f32<T>(ok ? sp[tap] * inv : 0.f);
+            const size_t dp = ((size_t)chunk * KK * it.CoutPad + co) * ck + cc;
+            for (int tap = 0; tap < KK; ++tap) put_packed<T, X3>(dst, dp + (size_t)tap * it.CoutPad * ck, ck, ok ? sp[tap] * inv : 0.f);
         }
     }
     if (it.dst_dgrad) {
@@ -75,9 +91,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
             const float* __restrict__ sp = it.src + ((size_t)k * it.Cin + o) * KK;
             if (it.stride == 1) {
                 // Wd[chunk][tap'][o = ci][k = co] = W[co][ci][KK-1-tap']   (180-degree rotated, transposed)
-                T* dp = dst + ((size_t)chunk * KK * it.CinPadO + o) * ck + cc;
+                const size_t dp = ((size_t)chunk * KK * it.CinPadO + o) * ck + cc;
                 for (int tap = 0; tap < KK; ++tap)
-                    dp[(size_t)tap * it.CinPadO * ck] = from_f32<T>(ok ? sp[KK - 1 - tap] * inv : 0.f);
+                    put_packed<T, X3>(dst, dp + (size_t)tap * it.CinPadO * ck, ck, ok ? sp[KK - 1 - tap] * inv : 0.f);
             } else {
                 // 4x4 stride-2 transposed conv as four output-parity classes of 2x2 taps:
                 // class (py,px), tap (ty,tx): ky = py ? 2-2*ty : 3-2*ty (same for x); [cls][chunk][t][o][ck]
@@ -86,15 +102,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
                     for (int tt = 0; tt < 4; ++tt) {
                         const int py = cls >> 1, px = cls & 1, ty = tt >> 1, tx = tt & 1;
                         const int ky = py ? 2 - 2 * ty : 3 - 2 * ty, kx = px ? 2 - 2 * tx : 3 - 2 * tx;
-                        dst[cls * per_cls + (((size_t)chunk * 4 + tt) * it.CinPadO + o) * ck + cc] =
-                            from_f32<T>(ok ? sp[ky * 4 + kx] * inv : 0.f);
+                        put_packed<T, X3>(dst, cls * per_cls + (((size_t)chunk * 4 + tt) * it.CinPadO + o) * ck + cc, ck,
+                                          ok ? sp[ky * 4 + kx] * inv : 0.f);
                     }
             }
         }
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void pack_seg_kernel(const ssr_pack_seg* __restrict__ items) {
     const ssr_pack_seg it = items[blockIdx.y];
     T* __restrict__ dst = reinterpret_cast<T*>(it.dst);
@@ -104,9 +120,9 @@ __global__ __launch_bounds__(256) void pack_seg_kernel(const ssr_pack_seg* __res
         const int k = it.kbase + kk, chunk = k / it.ck, cc = k - chunk * it.ck;
         const bool ok = o < it.nci;
         const float* __restrict__ sp = it.src + ((size_t)kk * it.Cin + it.ci0 + o) * 9;
-        T* dp = dst + ((size_t)chunk * 9 * it.rows_pad + o) * it.ck + cc;
+        const size_t dp = ((size_t)chunk * 9 * it.rows_pad + o) * it.ck + cc;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) dp[(size_t)tap * it.rows_pad * it.ck] = from_f32<T>(ok ? it.scale * sp[8 - tap] : 0.f);
+        for (int tap = 0; tap < 9; ++tap) put_packed<T, X3>(dst, dp + (size_t)tap * it.rows_pad * it.ck, it.ck, ok ? it.scale * sp[8 - tap] : 0.f);
     }
 }
 
@@ -562,12 +578,12 @@ inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items, int32_t dtype, void* stream) {
-    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
     // a table of a few large layers (the discriminator: conv3 alone is 131k (co, ci) pairs x 16 taps) needs more than 64
     // workgroups per layer to fill the chip (r01 rocprofv3: 42 us for 35 MB); the generator's 351 small layers do not
     dim3 grid(n_items <= 16 ? 1024 : 64, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_kernel<float, true>), grid, dim3(256), 0, ST(stream), items_dev);
     else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
     else return SSR_EUNSUP;
     SSR_LAUNCH_CHECK();
@@ -575,10 +591,10 @@ extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items,
 }
 
 extern "C" int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_items, int32_t dtype, void* stream) {
-    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
     dim3 grid(8, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_seg_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_seg_kernel<float, true>), grid, dim3(256), 0, ST(stream), items_dev);
     else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_seg_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
     else return SSR_EUNSUP;
     SSR_LAUNCH_CHECK();

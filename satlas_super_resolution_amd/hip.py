@@ -216,7 +216,9 @@ def view(t: Optional[torch.Tensor], coff: int = 0) -> View:
     if t is None:
         return View(None, 0, 0)
     assert t.is_contiguous()
-    _PARENTS[t.data_ptr()] = t
+    old = _PARENTS.get(t.data_ptr())
+    if old is None or old.numel() < t.numel():      # a leading slice shares its base address with the whole buffer: keep the larger
+        _PARENTS[t.data_ptr()] = t
     return View(t.data_ptr(), t.shape[-1], coff)
 
 

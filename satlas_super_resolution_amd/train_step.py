@@ -141,6 +141,7 @@ class ESRGANTrainStep:
         import os
         # r02c, same box, B=32 8xS2 bf16: 13.94 -> 13.27 ms per step with the fork (two pairs, +-0.02)
         self.overlap_d = os.environ.get("SSR_OVERLAP_D", "1") == "1"
+        self.dp_fork = os.environ.get("SSR_DP_FORK", "1") == "1"
         # the real-phase discriminator pass ahead of its place in the reference's order, beside G's forward (see _step_d_ahead)
         # (r02k, same box: 13.25 -> 13.15 ms at B = 32, 7.31 -> 7.45 ms at B = 16: the two forward chains mostly take CUs from
         # each other; correct — the golden / oracle step tests pass with it — and left off)
@@ -354,7 +355,28 @@ class ESRGANTrainStep:
         self.iter = self.iter + 1 if current_iter is None else current_iter
         cfg = self.cfg
         g_on = (self.iter % cfg.net_d_iters == 0) and (self.iter > cfg.net_d_init_iters)
-        if self.dp.active:
+        if self.dp.active and g_on and self.overlap_d and self.dp_fork:
+            # data parallel, forked: as in the single-process step the discriminator phases run on a side stream beside G's
+            # backward; each network's gradient exchange follows its own backward and each Adam its own exchange.  Collectives are
+            # ISSUED in the same program order on every rank (D's, then G's; they execute in that order on the one comm stream).
+            self._run("g_pre", lambda: self._phase_g(run_bwd=False))
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._run("d", self._phase_d)
+                hd = self.dp.all_reduce_async(self.d_store.grad)
+            self._run("g_bwd", self.g_plan.bwd.run)
+            hg = self.dp.all_reduce_async(self.g_store.grad)
+            with torch.cuda.stream(side):
+                self.dp.wait(hd)
+                self._run("opt_d", self._phase_opt_d)
+            self.dp.wait(hg)
+            self._run("opt_g", self._phase_opt_g)
+            cur.wait_stream(side)
+        elif self.dp.active:
             hg = None
             if g_on:
                 self._run("g", self._phase_g)

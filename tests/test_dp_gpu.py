@@ -157,7 +157,7 @@ def _rccl_worker(port, outdir):
                 logs.append(dict(ts.log()))
         torch.cuda.synchronize()
         if dp.active:
-            assert set(ts._graphs) == {"g", "d", "opt_g", "opt_d"}, set(ts._graphs)
+            assert set(ts._graphs) == {"g_pre", "g_bwd", "d", "opt_g", "opt_d"}, set(ts._graphs)
         res[name] = (logs, ts.g_store.data.cpu().clone(), ts.d_store.data.cpu().clone(), ts.opt_g.ema.cpu().clone())
     torch.save(res, os.path.join(outdir, "rccl.pt"))
     torch.distributed.destroy_process_group()

@@ -85,11 +85,14 @@ class SSRESRGANModel:
         self.device = torch.device("cuda")
         self.dp = init_distributed() if opt.get("dist", False) else None
         self.g_kwargs = _arch_kwargs(opt["network_g"], "SSR_RRDBNet")
-        self.d_kwargs = _arch_kwargs(opt["network_d"], "SSR_UNetDiscriminatorSN")
         self.compute_dtype = self.g_kwargs.pop("compute_dtype", opt.get("compute_dtype", "fp32"))
-        self.d_kwargs.pop("compute_dtype", None)
         self.feed_disc_lr = bool(opt.get("feed_disc_lr", False))
-        self.cfg = step_config_from_opt(opt)
+        if self.is_train:      # test.py builds the model with is_train=False: generator only (SRGANModel.__init__ / init_training_settings)
+            self.d_kwargs = _arch_kwargs(opt["network_d"], "SSR_UNetDiscriminatorSN")
+            self.d_kwargs.pop("compute_dtype", None)
+            self.cfg = step_config_from_opt(opt)
+        else:
+            self.d_kwargs, self.cfg = None, StepConfig()
         sch = opt.get("train", {}).get("scheduler", {})
         self.milestones = list(sch.get("milestones", []))
         self.gamma = float(sch.get("gamma", 0.1)) if sch else 1.0
@@ -166,7 +169,7 @@ class SSRESRGANModel:
         """ssr_esrgan_model.py:104-117: uint8 tensors -> float/255 on the device."""
         lr = data["lr"].to(self.device, non_blocking=True).float()
         B, _, h, w = lr.shape
-        if self._validating and self.ts is not None:
+        if not self.is_train or (self._validating and self.ts is not None):
             # validation batches (usually of another size) only feed test(): the train step, its plans and graphs stay as they are
             self.lr = lr / 255
             self.gt = data["hr"].to(self.device, non_blocking=True).float() / 255 if "hr" in data else None
@@ -217,15 +220,32 @@ class SSRESRGANModel:
         ts = self.ts
         B, _, h, w = self.lr.shape
         key = (B, h, w)
+        dt = ts.dt if ts is not None else hip.dtype_code(self.compute_dtype)
         if self._infer is None or self._infer[0] != key:
-            st = self._infer[1] if self._infer is not None else engine.ParamStore(engine.generator_specs(**self.g_kwargs), ts.dt)
+            st = self._infer[1] if self._infer is not None else engine.ParamStore(engine.generator_specs(**self.g_kwargs), dt)
+            if self._infer is None and ts is None:
+                st.load_state_dict(self._test_weights())
             self._infer = (key, st, engine.GeneratorPlan(st, B, h, w, training=False, **self.g_kwargs))
         _, st, plan = self._infer
-        st.data.copy_(ts.opt_g.ema if ts.opt_g.ema is not None else ts.g_store.data)
+        if ts is not None:
+            st.data.copy_(ts.opt_g.ema if ts.opt_g.ema is not None else ts.g_store.data)
         st.pack()
         plan.load_input((self.lr * 255).contiguous(), 1.0 / 255)
         plan.fwd.run()
         self.output = plan.read_output()
+
+    def _test_weights(self):
+        """is_train=False (test.py): load_network(net_g, pretrain_network_g, strict_load_g, param_key_g); without a checkpoint the
+        default initialisation under manual_seed, as constructing the reference model would give."""
+        path = self.opt.get("path", {}) or {}
+        if path.get("pretrain_network_g"):
+            ck = torch.load(path["pretrain_network_g"], map_location="cpu")
+            return ck[path.get("param_key_g", "params")]
+        from ..archs.rrdbnet_arch import SSR_RRDBNet
+        with torch.random.fork_rng(devices=[]):
+            if self.opt.get("manual_seed") is not None:
+                torch.manual_seed(int(self.opt["manual_seed"]))
+            return SSR_RRDBNet(**self.g_kwargs).state_dict()
 
     def get_current_visuals(self):
         out = OrderedDict()

@@ -369,6 +369,8 @@ def test_split_generator_chains_match_the_single_chain(monkeypatch):
     ref = res[("0", False)]
     for key in (("2", False), ("2", True)):
         out, gg, dg, log = res[key]
+        print(f"\n[split {key}] out {rel_err(out, ref[0]):.2e} mean {float((out - ref[0]).abs().mean() / ref[0].abs().max()):.2e} "
+              f"g-grads {rel_err(gg, ref[1]):.2e} d-grads {rel_err(dg, ref[2]):.2e}")
         assert rel_err(out, ref[0]) < 1e-2 and float((out - ref[0]).abs().mean() / ref[0].abs().max()) < 2e-4, (key, rel_err(out, ref[0]))
         assert rel_err(gg, ref[1]) < 3e-2 and rel_err(dg, ref[2]) < 3e-2, (key, rel_err(gg, ref[1]), rel_err(dg, ref[2]))
         for k, v in ref[3].items():

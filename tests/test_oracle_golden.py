@@ -150,3 +150,47 @@ def test_metrics_oracle_cpsnr_matches_reference_golden():
     assert 0.9 < MO.calculate_ssim(a, b, 4) < 1.0
     g = MO._gauss()
     assert abs(g.sum() - 1) < 1e-15 and abs(g[5] / g[4] - np.exp(1 / (2 * 1.5 ** 2))) < 1e-12
+
+
+def _full_inputs(fx, shape):
+    g = torch.Generator().manual_seed(fx["seed"] + 2)
+    x = torch.rand(*shape, generator=g)
+    assert torch.equal(x[0, :, 0, 0], fx["x_check"]), "seeded input differs from the one the golden was generated with"
+    return x, g
+
+
+@pytest.mark.parametrize("name,c_in", [("full_g24", 24), ("full_g96", 96)])
+def test_generator_full_size_matches_reference_golden(name, c_in):
+    """The oracle at the BENCHMARKED architecture (nf=64, gc=32, nb=23) against the unmodified reference class
+    (oracle/make_golden_fullsize.py; parameters rebuilt from the seed): output, input gradient, parameter gradients."""
+    from oracle.make_golden_fullsize import biased
+    fx = load_golden(name)
+    sd = biased(O.generator_init(seed=fx["seed"], **fx["kwargs"]), fx["seed"] + 1)
+    x, g = _full_inputs(fx, (2, c_in, 32, 32))
+    sdg = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    x = x.requires_grad_(True)
+    y = O.generator_forward(sdg, x, 4)
+    assert rel_err(y, fx["y"]) < TOL
+    r = torch.randn(y.shape, generator=g)
+    (y * r).sum().backward()
+    assert rel_err(x.grad, fx["dx"]) < 1e-4
+    for k, gr in fx["grads"].items():
+        assert rel_err(sdg[k].grad, gr) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["full_d3", "full_d27"])
+def test_discriminator_full_size_matches_reference_golden(name):
+    fx = load_golden(name)
+    sd = O.discriminator_init(fx["c_d"], 64, seed=fx["seed"])
+    sdg = OrderedDict((k, (v.clone().requires_grad_(True) if k in O.D_PARAM_KEYS else v.clone())) for k, v in sd.items())
+    x, g = _full_inputs(fx, (1, fx["c_d"], 128, 128))
+    x = x.requires_grad_(True)
+    y = O.discriminator_forward(sdg, x, train=True)
+    assert rel_err(y, fx["y"]) < TOL
+    r = torch.randn(y.shape, generator=g)
+    (y * r).sum().backward()
+    assert rel_err(x.grad[:, :3], fx["dx_first3"]) < 1e-4 and rel_err(x.grad[:, -3:], fx["dx_last3"]) < 1e-4
+    for k, gr in fx["grads"].items():
+        assert rel_err(sdg[k].grad, gr) < 1e-4, k
+    for k, v in fx["uv_after"].items():
+        assert rel_err(sdg[k], v) < TOL, k

@@ -417,7 +417,7 @@ def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
         assert e_dev <= 0.1 and m_dev <= 1e-2, (what, f_dev, e_dev, m_dev)      # sanity bound only: see the docstring
 
 
-@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24), ("fp32", "full_g96", 96)])
+@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24)])   # full_g96 pins the oracle (CPU test)
 def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
     """SSR_RRDBNet(nf=64, gc=32, nb=23) forward + backward on the device against what the UNMODIFIED reference class produced for
     the same parameters and inputs (oracle/make_golden_fullsize.py; the reference, not the oracle, is the comparison target)."""
@@ -450,7 +450,7 @@ def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
         _vs_truth(st.tensor(k, st.grad), gr, sd64[k].grad, k, mode)
 
 
-@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), ("fp32", "full_d27")])
+@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3")])                    # full_d27 pins the oracle (CPU test)
 def test_discriminator_vs_reference_class_at_full_size(mode, name):
     """SSR_UNetDiscriminatorSN(nf=64) on 128x128 (3- and 27-channel input) against the unmodified reference class: logits, input
     gradient, parameter gradients through the spectral norm, u / v after the power iteration."""

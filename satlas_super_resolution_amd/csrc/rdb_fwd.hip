@@ -39,6 +39,7 @@
 //   done_w[4]   (consumer w -> producers)  number of slabs wave w is finished with
 //   slice_cnt[] (consumers <-> consumers)  waves that have stored their part of slice K / arrived at the final sync
 #include "common.h"
+#include <stdlib.h>
 
 #ifdef SSR_PROBE   // tools/rdb_probe.hip
 #define PROBE(k)                                                                           \
@@ -737,6 +738,24 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
 
 }  // namespace
 
+// second-generation kernel (csrc/rdb_tile.hip): 8 x 16 or 8 x 8 tiles, swizzled rows, 6-KB slab ring
+int rdbt_launch(const ssr_rdb_desc& d, void* stream, bool bwd, int tw);
+// Tile choice.  SSR_RDB_TILE = 0: this file's kernel (8x8 tiles, 80-byte rows); 8 / 16: csrc/rdb_tile.hip with that tile
+// width; unset / "auto": 8x16 tiles when they still give every CU a workgroup (one workgroup owns a CU: 160 KB of LDS),
+// else the 8x8 tiles of rdb_tile.hip.
+int g_rdb_tile_override = -1;   // tools / tests: >= 0 overrides the environment
+static int rdb_pick_tile(const ssr_rdb_desc& d) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("SSR_RDB_TILE");
+        env = (e && *e && *e != 'a') ? atoi(e) : -1;
+    }
+    const int choice = g_rdb_tile_override >= 0 ? g_rdb_tile_override : env;
+    if (choice == 0 || choice == 8 || choice == 16) return choice;
+    const int t16 = d.N * ((d.H + 7) / 8) * ((d.W + 15) / 16);
+    return t16 >= 224 ? 16 : 8;
+}
+
 static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     if (!dp) return SSR_EINVAL;
     const ssr_rdb_desc& d = *dp;
@@ -748,6 +767,7 @@ static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     if (d.r2.p && ((d.r2.cs % 4) || (d.r2.coff % 4))) return SSR_EINVAL;
     for (int k = 0; k < 5; ++k)
         if (!d.w[k]) return SSR_EINVAL;
+    if (const int tw = rdb_pick_tile(d)) return rdbt_launch(d, stream, bwd, tw);
     static bool attr_done[2] = {false, false};
     const void* kern = bwd ? reinterpret_cast<const void*>(rdb_kernel<true>) : reinterpret_cast<const void*>(rdb_kernel<false>);
     if (!attr_done[bwd]) {

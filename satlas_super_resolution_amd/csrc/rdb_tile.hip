@@ -1,0 +1,868 @@
+// Fused ResidualDenseBlock forward / backward, second generation (bf16, num_feat = 64, num_grow_ch = 32): ONE launch for
+// /root/reference/ssr/archs/rrdbnet_arch.py:37-44
+//     x1 = lrelu(conv1(x)); x2 = lrelu(conv2(cat(x,x1))); ... x5 = conv5(cat(x..x4)); return x5*0.2 + x
+// (and the RRDB tail `out*0.2 + x`, :68, when this is the third block); rdbt_kernel<TW, true> is the gather-form backward
+// of the same block (ParamStore.add_rdb_gather): stage K produces dpre_{5-K} from [newer dpre | d_out].
+//
+// Same contract, descriptor and packed-weight formats as csrc/rdb_fwd.hip (the 8x8-tile kernel of rounds 1-2, kept for
+// small grids); what changed is everything the round-2 counters blamed:
+//   * tile 8 x TW pixels, TW = 16 (or 8): the 5-pixel halo recompute drops from 1.94x to 1.58x issued MFMAs per
+//     algorithmic MFMA, a weight fragment feeds 3 pixel tiles instead of 2 (1.33 instead of 1.5 LDS reads per MFMA),
+//     the 479 KB weight stream of a block is amortised over twice the pixels;
+//   * activation rows are dense 64-B rows (32 bf16), the 16-B parts XOR-swizzled by f = ((2Y + X) >> 2) & 3 of the
+//     pixel's coordinates in the tile's 18 x (TW+10) frame, and every slice has a row pitch = 2 (mod 4): the bank
+//     group of (pixel, part p) is 4*((2Y + X - 3S) & 3) + (p ^ f), a bijection of (2Y + X) mod 16 — so ANY 16 lanes
+//     whose pixels have distinct (2Y + X) mod 16 read conflict-free, in every slice and under every tap shift.
+//     The lane -> pixel table (rt_map) deals the pixels of a stage's region to lanes by that residue;
+//     (80-B padded rows of the first kernel: 160 KB for this tile; swizzled: 131 KB)
+//   * weight ring of 6-KB slabs (3 taps = one kernel row of one 32-channel chunk), 4 stages at TW = 16: the hand-over
+//     latency of the old two-stage 18-KB ring (830 cycles per slab, exposed in conv4/conv5) is covered by depth;
+//   * 4 MFMA waves + 4 producer waves = two waves per SIMD and 256 registers each (the old 4 + 6 left 168);
+//   * block -> tile map keeps the tiles of an image on ONE XCD (block b runs on XCD b % 8): halo re-reads hit that
+//     XCD's L2 instead of fetching every image into all eight.
+//
+// LDS map (TW = 16): ring 4 x 6144 B | bias table | control words | X0 2 planes x 468 rows | X1 414 | X2 308 | X3 262 |
+// X4 180 rows | dummy row = 159.9 KB.  After the prologue there is NO s_barrier: LDS flags as in rdb_fwd.hip
+//   ready[NST]  (producer -> consumers)    per ring stage: slabs its producer has published there
+//   done[4]     (consumer w -> producers)  number of slabs wave w is finished with
+//   slice[1..5] (consumers <-> consumers)  waves that have stored their part of slice K / arrived at the final sync
+#include "common.h"
+
+#ifdef SSR_PROBE   // tools/rdbt_probe.hip
+#define TPROBE(k)                                                                           \
+    do {                                                                                    \
+        if (threadIdx.x == 0) g_probe[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// fine stamps of wave 0 inside growth stage K: g_probe2[block][4*(K-1) + s], s = 0 stage entered, 1 pipeline primed,
+// 2 last MFMA issued, 3 slice stored
+#define TPROBE2(K, s)                                                                                        \
+    do {                                                                                                     \
+        if (threadIdx.x == 0) g_probe2[blockIdx.x * 16 + 4 * ((K) - 1) + (s)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TPROBE(k)
+#define TPROBE2(K, s)
+#endif
+
+namespace {
+
+// LDS accesses by 32-bit LDS address (address space 3): the operand addresses are per-lane integers (XOR swizzle), and a
+// generic `smem + offset` costs one v_add of the (zero) dynamic-LDS base per read
+#define RT_LDS __attribute__((address_space(3)))
+template <typename T> __device__ __forceinline__ T rt_lds_read(unsigned a) { return *(const RT_LDS T*)(uintptr_t)a; }
+template <typename T> __device__ __forceinline__ void rt_lds_write(unsigned a, const T& v) { *(RT_LDS T*)(uintptr_t)a = v; }
+typedef __bf16 rt_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned rt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rt_bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float rt_bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+constexpr int RT_SLAB = 6144;                      // 3 taps x 32 co x 32 ci (conv5: 3 taps x 64 co x 16 ci) bf16
+constexpr int RT_NSLAB = 78;                       // 6 + 9 + 12 + 15 + 36
+constexpr int RT_NPROD = 4, RT_NTHREADS = 256 + 64 * RT_NPROD;
+
+// ---- geometry of a tile of 8 x TW output pixels; frame = the 18 x (TW+10) halo region of the block input ----
+template <int TW> struct RtGeo {
+    static constexpr int RW0 = TW + 10, RH0 = 18;
+    static constexpr int rw(int s) { return RW0 - 2 * s; }
+    static constexpr int rh(int s) { return RH0 - 2 * s; }
+    static constexpr int pitch(int s) { return (rw(s) & 3) == 2 ? rw(s) : rw(s) + 2; }   // = 2 (mod 4)
+    static constexpr int rows(int s) { return (rh(s) - 1) * pitch(s) + rw(s); }
+    static constexpr int PLANE = rows(0) * 64;    // x: two planes of 32 channels
+    // the ring comes first: its offsets (and the flags') fit the 16-bit immediate of a DS instruction; the activation
+    // slices are addressed through per-lane registers anyway
+    static constexpr int NST = TW == 16 ? 4 : 8;  // ring stages
+    static constexpr int RING = 0;
+    static constexpr int BIAS = RING + NST * RT_SLAB;          // [4 x 32 + 64] fp32: conv k < 5 at k*32, conv5 at 128
+    static constexpr int CTL = BIAS + (4 * 32 + 64) * 4;       // 32 control words
+    static constexpr int ACT = CTL + 128;                      // multiple of 64
+    static constexpr int base(int s) { return s == 0 ? ACT : s == 1 ? ACT + 2 * PLANE : base(s - 1) + rows(s - 1) * 64; }
+    static constexpr int DUMMY = base(4) + rows(4) * 64;
+    static constexpr int SCR = DUMMY + 64;                     // 8 x 256 B: where lanes 1..63 of a flag write go
+    static constexpr int SRC = SCR + 2048;                     // [80] 64-bit source address of every weight slab
+    static constexpr int LDS = SRC + 640;
+    static_assert(ACT % 64 == 0, "activation rows are 64-byte aligned");
+    static constexpr int TROW = 144;              // output transpose slab: [32 px][64 co] bf16, 144-B rows, one per wave
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(NST * RT_SLAB >= 4 * 32 * TROW, "ring doubles as the output transpose slabs");
+    // M-tiles (32 pixels) per stage and per MFMA wave
+    static constexpr int ntiles(int K) {
+        return TW == 16 ? (K == 1 ? 12 : K == 2 ? 10 : K == 3 ? 8 : K == 4 ? 6 : 4) : (K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2);
+    }
+    static constexpr int nmt(int K) { return TW == 16 ? (K <= 2 ? 3 : K <= 4 ? 2 : 1) : (K <= 3 ? 2 : 1); }
+    static constexpr int NT5 = TW == 16 ? 2 : 1;  // N-tiles of conv5 per wave
+    // M-tile m of wave w in stage K (-1: none — the wave runs a dummy tile, the ring keeps the waves in lock step anyway)
+    static constexpr int tile_of(int K, int w, int m) {
+        if (TW == 16) {
+            if (K == 1) return w + 4 * m;
+            if (K == 2) return m < 2 ? w + 4 * m : (w < 2 ? 8 + w : -1);
+            if (K == 3) return w + 4 * m;
+            if (K == 4) return m == 0 ? w : (w >= 2 ? w + 2 : -1);
+            return w;
+        }
+        if (K == 1) return w + 4 * m;
+        if (K == 2) return m == 0 ? w : (w < 3 ? w + 4 : -1);
+        if (K == 3) return m == 0 ? w : (w == 3 ? 4 : -1);
+        if (K == 4) return w;
+        return w & 1;
+    }
+};
+constexpr int ctl_ready(int st) { return st; }   // [NST <= 8]
+constexpr int RT_CTL_DONE = 8;                       // [4], 16-byte aligned
+constexpr int RT_CTL_SLICE = 12;                     // [1..4] slice K complete, [5] final sync
+
+// ---- lane -> pixel map: stage K (region [K, 18-K) x [K, TW+10-K) of the frame), M-tile t, lane i & 31 ->
+//      Y | X << 5 | valid << 10 with (2Y + X) mod 16 == i mod 16.  Class c = region pixels with that residue, enumerated
+//      by rising (Y, X); M-tile t takes the class's entries 2t (lanes 0..15) and 2t+1 (lanes 16..31).  The hardware
+//      serves a ds_read_b128 in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): each holds 16 distinct
+//      classes.  Unused slots point at the class's first pixel with valid = 0. ----
+template <int TW> struct RtMap { unsigned short e[5][12][32]; };
+template <int TW> constexpr RtMap<TW> rt_make_map() {
+    using G = RtGeo<TW>;
+    RtMap<TW> m{};
+    for (int K = 1; K <= 5; ++K) {
+        const int nt = G::ntiles(K);
+        for (int c = 0; c < 16; ++c) {
+            int cnt = 0, first = 0;
+            for (int Y = K; Y < 18 - K; ++Y)
+                for (int X = K; X < G::RW0 - K; ++X) {
+                    if (((2 * Y + X) & 15) != c) continue;
+                    const unsigned short v = (unsigned short)(Y | (X << 5));
+                    if (cnt == 0) first = v;
+                    if (cnt < 2 * nt) m.e[K - 1][cnt >> 1][(cnt & 1) * 16 + c] = (unsigned short)(v | (1 << 10));
+                    ++cnt;
+                }
+            for (int sl = cnt; sl < 2 * nt; ++sl) m.e[K - 1][sl >> 1][(sl & 1) * 16 + c] = (unsigned short)first;
+        }
+    }
+    return m;
+}
+template <int TW> constexpr bool rt_map_complete() {   // every region pixel is owned by exactly one (tile, lane)
+    using G = RtGeo<TW>;
+    constexpr RtMap<TW> m = rt_make_map<TW>();
+    for (int K = 1; K <= 5; ++K) {
+        int n = 0;
+        for (int t = 0; t < G::ntiles(K); ++t)
+            for (int i = 0; i < 32; ++i) {
+                const int e = m.e[K - 1][t][i];
+                const int Y = e & 31, X = (e >> 5) & 31;
+                if (Y < K || Y >= 18 - K || X < K || X >= G::RW0 - K || ((2 * Y + X) & 15) != (i & 15)) return false;
+                if (e >> 10) ++n;
+            }
+        if (n != (18 - 2 * K) * (G::RW0 - 2 * K)) return false;
+    }
+    return true;
+}
+static_assert(rt_map_complete<16>(), "lane -> pixel map must cover every region exactly once");
+static_assert(rt_map_complete<8>(), "lane -> pixel map must cover every region exactly once");
+template <int TW> struct RtMapHolder { static const RtMap<TW> map; };
+__device__ const RtMap<16> rt_map16 = rt_make_map<16>();
+__device__ const RtMap<8> rt_map8 = rt_make_map<8>();
+template <int TW> __device__ __forceinline__ int rt_map_entry(int K, int t, int i) {
+    if constexpr (TW == 16) return rt_map16.e[K - 1][t][i];
+    else return rt_map8.e[K - 1][t][i];
+}
+
+// swizzle of a frame pixel: XOR applied to the 16-B part index of its 64-B row
+__device__ __forceinline__ int rt_f(int Y, int X) { return ((2 * Y + X) >> 2) & 3; }
+
+// ---- weight slab q of the block's schedule ----
+//   conv K = 1..4: chunks j = 0..K (32 input channels each: LDS slice (j < 2 ? 0 (plane j) : j - 1), oldest first so that
+//   the slice produced by the previous stage is needed last) x kernel rows ky = 0..2; conv5: chunks j = 0..5 x 16-channel
+//   halves h x ky.  Weight chunk in memory: forward = j (rrdbnet_arch.py:39-42 cat order); backward = [dpre newest ..
+//   oldest | d_out p0 p1] (ParamStore.add_rdb_gather) -> j < 2 ? K-1+j : K-j.
+//   conv1..4: [chunk of 32 ci][tap][32 co][32 ci]  -> a slab is 96 rows of 64 B, 16-B part XOR-swizzled by (row >> 2) & 3
+//   conv5   : [chunk of 16 ci][tap][64 co][16 ci]  -> a slab is 192 rows of 32 B, 16-B part XOR-swizzled by (row >> 3) & 1
+constexpr int rt_q0(int K) { return K == 1 ? 0 : K == 2 ? 6 : K == 3 ? 15 : K == 4 ? 27 : 42; }
+// Source address of slab q (6144 contiguous bytes of one packed weight array).  Evaluated ONCE per block, one slab per
+// thread, into an LDS table (the producers' loop then costs one ds_read_b64 per slab instead of a 40-instruction decode; and
+// hipcc turned every scalar formulation of "pick one of five kernel-argument pointers" into an indexed load from a scratch
+// copy of the pointers, i.e. a memory round trip in front of every slab).
+template <bool BWD>
+__device__ __forceinline__ unsigned long long rt_slab_src(const ssr_rdb_desc& d, int q) {
+    int k, r;
+    if (q < 6) { k = 0; r = q; }
+    else if (q < 15) { k = 1; r = q - 6; }
+    else if (q < 27) { k = 2; r = q - 15; }
+    else if (q < 42) { k = 3; r = q - 27; }
+    else { k = 4; r = q - 42; }
+    unsigned long long base = (unsigned long long)(uintptr_t)d.w[0];
+    base = k == 1 ? (unsigned long long)(uintptr_t)d.w[1] : base;
+    base = k == 2 ? (unsigned long long)(uintptr_t)d.w[2] : base;
+    base = k == 3 ? (unsigned long long)(uintptr_t)d.w[3] : base;
+    base = k == 4 ? (unsigned long long)(uintptr_t)d.w[4] : base;
+    int j, ky, tapblk;
+    if (k == 4) { j = r / 6; const int h = (r / 3) & 1; ky = r % 3; const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j; tapblk = (2 * c + h) * 9 + 3 * ky; }
+    else { j = r / 3; ky = r - 3 * j; const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j; tapblk = c * 9 + 3 * ky; }
+    return base + (unsigned long long)(tapblk * 2048);   // tap block: 32 co x 32 ci (conv5: 64 co x 16 ci) bf16 = 2048 B
+}
+typedef const __attribute__((address_space(1))) char* rt_gptr;   // global memory, explicitly (never a flat access)
+
+#ifndef RT_POLL_SLEEP
+#define RT_POLL_SLEEP 3
+#endif
+#ifndef RT_PF3
+#define RT_PF3 3      // operand prefetch distance in k-steps, stages with 3 M-tiles per wave (4 reads per k-step)
+#endif
+#ifndef RT_PF2
+#define RT_PF2 4      // ... stages with 1 or 2 M-tiles per wave
+#endif
+#ifndef RT_PF5
+#define RT_PF5 4      // ... conv5
+#endif
+// The MFMA waves are ISSUE bound (one wave per SIMD issues ~8 instructions per 32-cycle MFMA; r03 counters: the first cut
+// of this kernel spent 13 instructions per MFMA, 7 of them address arithmetic hipcc rematerialised instead of keeping
+// 40 registers).  rt_pin makes a value opaque: it must live in a register from here on.
+__device__ __forceinline__ void rt_pin(unsigned& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void rt_pin(int& v) { asm volatile("" : "+v"(v)); }
+
+// ---- LDS flags (workgroup scope: plain ds_read / ds_write, no cache or counter side effects) ----
+__device__ __forceinline__ int rt_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void rt_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void rt_inc(int* p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void rt_wait_ge(const int* p, int target) {
+    while (rt_ld(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+struct RtPix {            // this lane's pixel of one M-tile
+    int Y, X;             // frame coordinates
+    bool valid, inside;   // owns a region pixel / that pixel is inside the image
+    size_t gpix;          // clamped global pixel index (n*H + iy)*W + ix
+};
+__device__ __forceinline__ RtPix rt_pix(int e, bool real, int n, int ty0, int tx0, int H, int W) {
+    RtPix t;
+    t.Y = e & 31;
+    t.X = (e >> 5) & 31;
+    t.valid = real && (e >> 10) != 0;
+    const int iy = ty0 - 5 + t.Y, ix = tx0 - 5 + t.X;
+    t.inside = t.valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    t.gpix = (size_t)(n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
+    return t;
+}
+
+struct RtCtx {            // what every stage needs
+    const ssr_rdb_desc& d;
+    unsigned lds0;        // LDS address of the dynamic shared block (0 unless the toolchain places something before it)
+    int* ctl;
+    const float* bias_lds;
+    int n, ty0, tx0, tid, lane, wave, i, g;
+    int wb0, wb1;         // this lane's weight-fragment offsets inside a conv1..4 slab (k-substep 0 / 1), relative to the ring
+    int wb5;              // ... inside a conv5 slab (N-tile 0)
+    int hint;             // ready counter of the next slab's ring stage, sampled two k-steps ahead
+    unsigned ctlv;        // LDS address of the control words (pinned register: flag accesses are base + immediate)
+    unsigned donev;       // LDS address of this wave's done word
+#ifdef SSR_PROBE
+    unsigned long long wait_ticks = 0, wait_n = 0, slice_ticks = 0;
+#endif
+};
+template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
+    // slab q is the (q / NST + 1)-th user of stage q % NST; the stage's word counts the slabs its producer has published
+    // (the producer cannot publish slab q + NST before every consumer has released slab q, so the count is exact)
+    using G = RtGeo<TW>;
+    const int target = q / G::NST + 1;
+#ifdef RT_X_NOSYNC   // probe: no hand-over (wrong results)
+    return;
+#endif
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(c.hint) < target, 0)) {   // the word is the same for every lane: scalar compare + branch
+#ifdef SSR_PROBE   // slots 14 / 15 of thread 0's probe row: ticks spent polling for slabs, number of slabs that had to wait
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        while (rt_ld(c.ctl + ctl_ready(q % G::NST)) < target) __builtin_amdgcn_s_sleep(1);   // leave the issue slots to the producer wave of this SIMD
+#ifdef SSR_PROBE
+        c.wait_ticks += __builtin_amdgcn_s_memtime() - t0;
+        c.wait_n += 1;
+#endif
+    }
+}
+template <int TW> __device__ __forceinline__ void rt_sample(RtCtx& c, int q) {
+    c.hint = __hip_atomic_load((const RT_LDS int*)(uintptr_t)(c.ctlv + 4 * ctl_ready(q % RtGeo<TW>::NST)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rt_release(RtCtx& c, int upto) {   // this wave is finished with every slab < upto
+    // no exec games in the MFMA stream: lane 0 holds the address of the wave's done word, every other lane the address of
+    // its own dword of a scratch row — one conflict-free ds_write_b32
+    rt_lds_write<int>(c.donev, upto);
+    asm volatile("" ::: "memory");
+}
+
+// accumulator start: the bias of this lane's 16 channels (forward) / zero (backward: the gather dgrad has no bias)
+template <bool BWD>
+__device__ __forceinline__ void rt_acc_init(f32x16& acc, const float* bias_lds, int g) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (!BWD) bq = *reinterpret_cast<const f32x4*>(bias_lds + 8 * q4 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q4 + e] = bq[e];
+    }
+}
+// Epilogue of conv K < 5.  forward: x_K = lrelu(acc) (bias is already in acc); backward: dpre = acc * lrelu'(x_k)
+// (mk = the saved forward activation); zero outside the image (zero padding of the NEXT stage's input), packed to
+// bf16 and written to LDS slice K with four 8-byte stores.  C fragment with the operands swapped (weights = A): lane l
+// owns ONE pixel and 16 output channels co = 8*q4 + 4*(l>>5) + e.
+template <int TW, int K, bool BWD>
+__device__ __forceinline__ void rt_store_slice(const f32x16& acc, const RtPix& px, const rt_u32x2 (&mk)[4], unsigned lds0, int g) {
+    using G = RtGeo<TW>;
+    const int f0 = rt_f(px.Y, px.X);
+    const unsigned row = lds0 + (px.valid ? G::base(K) + 64 * ((px.Y - K) * G::pitch(K) + (px.X - K)) : G::DUMMY) + 8 * g;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q4 + e];
+        if (BWD) {
+            v[0] = lrelu_mask_lo(v[0], mk[q4][0]); v[1] = lrelu_mask_hi(v[1], mk[q4][0]);
+            v[2] = lrelu_mask_lo(v[2], mk[q4][1]); v[3] = lrelu_mask_hi(v[3], mk[q4][1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lrelu_max(v[e]);   // == lrelu(v)
+        }
+        rt_bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        rt_u32x2 w = __builtin_bit_cast(rt_u32x2, o);
+        w[0] = px.inside ? w[0] : 0u;
+        w[1] = px.inside ? w[1] : 0u;
+        rt_lds_write<rt_u32x2>(row + ((q4 ^ f0) << 4), w);
+    }
+}
+// backward: the 16 channels of x_k (k = 5 - K) of this lane's pixel, from the saved forward buffer
+template <int K>
+__device__ __forceinline__ void rt_load_mask(const ssr_rdb_desc& d, const RtPix& px, int g, rt_u32x2 (&mk)[4]) {
+    const __bf16* mp = reinterpret_cast<const __bf16*>(d.mask.p) + px.gpix * d.mask.cs + d.mask.coff + 64 +
+                       32 * (5 - K - 1) + 4 * g;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) mk[q4] = *reinterpret_cast<const rt_u32x2*>(mp + 8 * q4);
+}
+
+// cooperative write of the 8 x TW core of LDS slice K (32 channels) to the dense buffer: 16-B vectors, 256 threads
+template <int TW, int K, bool BWD>
+__device__ __forceinline__ void rt_flush_core(const ssr_rdb_desc& d, unsigned lds0, int n, int ty0, int tx0, int tid) {
+    using G = RtGeo<TW>;
+#pragma unroll
+    for (int rep = 0; rep < TW / 8; ++rep) {
+        const int v = tid + rep * 256;
+        const int q = v >> 2, part = v & 3;
+        const int cy = q / TW, cx = q - cy * TW;
+        const int Y = cy + 5, X = cx + 5;
+        const u32x4 val = rt_lds_read<u32x4>(lds0 + G::base(K) + 64 * ((Y - K) * G::pitch(K) + (X - K)) + ((part ^ rt_f(Y, X)) << 4));
+        const int iy = ty0 + cy, ix = tx0 + cx;
+        if (iy < d.H && ix < d.W) {
+            constexpr int KD = BWD ? 5 - K : K;      // backward stage K produces dpre_{5-K}
+            __bf16* dst = reinterpret_cast<__bf16*>(d.slices.p) + ((size_t)(n * d.H + iy) * d.W + ix) * d.slices.cs +
+                          d.slices.coff + 64 + 32 * (KD - 1) + part * 8;
+            *reinterpret_cast<u32x4*>(dst) = val;
+        }
+    }
+}
+
+// One growth conv (K = 1..4) for NMT M-tiles of this wave, as ONE software pipeline over its (K+1)*18 k-steps
+// (chunk j, kernel row ky, column kx, 16-channel k-substep kk); k-step n consumes weight slab Q0 + 3j + ky.
+// There is one MFMA wave per SIMD beside a producer wave, so LDS latency is hidden inside the wave: operand reads run PF
+// k-steps ahead of the MFMAs that consume them and the sched_barrier fences pin that order (left alone, hipcc sinks every
+// ds_read next to its MFMA).  Ring hand-over rides in the same stream: slab q is acquired right before its first operand
+// read and released right after its last one (LDS executes a wave's operations in order, so the flag write cannot overtake
+// the reads); the ready counter of the next slab is sampled two k-steps early.  The last chunk (j = K) reads slice K-1,
+// which the previous stage may still be writing: its first read waits for the slice and sends the slice's core to the
+// dense buffer first.
+template <int TW, int S> __device__ __forceinline__ unsigned rt_chunk_base(unsigned lds0, int Y, int X) {
+    // tap (0,0) neighbour of frame pixel (Y, X) in slice S (plane 0)
+    using G = RtGeo<TW>;
+    return lds0 + G::base(S) + 64 * ((Y - S - 1) * G::pitch(S) + (X - S - 1));
+}
+template <int TW, int K, int NMT, bool BWD>
+__device__ __forceinline__ void rt_stage(RtCtx& c, const int (&ent)[NMT], const bool (&real)[NMT]) {
+    using G = RtGeo<TW>;
+    constexpr int NS = (K + 1) * 18, PF = NMT >= 3 ? RT_PF3 : RT_PF2, NB = PF + 1, Q0 = rt_q0(K);
+    TPROBE2(K, 0);
+    f32x16 acc[NMT];
+    RtPix px[NMT];
+    // operand addresses of the current chunk, per M-tile: A[kk][t] = chunk base + ((kk*2 + g) ^ f_t) << 4 for the 7 values
+    // t = 2(ky-1) + (kx-1) + 3 of a tap's swizzle; a read is A + immediate (tap row/column, plane of x).  Pinned registers.
+    unsigned A0[NMT][7], A1[NMT][7];
+    rt_u32x2 mk[NMT][4];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        px[m] = rt_pix(ent[m], real[m], c.n, c.ty0, c.tx0, c.d.H, c.d.W);
+        const int v0 = 2 * px[m].Y + px[m].X;
+        const unsigned cb = rt_chunk_base<TW, 0>(c.lds0, px[m].Y, px[m].X);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            A0[m][t] = cb + ((c.g ^ (((v0 + t - 3) >> 2) & 3)) << 4);
+            A1[m][t] = A0[m][t] ^ 32u;
+            rt_pin(A0[m][t]);
+            rt_pin(A1[m][t]);
+        }
+    }
+    rt_acc_init<BWD>(acc[0], c.bias_lds + 32 * (K - 1), c.g);
+#pragma unroll
+    for (int m = 1; m < NMT; ++m) acc[m] = acc[0];
+    u32x4 bq[NB], aq[NB][NMT];
+    auto issue = [&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        constexpr int j = n / 18, r = n % 18, ky = r / 6, kx = (r % 6) / 2, kk = r % 2, q = Q0 + 3 * j + ky;
+        constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
+        if constexpr (r == 0 && j > 0) {
+            if constexpr (j == K && K > 1) {
+#ifdef SSR_PROBE
+                const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+                rt_wait_ge(c.ctl + RT_CTL_SLICE + (K - 1), 4);
+#ifdef SSR_PROBE
+                c.slice_ticks += __builtin_amdgcn_s_memtime() - ts0;
+#endif
+                rt_flush_core<TW, K - 1, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.tid);
+            }
+            if constexpr (j == K && BWD) {   // the epilogue's masks: requested one chunk (54 MFMAs or more) ahead
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) rt_load_mask<K>(c.d, px[m], c.g, mk[m]);
+            }
+            // chunk 1 is plane 1 of x: same registers, the plane is an immediate.  A later chunk moves every address by the
+            // distance between the two slices' bases for this lane's pixel (a multiple of 64: the swizzle bits stay).
+            if constexpr (j >= 2) {
+                constexpr int SP = j == 2 ? 0 : j - 2;
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    const unsigned delta = rt_chunk_base<TW, S>(0u, px[m].Y, px[m].X) - rt_chunk_base<TW, SP>(0u, px[m].Y, px[m].X);
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) {
+                        A0[m][t] += delta;
+                        A1[m][t] += delta;
+                        rt_pin(A0[m][t]);
+                        rt_pin(A1[m][t]);
+                    }
+                }
+            }
+        }
+        if constexpr (r % 6 == 0) rt_acquire<TW>(c, q);
+    };
+    // the reads of k-step n: part 0 = the weight fragment (+ the flag traffic of a slab boundary), part 1 + m = the pixel
+    // fragment of M-tile m.  Parts are issued one per MFMA gap (RT_INTERLEAVE) or together before the k-step's MFMAs.
+    auto issue_part = [&](auto n_c, auto p_c) {
+        constexpr int n = decltype(n_c)::value, part = decltype(p_c)::value;
+        constexpr int j = n / 18, r = n % 18, ky = r / 6, kx = (r % 6) / 2, kk = r % 2, q = Q0 + 3 * j + ky;
+        constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
+        constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
+        if constexpr (part == 0) {
+#ifdef RT_X_NOB   // probe: no weight-fragment reads (wrong results)
+            bq[n % NB] = u32x4{0x3c003c00u + (unsigned)c.wb0, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#else
+            bq[n % NB] = rt_lds_read<u32x4>((kk ? c.wb1 : c.wb0) + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048));
+#endif
+        } else {
+            constexpr int m = part - 1;
+#ifdef RT_X_NOA   // probe: no pixel-fragment reads (wrong results)
+            aq[n % NB][m] = u32x4{0x3c003c00u + A0[m][t], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#else
+            aq[n % NB][m] = rt_lds_read<u32x4>((kk ? A1[m][t] : A0[m][t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
+#endif
+            if constexpr (m == NMT - 1) {
+                if constexpr (r % 6 == 3 && q + 1 < RT_NSLAB) rt_sample<TW>(c, q + 1);
+                if constexpr (r % 6 == 5) rt_release(c, q + 1);
+            }
+        }
+    };
+    auto issue_all = [&](auto n_c) {
+        issue(n_c);
+        static_for<0, NMT + 1>([&](auto p_c) { issue_part(n_c, p_c); });
+    };
+    static_for<0, PF>(issue_all);
+    TPROBE2(K, 1);
+    static_for<0, NS>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        using NX = std::integral_constant<int, n + PF>;
+#ifdef RT_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NS) { issue(NX{}); issue_part(NX{}, std::integral_constant<int, 0>{}); }
+        static_for<0, NMT>([&](auto m_c) {
+            constexpr int m = decltype(m_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            mma16<__bf16>(acc[m], bq[n % NB], aq[n % NB][m]);   // A = weights (rows = co), B = pixels
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (n + PF < NS) issue_part(NX{}, std::integral_constant<int, m + 1>{});
+        });
+#else
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NS) issue_all(NX{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) mma16<__bf16>(acc[m], bq[n % NB], aq[n % NB][m]);   // A = weights (rows = co), B = pixels
+#endif
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    TPROBE2(K, 2);
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) rt_store_slice<TW, K, BWD>(acc[m], px[m], mk[m], c.lds0, c.g);
+    if (c.lane == 0) rt_inc(c.ctl + RT_CTL_SLICE + K);   // LDS ops of a wave execute in order
+    TPROBE2(K, 3);
+}
+
+// conv5 over the 8 x TW core: this wave's M-tile x NT5 N-tiles of 32 output channels; 108 k-steps (chunk j, 16-channel
+// half h, ky, kx), slab 42 + 6j + 3h + ky; chunk 5 reads slice 4.
+template <int TW, bool BWD>
+__device__ __forceinline__ void rt_stage5(RtCtx& c, f32x16 (&acc)[RtGeo<TW>::NT5], const RtPix& px, int nt0) {
+    using G = RtGeo<TW>;
+    constexpr int NT5 = G::NT5, NS = 108, PF = RT_PF5, NB = PF + 1;
+    unsigned A0[7], A1[7];
+    {
+        const int v0 = 2 * px.Y + px.X;
+        const unsigned cb = rt_chunk_base<TW, 0>(c.lds0, px.Y, px.X);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            A0[t] = cb + ((c.g ^ (((v0 + t - 3) >> 2) & 3)) << 4);
+            A1[t] = A0[t] ^ 32u;
+            rt_pin(A0[t]);
+            rt_pin(A1[t]);
+        }
+    }
+    u32x4 bq[NB][NT5], aq[NB];
+    auto issue = [&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        constexpr int j = n / 18, r = n % 18, h = r / 9, ky = (r % 9) / 3, kx = r % 3, q = 42 + n / 3;
+        constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
+        if constexpr (r == 0 && j > 0) {
+            if constexpr (j == 5) {
+#ifdef SSR_PROBE
+                const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+                rt_wait_ge(c.ctl + RT_CTL_SLICE + 4, 4);
+#ifdef SSR_PROBE
+                c.slice_ticks += __builtin_amdgcn_s_memtime() - ts0;
+#endif
+                rt_flush_core<TW, 4, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.tid);
+            }
+            if constexpr (j >= 2) {
+                constexpr int SP = j == 2 ? 0 : j - 2;
+                const unsigned delta = rt_chunk_base<TW, S>(0u, px.Y, px.X) - rt_chunk_base<TW, SP>(0u, px.Y, px.X);
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    A0[t] += delta;
+                    A1[t] += delta;
+                    rt_pin(A0[t]);
+                    rt_pin(A1[t]);
+                }
+            }
+        }
+        if constexpr (kx == 0) rt_acquire<TW>(c, q);
+        constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
+#pragma unroll
+        for (int u = 0; u < NT5; ++u)
+            bq[n % NB][u] = rt_lds_read<u32x4>(c.wb5 + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048 + u * 1024));
+        aq[n % NB] = rt_lds_read<u32x4>((h ? A1[t] : A0[t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
+        if constexpr (kx == 1 && q + 1 < RT_NSLAB) rt_sample<TW>(c, q + 1);
+        if constexpr (kx == 2) rt_release(c, q + 1);
+    };
+    static_for<0, PF>(issue);
+    static_for<0, NS>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NS) issue(std::integral_constant<int, n + PF>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NT5; ++u) mma16<__bf16>(acc[u], bq[n % NB][u], aq[n % NB]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int TW, bool BWD>
+__global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d) {
+    using G = RtGeo<TW>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SALU
+    const int i = lane & 31, g = lane >> 5;
+    const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + 7) / 8, tpi = tiles_x * tiles_y;
+    // block -> tile: block b runs on XCD b % 8 (observed placement; only speed depends on it).  The work list (image-major)
+    // is cut into 8 contiguous shares, one per XCD, so that the tiles of an image share an L2.
+    int item = blockIdx.x;
+    if ((gridDim.x & 7) == 0) item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int n = item / tpi;
+    const int trem = item - n * tpi;
+    const int ty_i = trem / tiles_x, tx_i = trem - ty_i * tiles_x;
+    const int ty0 = ty_i * 8, tx0 = tx_i * TW;
+    const int H = d.H, W = d.W;
+    const unsigned lds0 = (unsigned)(size_t)(RT_LDS char*)smem;
+    int* ctl = reinterpret_cast<int*>(smem + G::CTL);
+    float* bias_lds = reinterpret_cast<float*>(smem + G::BIAS);
+    TPROBE(0);
+    const bool producer = wave >= 4;
+    const int pw = wave - 4;
+    {
+        const int k = tid < 128 ? tid >> 5 : 4, cc = tid < 128 ? tid & 31 : tid - 128;   // 4 x 32 + 64 entries
+        const float* bp = k == 0 ? d.bias[0] : k == 1 ? d.bias[1] : k == 2 ? d.bias[2] : k == 3 ? d.bias[3] : d.bias[4];   // no indexed access: the
+        if (tid < 192) bias_lds[tid] = bp ? bp[cc] : 0.f;                                                                 // descriptor stays in SGPRs
+        if (tid >= 192 && tid < 224) ctl[tid - 192] = 0;
+        if (tid < 80) rt_lds_write<unsigned long long>(lds0 + G::SRC + 8 * tid, rt_slab_src<BWD>(d, min(tid, RT_NSLAB - 1)));
+    }
+    // ---- the 64-channel input halo region (x / d_out): 18 x (TW+10) pixels -> X0 (2 planes of 32 channels, swizzled rows),
+    //      staged through registers by ALL waves (the MFMA waves have nothing else to do before the barrier).  It is what the
+    //      first MFMA needs, so the producers issue its loads BEFORE their first weight slabs (a wave's loads return in order).
+    constexpr int NPX0 = 18 * G::RW0, NV0 = 2 * NPX0 * 4, NQ = (NV0 + RT_NTHREADS - 1) / RT_NTHREADS;
+    auto x0_load = [&](u32x4 (&rx)[NQ]) {
+        const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.in.p);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = tid + q * RT_NTHREADS;                 // (plane, pixel, part)
+            const int plane = v / (NPX0 * 4), r2 = v - plane * (NPX0 * 4);
+            const int pix = r2 >> 2, part = r2 & 3;
+            const int py = pix / G::RW0, pxx = pix - py * G::RW0;
+            const int iy = ty0 - 5 + py, ix = tx0 - 5 + pxx;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < NV0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * H + iy) * W + ix) * d.in.cs + d.in.coff +
+                                                      plane * 32 + part * 8);
+            rx[q] = val;
+        }
+    };
+    auto x0_store = [&](const u32x4 (&rx)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = tid + q * RT_NTHREADS;
+            const int plane = v / (NPX0 * 4), r2 = v - plane * (NPX0 * 4);
+            const int pix = r2 >> 2, part = r2 & 3;
+            const int py = pix / G::RW0, pxx = pix - py * G::RW0;
+            if (v < NV0) rt_lds_write<u32x4>(lds0 + G::base(0) + plane * G::PLANE + 64 * pix + ((part ^ rt_f(py, pxx)) << 4), rx[q]);
+        }
+    };
+    // ---- producer waves: the block's data movers ----
+    if (producer) {
+        u32x4 rx[NQ];
+        x0_load(rx);
+        // wave pw owns the slabs q = pw (mod 4) and with them the ring stages q % NST (NST = 4: exactly one), so a stage's
+        // ready word has ONE writer and a slab costs one decode, six loads, six stores and one flag; a queue of RT_RQ whole
+        // slabs (6 KiB: six 16-byte vectors per lane) lives in registers.  (r03: dealing 1-KiB pieces round-robin made the
+        // producers instruction bound — ~100 mostly scalar instructions per piece — and they paced the whole block.)
+        constexpr int RT_RQ = 3, NSP = (RT_NSLAB + RT_NPROD - 1) / RT_NPROD;    // up to 20 slabs per producer
+        static_assert(G::NST % RT_NPROD == 0, "a ring stage belongs to one producer");
+        u32x4 wq[RT_RQ][6];
+        // lane's 16 bytes inside a 1-KiB piece: conv1..4 rows of 64 B (part swizzled by (row >> 2) & 3), conv5 rows of 32 B
+        // (by (row >> 3) & 1); the row phase of a piece is a multiple of 16 rows, so the pattern is the same for every piece
+        const int lo14 = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        const int lo5 = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+        auto load_from = [&](unsigned long long src64, int q, u32x4 (&r)[6]) {
+            rt_gptr src = (rt_gptr)src64;
+            const int lo = q >= 42 ? lo5 : lo14;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
+        };
+        // slab q >= 12: its source comes from the LDS table (beyond the end: the last slab again, never stored)
+        auto load_slab = [&](int q, u32x4 (&r)[6]) {
+            const int qc = min(q, RT_NSLAB - 1);
+            unsigned long long a;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"((int)lds0 + G::SRC + 8 * qc) : "memory");
+            const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            load_from(((unsigned long long)ahi << 32) | alo, qc, r);
+        };
+        // the first RT_RQ slabs go out before the barrier (the table is not there yet): decoded on the vector unit from an
+        // opaque copy of q, so that the pointer pick stays a v_cndmask chain
+        static_for<0, RT_RQ>([&](auto uc) {
+            const int q = pw + RT_NPROD * decltype(uc)::value;
+            int qv = q;
+            rt_pin(qv);
+            const unsigned long long a = rt_slab_src<BWD>(d, qv);
+            const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            load_from(((unsigned long long)ahi << 32) | alo, q, wq[decltype(uc)::value]);
+        });
+        x0_store(rx);
+        __syncthreads();   // the only barrier: X0, bias table, source table, zeroed control words
+#ifdef RT_X_NOPROD   // probe: the MFMA waves alone (with RT_X_NOSYNC)
+        return;
+#endif
+        // slab s of this wave (q = pw + 4 s): registers (requested RT_RQ slabs ahead) -> ring stage q % NST once every MFMA
+        // wave is finished with slab q - NST -> publish.  LDS operations of a wave execute in order, so the flag follows
+        // the data.
+#ifdef SSR_PROBE   // producer wave 4: ticks waiting for the consumers (slot 11), waiting for its loads + storing (12)
+        unsigned long long pacc[2] = {0, 0};
+#define RT_PT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RT_PADD(k, a, b) pacc[k] += (b) - (a)
+#else
+#define RT_PT(var)
+#define RT_PADD(k, a, b)
+#endif
+        unsigned stv = lds0 + G::RING + lane * 16;             // + stage * RT_SLAB + e * 1024
+        unsigned flagv = lane == 0 ? lds0 + G::CTL : lds0 + G::SCR + 256 * wave + 4 * lane;   // lane 0: the ready words; others: scratch
+        rt_pin(stv);
+        rt_pin(flagv);
+        auto put = [&](int q, const u32x4 (&r)[6]) {
+            RT_PT(tp0);
+#ifndef RT_X_NOSYNC
+            if (q >= G::NST) {
+                for (;;) {
+                    // inline asm: a compiler-visible LDS read here would make hipcc drain the refill loads first
+                    u32x4 dn;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
+                    const int dmin = (int)min(min(dn[0], dn[1]), min(dn[2], dn[3]));
+                    if (__builtin_amdgcn_readfirstlane(dmin) >= q - (G::NST - 1)) break;
+                    __builtin_amdgcn_s_sleep(RT_POLL_SLEEP);   // the ring is normally full: a poll per ~200 cycles is plenty and costs the MFMA wave of this SIMD nothing
+                }
+            }
+#endif
+            RT_PT(tp1);
+            const int st = q % G::NST;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) rt_lds_write<u32x4>(stv + st * RT_SLAB + e * 1024, r[e]);
+            rt_lds_write<int>(flagv + (lane == 0 ? 4 * ctl_ready(0) + 4 * st : 0), q / G::NST + 1);
+            asm volatile("" ::: "memory");
+            RT_PT(tp2);
+            RT_PADD(0, tp0, tp1);
+            RT_PADD(1, tp1, tp2);
+        };
+        for (int s0 = 0; s0 < NSP; s0 += RT_RQ)
+            static_for<0, RT_RQ>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int q = pw + RT_NPROD * (s0 + u);
+                if (q < RT_NSLAB) put(q, wq[u]);
+                // refill unconditionally so that the number of loads in flight is the same on every path and the compiler's
+                // vmcnt bookkeeping keeps the queue RT_RQ slabs deep
+                load_slab(q + RT_NPROD * RT_RQ, wq[u]);
+            });
+#ifdef SSR_PROBE
+        if (tid == 256) { g_probe[blockIdx.x * 16 + 11] = pacc[0]; g_probe[blockIdx.x * 16 + 12] = pacc[1]; }
+#endif
+        return;
+    }
+    // ---------------- MFMA waves ----------------
+    u32x4 rx0[NQ];
+    x0_load(rx0);
+    // this lane's pixels (rt_map) for every stage, requested now
+    const int w4 = wave & 3;
+    int ent1[G::nmt(1)], ent2[G::nmt(2)], ent3[G::nmt(3)], ent4[G::nmt(4)];
+    bool real1[G::nmt(1)], real2[G::nmt(2)], real3[G::nmt(3)], real4[G::nmt(4)];
+    auto fetch = [&](int K, int m, int& e, bool& rl) {
+        int t = 0;
+        // tile_of is constexpr in (K, w, m); w is a run-time value: select over the four waves
+        const int t0 = G::tile_of(K, 0, m), t1 = G::tile_of(K, 1, m), t2 = G::tile_of(K, 2, m), t3 = G::tile_of(K, 3, m);
+        t = w4 == 0 ? t0 : w4 == 1 ? t1 : w4 == 2 ? t2 : t3;
+        rl = t >= 0;
+        e = rt_map_entry<TW>(K, rl ? t : 0, i);
+    };
+#pragma unroll
+    for (int m = 0; m < G::nmt(1); ++m) fetch(1, m, ent1[m], real1[m]);
+#pragma unroll
+    for (int m = 0; m < G::nmt(2); ++m) fetch(2, m, ent2[m], real2[m]);
+#pragma unroll
+    for (int m = 0; m < G::nmt(3); ++m) fetch(3, m, ent3[m], real3[m]);
+#pragma unroll
+    for (int m = 0; m < G::nmt(4); ++m) fetch(4, m, ent4[m], real4[m]);
+    const int mt5 = TW == 16 ? w4 : (w4 & 1), nt0 = TW == 16 ? 0 : (w4 >> 1);
+    const int e5 = rt_map_entry<TW>(5, mt5, i);
+    // rows of the output transpose slab this lane sends to memory: v = h*64 + lane -> row v >> 3 (TW=16: 64 co = 8 parts)
+    // or v >> 2 (TW=8: 32 co = 4 parts)
+    constexpr int OPARTS = G::NT5 * 4, OVEC = 32 * OPARTS / 64;
+    int e5s[OVEC];
+#pragma unroll
+    for (int hh = 0; hh < OVEC; ++hh) e5s[hh] = rt_map_entry<TW>(5, mt5, (hh * 64 + lane) / OPARTS);
+    x0_store(rx0);
+    TPROBE(1);
+    __syncthreads();   // the only barrier (see the producer branch)
+#ifndef RT_PRIO_MFMA
+#define RT_PRIO_MFMA 1
+#endif
+    __builtin_amdgcn_s_setprio(RT_PRIO_MFMA);
+    const int bsw = (i >> 2) & 3;
+    RtCtx c{d, lds0, ctl, bias_lds, n, ty0, tx0, tid, lane, wave, i, g,
+            (int)lds0 + i * 64 + ((g ^ bsw) << 4), (int)lds0 + i * 64 + (((g ^ bsw) ^ 2) << 4),
+            (int)lds0 + nt0 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4), 0, lds0 + G::CTL, lane == 0 ? lds0 + G::CTL + 4 * (RT_CTL_DONE + w4) : lds0 + G::SCR + 256 * wave + 4 * lane};
+    rt_pin(c.ctlv);
+    rt_pin(c.donev);
+    rt_pin(c.wb0);
+    rt_pin(c.wb1);
+    rt_pin(c.wb5);
+    rt_stage<TW, 1, G::nmt(1), BWD>(c, ent1, real1);
+    TPROBE(2);
+    rt_stage<TW, 2, G::nmt(2), BWD>(c, ent2, real2);
+    TPROBE(3);
+    rt_stage<TW, 3, G::nmt(3), BWD>(c, ent3, real3);
+    TPROBE(4);
+    rt_stage<TW, 4, G::nmt(4), BWD>(c, ent4, real4);
+    TPROBE(5);
+    // ================= stage 5: the core x 64 channels ======
+    {
+        constexpr int NT5 = G::NT5;
+        f32x16 acc[NT5];
+        const RtPix px = rt_pix(e5, true, n, ty0, tx0, H, W);       // always a core pixel
+        // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
+        // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
+        //                 + beta1*d_out + beta2*d_out_rrdb
+        // (alpha5 multiplies the bias too: the accumulator starts at b5 and is scaled as a whole)
+#pragma unroll
+        for (int u = 0; u < NT5; ++u) rt_acc_init<BWD>(acc[u], bias_lds + 128 + (nt0 + u) * 32, g);
+        // residual r2 (x_rrdb / d out_rrdb): this lane's pixel, 16 channels per N-tile = four 8-byte loads, issued now and
+        // consumed in the epilogue
+        const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+        rt_u32x2 r2v[NT5][4];
+        if (r2p) {
+            const __bf16* rp = r2p + px.gpix * d.r2.cs + d.r2.coff + 4 * g;
+#pragma unroll
+            for (int u = 0; u < NT5; ++u)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) r2v[u][q4] = *reinterpret_cast<const rt_u32x2*>(rp + (nt0 + u) * 32 + 8 * q4);
+        }
+        rt_stage5<TW, BWD>(c, acc, px, nt0);
+        TPROBE(6);
+        if (lane == 0) rt_inc(ctl + RT_CTL_SLICE + 5);
+        rt_wait_ge(ctl + RT_CTL_SLICE + 5, 4);   // every wave is finished with the ring: it becomes the output transpose slabs
+        {
+            const int f0 = rt_f(px.Y, px.X);
+            const int xrow = 64 * (px.Y * G::pitch(0) + px.X);
+            const unsigned slabw = lds0 + G::RING + w4 * (32 * G::TROW);     // [32 px][NT5*32 co] bf16, TROW-byte rows
+#pragma unroll
+            for (int u = 0; u < NT5; ++u)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const rt_u32x2 xw = rt_lds_read<rt_u32x2>(lds0 + G::base(0) + (nt0 + u) * G::PLANE + xrow + ((q4 ^ f0) << 4) + 8 * g);
+                    const float xv[4] = {rt_bf_lo(xw[0]), rt_bf_hi(xw[0]), rt_bf_lo(xw[1]), rt_bf_hi(xw[1])};
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (r2p) { rv[0] = rt_bf_lo(r2v[u][q4][0]); rv[1] = rt_bf_hi(r2v[u][q4][0]); rv[2] = rt_bf_lo(r2v[u][q4][1]); rv[3] = rt_bf_hi(r2v[u][q4][1]); }
+                    rt_bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = d.alpha5 * acc[u][4 * q4 + e] + d.beta1 * xv[e];
+                        if (r2p) v += d.beta2 * rv[e];
+                        o[e] = (__bf16)v;
+                    }
+                    rt_lds_write<rt_bf16x4>(slabw + i * G::TROW + u * 64 + 16 * q4 + 8 * g, o);
+                }
+            // the wave's 32 px x (NT5*64 B) tile -> 16-byte vectors (row = the lane of the M-tile that owns the pixel)
+#pragma unroll
+            for (int hh = 0; hh < OVEC; ++hh) {
+                const int v = hh * 64 + lane;
+                const int row = v / OPARTS, part = v - row * OPARTS;
+                const int es = e5s[hh];
+                const int oy = ty0 - 5 + (es & 31), ox = tx0 - 5 + ((es >> 5) & 31);
+                const u32x4 val = rt_lds_read<u32x4>(slabw + row * G::TROW + part * 16);
+                if (oy < H && ox < W) {
+                    __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * H + oy) * W + ox) * d.out.cs +
+                                  d.out.coff + nt0 * 32 + part * 8;
+                    *reinterpret_cast<u32x4*>(dst) = val;
+                }
+            }
+        }
+    }
+    TPROBE(7);
+#ifdef SSR_PROBE
+    if (threadIdx.x == 0) { g_probe[blockIdx.x * 16 + 13] = c.slice_ticks; g_probe[blockIdx.x * 16 + 14] = c.wait_ticks; g_probe[blockIdx.x * 16 + 15] = c.wait_n; }
+#endif
+}
+
+template <int TW>
+int rdbt_launch_tw(const ssr_rdb_desc& d, void* stream, bool bwd) {
+    using G = RtGeo<TW>;
+    static bool attr_done[2] = {false, false};
+    const void* kern = bwd ? reinterpret_cast<const void*>(rdbt_kernel<TW, true>) : reinterpret_cast<const void*>(rdbt_kernel<TW, false>);
+    if (!attr_done[bwd]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[bwd] = true;
+    }
+    const int tiles = d.N * ((d.H + 7) / 8) * ((d.W + TW - 1) / TW);
+    if (bwd) hipLaunchKernelGGL((rdbt_kernel<TW, true>), dim3(tiles), dim3(RT_NTHREADS), G::LDS, reinterpret_cast<hipStream_t>(stream), d);
+    else hipLaunchKernelGGL((rdbt_kernel<TW, false>), dim3(tiles), dim3(RT_NTHREADS), G::LDS, reinterpret_cast<hipStream_t>(stream), d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+}  // namespace
+
+// tile width 16 or 8; descriptor already validated by the caller (csrc/rdb_fwd.hip: rdb_launch)
+int rdbt_launch(const ssr_rdb_desc& d, void* stream, bool bwd, int tw) {
+    return tw == 16 ? rdbt_launch_tw<16>(d, stream, bwd) : rdbt_launch_tw<8>(d, stream, bwd);
+}

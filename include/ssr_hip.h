@@ -120,7 +120,7 @@ int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad)
 
 /*
  * Fused ResidualDenseBlock (rrdbnet_arch.py:37-44, and :68 for the third block of an RRDB), bf16,
- * num_feat 64 / num_grow_ch 32.  One launch keeps the whole dense block of an 8x8 tile (with its 5-pixel halo)
+ * num_feat 64 / num_grow_ch 32.  One launch keeps the whole dense block of an 8x8 or 8x16 tile (with its 5-pixel halo)
  * resident in LDS; only the weights are streamed.
  *   forward : in = x (64 ch) -> x1..x4 written to channels [64,192) of `slices`,
  *             out[0,64) = alpha5*(conv5(cat(x..x4)) + b5) + beta1*x + beta2*r2;
@@ -147,6 +147,11 @@ typedef struct ssr_rdb_desc {
 } ssr_rdb_desc;
 int ssr_rdb_forward(const ssr_rdb_desc* d, void* stream);
 int ssr_rdb_backward(const ssr_rdb_desc* d, void* stream);
+/* Which kernel the two entry points above run: -1 = automatic (the default: SSR_RDB_TILE from the environment, else 8 x 16
+ * tiles of csrc/rdb_tile.hip when the launch gives (nearly) every CU a workgroup, else the 8 x 8 tiles of csrc/rdb_fwd.hip),
+ * 0 = 8 x 8 tiles, 16 = 8 x 16 tiles.  Both kernels add the same products in the same order: their results are bit-identical
+ * (tests/test_gpu_rdb_tile.py).  Returns the previous setting. */
+int ssr_rdb_set_tile(int32_t tile);
 
 /*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at

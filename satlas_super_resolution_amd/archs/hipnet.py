@@ -63,6 +63,7 @@ class HipNet(nn.Module):
         self._store = None
         self._plans: Dict[Tuple, object] = {}
         self._packed_version = None
+        self._frozen = False
 
     # ---- flat-arena storage ----
     def _leaf(self, name: str) -> nn.Module:
@@ -103,18 +104,32 @@ class HipNet(nn.Module):
         return st
 
     def pack_if_stale(self):
-        """The kernels read packed compute-dtype copies of the weights.  Re-pack only when a parameter changed since the last
-        packing: every in-place update through the Parameter objects (optimizer steps, load_state_dict, .copy_) bumps the
-        tensor's version counter.  Under no_grad inference (infer.py / infer_grid.py call the module once per chunk) the 351
-        weight tensors are packed once, not per forward.  Code that writes through `.data` must call mark_weights_dirty()."""
+        """The kernels read packed compute-dtype copies of the weights.  By default they are re-packed on EVERY forward: a
+        Parameter's version counter does not move under writes through `.data` (BasicSR's model_ema updates net_g_ema exactly that
+        way on every iteration, and any user `p.data.copy_` does too), so "unchanged since the last packing" cannot be decided from
+        the versions.  Inference loops that call the module once per chunk with fixed weights (infer.py / infer_grid.py) opt in to
+        packing once with freeze_packed(); load_state_dict / store rebuilds / mark_weights_dirty() thaw it again."""
         st = self.store()
-        ver = sum(p._version for p in self.parameters())
-        if ver != self._packed_version:
+        if self._packed_version is None or not self._frozen:
             st.pack()
-            self._packed_version = ver
+            self._packed_version = 1
+
+    def freeze_packed(self, on: bool = True):
+        """Explicit promise that the parameters will not change until freeze_packed(False): pack now, skip packing afterwards."""
+        self._frozen = bool(on)
+        self._packed_version = None
+        if on:
+            self.pack_if_stale()
+        return self
 
     def mark_weights_dirty(self):
         self._packed_version = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._frozen = False            # new weights: thaw (the caller freezes again if it wants to)
+        self._packed_version = None
+        return out
 
     def grads_from_arena(self, needs: List[bool]):
         st = self._store

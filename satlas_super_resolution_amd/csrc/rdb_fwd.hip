@@ -740,9 +740,8 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
 
 // second-generation kernel (csrc/rdb_tile.hip): 8 x 16 or 8 x 8 tiles, swizzled rows, 6-KB slab ring
 int rdbt_launch(const ssr_rdb_desc& d, void* stream, bool bwd, int tw);
-// Tile choice.  SSR_RDB_TILE = 0: this file's kernel (8x8 tiles, 80-byte rows); 8 / 16: csrc/rdb_tile.hip with that tile
-// width; unset / "auto": 8x16 tiles when they still give every CU a workgroup (one workgroup owns a CU: 160 KB of LDS),
-// else the 8x8 tiles of rdb_tile.hip.
+// Tile choice.  SSR_RDB_TILE = 0: this file's kernel (8x8 tiles, 80-byte rows); 16: csrc/rdb_tile.hip (8x16 tiles);
+// unset / "auto": 8x16 tiles when they still give (nearly) every CU a workgroup (one workgroup owns a CU: 160 KB of LDS).
 int g_rdb_tile_override = -1;   // tools / tests: >= 0 overrides the environment
 static int rdb_pick_tile(const ssr_rdb_desc& d) {
     static int env = -2;
@@ -751,9 +750,10 @@ static int rdb_pick_tile(const ssr_rdb_desc& d) {
         env = (e && *e && *e != 'a') ? atoi(e) : -1;
     }
     const int choice = g_rdb_tile_override >= 0 ? g_rdb_tile_override : env;
-    if (choice == 0 || choice == 8 || choice == 16) return choice;
+    if (choice == 0 || choice == 16) return choice;
+    // 8 x 16 tiles want a workgroup for (nearly) every CU; below that the 8 x 8 tiles of this file fill the chip better
     const int t16 = d.N * ((d.H + 7) / 8) * ((d.W + 15) / 16);
-    return t16 >= 224 ? 16 : 8;
+    return t16 >= 192 ? 16 : 0;
 }
 
 static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
@@ -782,5 +782,10 @@ static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     return SSR_OK;
 }
 
+extern "C" int ssr_rdb_set_tile(int32_t tile) {
+    const int prev = g_rdb_tile_override;
+    g_rdb_tile_override = (tile == 0 || tile == 16) ? tile : -1;
+    return prev;
+}
 extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, false); }
 extern "C" int ssr_rdb_backward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, true); }

@@ -24,7 +24,7 @@
 // LDS map (TW = 16): ring 4 x 6144 B | bias table | control words | X0 2 planes x 468 rows | X1 414 | X2 308 | X3 262 |
 // X4 180 rows | dummy row = 159.9 KB.  After the prologue there is NO s_barrier: LDS flags as in rdb_fwd.hip
 //   ready[NST]  (producer -> consumers)    per ring stage: slabs its producer has published there
-//   done[4]     (consumer w -> producers)  number of slabs wave w is finished with
+//   done[8]     (consumer w -> producers)  number of slabs wave w is finished with
 //   slice[1..5] (consumers <-> consumers)  waves that have stored their part of slice K / arrived at the final sync
 #include "common.h"
 
@@ -43,6 +43,18 @@
 #define TPROBE(k)
 #define TPROBE2(K, s)
 #endif
+#ifdef RT_TRACE   // tools/rdbt_check trace: every wave of block 0 logs (event, slab / stage, s_memtime) to g_trace[wave][512]
+#define TRACE(ev, arg)                                                                                                   \
+    do {                                                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                                                \
+            unsigned long long* tr_ = g_trace + (threadIdx.x >> 6) * 512;                                                \
+            const unsigned long long n_ = tr_[0];                                                                        \
+            if (n_ < 510) { tr_[1 + n_] = ((unsigned long long)(ev) << 56) | ((unsigned long long)(arg) << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); tr_[0] = n_ + 1; } \
+        }                                                                                                                \
+    } while (0)
+#else
+#define TRACE(ev, arg)
+#endif
 
 namespace {
 
@@ -58,7 +70,7 @@ __device__ __forceinline__ float rt_bf_hi(unsigned w) { return __builtin_bit_cas
 
 constexpr int RT_SLAB = 6144;                      // 3 taps x 32 co x 32 ci (conv5: 3 taps x 64 co x 16 ci) bf16
 constexpr int RT_NSLAB = 78;                       // 6 + 9 + 12 + 15 + 36
-constexpr int RT_NPROD = 4, RT_NTHREADS = 256 + 64 * RT_NPROD;
+constexpr int RT_NCONS = 8, RT_NPROD = 4, RT_NTHREADS = 64 * (RT_NCONS + RT_NPROD);   // MFMA waves (two per SIMD), producer waves (one per SIMD)
 
 // ---- geometry of a tile of 8 x TW output pixels; frame = the 18 x (TW+10) halo region of the block input ----
 template <int TW> struct RtGeo {
@@ -77,38 +89,54 @@ template <int TW> struct RtGeo {
     static constexpr int ACT = CTL + 128;                      // multiple of 64
     static constexpr int base(int s) { return s == 0 ? ACT : s == 1 ? ACT + 2 * PLANE : base(s - 1) + rows(s - 1) * 64; }
     static constexpr int DUMMY = base(4) + rows(4) * 64;
-    static constexpr int SCR = DUMMY + 64;                     // 8 x 256 B: where lanes 1..63 of a flag write go
-    static constexpr int SRC = SCR + 2048;                     // [80] 64-bit source address of every weight slab
+    static constexpr int SCR = DUMMY + 64;                     // 256 B: where lanes 1..63 of a flag write go (never read)
+    static constexpr int SRC = SCR + 256;                      // [80] 64-bit source address of every weight slab
     static constexpr int LDS = SRC + 640;
     static_assert(ACT % 64 == 0, "activation rows are 64-byte aligned");
-    static constexpr int TROW = 144;              // output transpose slab: [32 px][64 co] bf16, 144-B rows, one per wave
+    static constexpr int TROW = 80;               // output transpose slab: [32 px][32 co] bf16, 80-B rows, one per wave
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static_assert(NST * RT_SLAB >= 4 * 32 * TROW, "ring doubles as the output transpose slabs");
-    // M-tiles (32 pixels) per stage and per MFMA wave
+    static_assert(NST * RT_SLAB >= RT_NCONS * 32 * TROW, "ring doubles as the output transpose slabs");
+    // M-tiles (32 pixels) per stage
     static constexpr int ntiles(int K) {
         return TW == 16 ? (K == 1 ? 12 : K == 2 ? 10 : K == 3 ? 8 : K == 4 ? 6 : 4) : (K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2);
     }
-    static constexpr int nmt(int K) { return TW == 16 ? (K <= 2 ? 3 : K <= 4 ? 2 : 1) : (K <= 3 ? 2 : 1); }
-    static constexpr int NT5 = TW == 16 ? 2 : 1;  // N-tiles of conv5 per wave
-    // M-tile m of wave w in stage K (-1: none — the wave runs a dummy tile, the ring keeps the waves in lock step anyway)
+    // M-tile m of MFMA wave w (0..7; waves w and w + 4 share a SIMD) in growth stage K; -1: none.  A wave without a tile skips
+    // the stage (it releases the stage's slabs at once).  TW = 16: the SIMDs carry 3,3,3,3 | 3,3,2,2 | 2,2,2,2 | 1,1,2,2 tiles.
     static constexpr int tile_of(int K, int w, int m) {
         if (TW == 16) {
-            if (K == 1) return w + 4 * m;
-            if (K == 2) return m < 2 ? w + 4 * m : (w < 2 ? 8 + w : -1);
-            if (K == 3) return w + 4 * m;
-            if (K == 4) return m == 0 ? w : (w >= 2 ? w + 2 : -1);
-            return w;
+            if (K == 1) return m == 0 ? w + (w >= 4 ? 4 : 0) : (w < 4 ? w + 4 : -1);     // w<4: {w, w+4}; w>=4: {w+4}
+            if (K == 2) return m == 0 ? (w < 4 ? w : w < 6 ? w + 4 : -1) : (w < 4 ? w + 4 : -1);   // w<4: {w, w+4}; 4,5: {8, 9}
+            if (K == 3) return m == 0 ? w : -1;
+            if (K == 4) return m == 0 ? (w < 4 ? w : w >= 6 ? w - 2 : -1) : -1;           // w<4: {w}; 6,7: {4, 5}
+            return -1;
         }
-        if (K == 1) return w + 4 * m;
-        if (K == 2) return m == 0 ? w : (w < 3 ? w + 4 : -1);
-        if (K == 3) return m == 0 ? w : (w == 3 ? 4 : -1);
-        if (K == 4) return w;
-        return w & 1;
+        if (m > 0) return -1;
+        if (K == 1) return w;
+        if (K == 2) return w < 7 ? w : -1;
+        if (K == 3) return w < 5 ? w : -1;
+        if (K == 4) return w < 4 ? w : -1;
+        return -1;
     }
+    static constexpr int nmt(int K) { return TW == 16 && K <= 2 ? 2 : 1; }              // most tiles a wave has in stage K
+    static constexpr int ntl(int K, int w) { return (tile_of(K, w, 0) >= 0) + (nmt(K) > 1 && tile_of(K, w, 1) >= 0); }
+    static constexpr int npart(int K) {                                                   // waves that take part in stage K
+        int n = 0;
+        for (int w = 0; w < RT_NCONS; ++w) n += K <= 4 ? ntl(K, w) > 0 : (TW == 16 || w < 4);
+        return n;
+    }
+    static constexpr int prank(int K, int w) {                                            // rank of wave w among them
+        int n = 0;
+        for (int u = 0; u < w; ++u) n += K <= 4 ? ntl(K, u) > 0 : (TW == 16 || u < 4);
+        return n;
+    }
+    // conv5: wave w owns (M-tile, N-tile of 32 output channels)
+    static constexpr int m5(int w) { return TW == 16 ? (w & 3) : (w & 1); }
+    static constexpr int n5(int w) { return TW == 16 ? (w >> 2) : ((w >> 1) & 1); }
+    static constexpr bool in5(int w) { return TW == 16 || w < 4; }
 };
 constexpr int ctl_ready(int st) { return st; }   // [NST <= 8]
-constexpr int RT_CTL_DONE = 8;                       // [4], 16-byte aligned
-constexpr int RT_CTL_SLICE = 12;                     // [1..4] slice K complete, [5] final sync
+constexpr int RT_CTL_DONE = 8;                       // [8], 16-byte aligned
+constexpr int RT_CTL_SLICE = 16;                     // [1..4] slice K complete, [5] final sync
 
 // ---- lane -> pixel map: stage K (region [K, 18-K) x [K, TW+10-K) of the frame), M-tile t, lane i & 31 ->
 //      Y | X << 5 | valid << 10 with (2Y + X) mod 16 == i mod 16.  Class c = region pixels with that residue, enumerated
@@ -165,49 +193,92 @@ template <int TW> __device__ __forceinline__ int rt_map_entry(int K, int t, int 
 // swizzle of a frame pixel: XOR applied to the 16-B part index of its 64-B row
 __device__ __forceinline__ int rt_f(int Y, int X) { return ((2 * Y + X) >> 2) & 3; }
 
-// ---- weight slab q of the block's schedule ----
-//   conv K = 1..4: chunks j = 0..K (32 input channels each: LDS slice (j < 2 ? 0 (plane j) : j - 1), oldest first so that
-//   the slice produced by the previous stage is needed last) x kernel rows ky = 0..2; conv5: chunks j = 0..5 x 16-channel
-//   halves h x ky.  Weight chunk in memory: forward = j (rrdbnet_arch.py:39-42 cat order); backward = [dpre newest ..
-//   oldest | d_out p0 p1] (ParamStore.add_rdb_gather) -> j < 2 ? K-1+j : K-j.
+// ---- the block's schedule: "extended stages" E1..E5.  conv5 contracts chunk c over slice c-1 (chunks 0, 1: the two planes of
+//      x) and needs nothing else, so its chunks are spread over the growth stages instead of forming a sixth of the block's
+//      MFMAs with half of its weight bytes at the end (r03: 216 KB for 864 MFMAs = the producers' top rate, the ring ran dry):
+//        E1: conv1 chunks 0,1 | conv5 chunk 0            E2: conv2 chunks 0,1 | conv5 chunk 1 | conv2 chunk 2
+//        E3: conv3 chunks 0..2 | conv5 chunk 2 | conv3 chunk 3      E4: conv4 chunks 0..3 | conv5 chunk 3 | conv4 chunk 4
+//        E5: conv5 chunks 4, 5
+//      i.e. inside E_K the conv5 chunk needs only slices that are long complete, and sits in front of the one growth chunk that
+//      needs the slice the previous stage has just produced: a wave that is early has work that does not wait for the others.
+//      The order of conv5's contraction (chunk, half, row, column) is unchanged.  A slab = one kernel row (3 taps) of one
+//      32-channel chunk (conv5: of one 16-channel half chunk); slab numbers run in this order.
+#ifndef RT_INTERLEAVE5
+#define RT_INTERLEAVE5 0   // 1: conv5's chunks spread over the growth stages (r03: measured 1-3 us slower per launch); 0: conv5 after conv4
+#endif
+#if RT_INTERLEAVE5
+constexpr int rt_ebase(int E) { return E == 1 ? 0 : E == 2 ? 12 : E == 3 ? 27 : E == 4 ? 45 : 66; }
+constexpr int rt_qg(int K, int j, int ky) { return K == 1 ? 3 * j + ky : rt_ebase(K) + (j < K ? 3 * j + ky : 3 * K + 6 + ky); }
+constexpr int rt_q5(int c, int h, int ky) { return (c == 0 ? 6 : c <= 3 ? rt_ebase(c + 1) + 3 * (c + 1) : c == 4 ? 66 : 72) + 3 * h + ky; }
+#else
+constexpr int rt_qg(int K, int j, int ky) { return (K == 1 ? 0 : K == 2 ? 6 : K == 3 ? 15 : 27) + 3 * j + ky; }
+constexpr int rt_q5(int c, int h, int ky) { return 42 + 6 * c + 3 * h + ky; }
+#endif
+#if RT_INTERLEAVE5
+static_assert(rt_qg(1, 1, 2) == 5 && rt_q5(0, 0, 0) == 6 && rt_qg(2, 0, 0) == 12 && rt_q5(1, 0, 0) == 18 && rt_qg(2, 2, 0) == 24 &&
+              rt_qg(3, 0, 0) == 27 && rt_q5(2, 0, 0) == 36 && rt_qg(3, 3, 2) == 44 && rt_qg(4, 0, 0) == 45 && rt_q5(3, 1, 2) == 62 &&
+              rt_qg(4, 4, 0) == 63 && rt_q5(4, 0, 0) == 66 && rt_q5(5, 1, 2) == 77, "slab numbering");
+#endif
+
+// Source address of slab q (6144 contiguous bytes of one packed weight array), bit 0 = conv5 layout.  Evaluated ONCE per block,
+// one slab per thread, into an LDS table (the producers' loop then costs one ds_read_b64 per slab instead of a 40-instruction
+// decode; and hipcc turned every scalar formulation of "pick one of five kernel-argument pointers" into an indexed load from a
+// scratch copy of the pointers, i.e. a memory round trip in front of every slab).
+//   weight chunk in memory: forward = j (rrdbnet_arch.py:39-42 cat order); backward = [dpre newest .. oldest | d_out p0 p1]
+//   (ParamStore.add_rdb_gather) -> j < 2 ? k + j : k + 1 - j for conv index k = K - 1
 //   conv1..4: [chunk of 32 ci][tap][32 co][32 ci]  -> a slab is 96 rows of 64 B, 16-B part XOR-swizzled by (row >> 2) & 3
 //   conv5   : [chunk of 16 ci][tap][64 co][16 ci]  -> a slab is 192 rows of 32 B, 16-B part XOR-swizzled by (row >> 3) & 1
-constexpr int rt_q0(int K) { return K == 1 ? 0 : K == 2 ? 6 : K == 3 ? 15 : K == 4 ? 27 : 42; }
-// Source address of slab q (6144 contiguous bytes of one packed weight array).  Evaluated ONCE per block, one slab per
-// thread, into an LDS table (the producers' loop then costs one ds_read_b64 per slab instead of a 40-instruction decode; and
-// hipcc turned every scalar formulation of "pick one of five kernel-argument pointers" into an indexed load from a scratch
-// copy of the pointers, i.e. a memory round trip in front of every slab).
 template <bool BWD>
 __device__ __forceinline__ unsigned long long rt_slab_src(const ssr_rdb_desc& d, int q) {
-    int k, r;
-    if (q < 6) { k = 0; r = q; }
-    else if (q < 15) { k = 1; r = q - 6; }
-    else if (q < 27) { k = 2; r = q - 15; }
-    else if (q < 42) { k = 3; r = q - 27; }
-    else { k = 4; r = q - 42; }
+#if !RT_INTERLEAVE5
+    {
+        const int k = q < 6 ? 0 : q < 15 ? 1 : q < 27 ? 2 : q < 42 ? 3 : 4;
+        const int r = q - (k == 0 ? 0 : k == 1 ? 6 : k == 2 ? 15 : k == 3 ? 27 : 42);
+        const int j = k == 4 ? r / 6 : r / 3, h = k == 4 ? (r / 3) & 1 : 0, ky = r % 3;
+        unsigned long long base = (unsigned long long)(uintptr_t)d.w[0];
+        base = k == 1 ? (unsigned long long)(uintptr_t)d.w[1] : base;
+        base = k == 2 ? (unsigned long long)(uintptr_t)d.w[2] : base;
+        base = k == 3 ? (unsigned long long)(uintptr_t)d.w[3] : base;
+        base = k == 4 ? (unsigned long long)(uintptr_t)d.w[4] : base;
+        const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j;
+        const int tapblk = k == 4 ? (2 * c + h) * 9 + 3 * ky : c * 9 + 3 * ky;
+        return (base + (unsigned long long)(tapblk * 2048)) | (k == 4 ? 1ull : 0ull);
+    }
+#endif
+    int E, r;
+    if (q < 12) { E = 1; r = q; }
+    else if (q < 27) { E = 2; r = q - 12; }
+    else if (q < 45) { E = 3; r = q - 27; }
+    else if (q < 66) { E = 4; r = q - 45; }
+    else { E = 5; r = q - 66; }
+    const int ng = E == 1 ? 6 : 3 * E;            // growth slabs in front of the stage's conv5 chunk
+    int k, j, ky, h = 0;                           // conv index (0..4), chunk, kernel row, half
+    if (E == 5) { k = 4; j = 4 + r / 6; h = (r % 6) / 3; ky = r % 3; }
+    else if (r < ng) { k = E - 1; j = r / 3; ky = r % 3; }
+    else if (r < ng + 6) { k = 4; j = E - 1; h = (r - ng) / 3; ky = (r - ng) % 3; }
+    else { k = E - 1; j = E; ky = r - ng - 6; }
     unsigned long long base = (unsigned long long)(uintptr_t)d.w[0];
     base = k == 1 ? (unsigned long long)(uintptr_t)d.w[1] : base;
     base = k == 2 ? (unsigned long long)(uintptr_t)d.w[2] : base;
     base = k == 3 ? (unsigned long long)(uintptr_t)d.w[3] : base;
     base = k == 4 ? (unsigned long long)(uintptr_t)d.w[4] : base;
-    int j, ky, tapblk;
-    if (k == 4) { j = r / 6; const int h = (r / 3) & 1; ky = r % 3; const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j; tapblk = (2 * c + h) * 9 + 3 * ky; }
-    else { j = r / 3; ky = r - 3 * j; const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j; tapblk = c * 9 + 3 * ky; }
-    return base + (unsigned long long)(tapblk * 2048);   // tap block: 32 co x 32 ci (conv5: 64 co x 16 ci) bf16 = 2048 B
+    const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j;
+    const int tapblk = k == 4 ? (2 * c + h) * 9 + 3 * ky : c * 9 + 3 * ky;
+    return (base + (unsigned long long)(tapblk * 2048)) | (k == 4 ? 1ull : 0ull);   // tap block: 32 co x 32 ci (conv5: 64 co x 16 ci) bf16 = 2048 B
 }
 typedef const __attribute__((address_space(1))) char* rt_gptr;   // global memory, explicitly (never a flat access)
 
 #ifndef RT_POLL_SLEEP
 #define RT_POLL_SLEEP 3
 #endif
-#ifndef RT_PF3
-#define RT_PF3 3      // operand prefetch distance in k-steps, stages with 3 M-tiles per wave (4 reads per k-step)
-#endif
 #ifndef RT_PF2
-#define RT_PF2 4      // ... stages with 1 or 2 M-tiles per wave
+#define RT_PF2 3      // operand prefetch distance in k-steps, 2 M-tiles per wave (3 reads per k-step; at most 15 LDS operations can be counted)
+#endif
+#ifndef RT_PF1
+#define RT_PF1 5      // ... 1 M-tile per wave (2 reads per k-step)
 #endif
 #ifndef RT_PF5
-#define RT_PF5 4      // ... conv5
+#define RT_PF5 5      // ... conv5 (2 reads per k-step)
 #endif
 // The MFMA waves are ISSUE bound (one wave per SIMD issues ~8 instructions per 32-cycle MFMA; r03 counters: the first cut
 // of this kernel spent 13 instructions per MFMA, 7 of them address arithmetic hipcc rematerialised instead of keeping
@@ -245,6 +316,7 @@ struct RtCtx {            // what every stage needs
     int* ctl;
     const float* bias_lds;
     int n, ty0, tx0, tid, lane, wave, i, g;
+    int prank;            // rank of this wave among the waves that take part in the current stage
     int wb0, wb1;         // this lane's weight-fragment offsets inside a conv1..4 slab (k-substep 0 / 1), relative to the ring
     int wb5;              // ... inside a conv5 slab (N-tile 0)
     int hint;             // ready counter of the next slab's ring stage, sampled two k-steps ahead
@@ -262,6 +334,7 @@ template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
 #ifdef RT_X_NOSYNC   // probe: no hand-over (wrong results)
     return;
 #endif
+    TRACE(1, q);
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(c.hint) < target, 0)) {   // the word is the same for every lane: scalar compare + branch
 #ifdef SSR_PROBE   // slots 14 / 15 of thread 0's probe row: ticks spent polling for slabs, number of slabs that had to wait
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -271,6 +344,7 @@ template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
         c.wait_ticks += __builtin_amdgcn_s_memtime() - t0;
         c.wait_n += 1;
 #endif
+        TRACE(2, q);
     }
 }
 template <int TW> __device__ __forceinline__ void rt_sample(RtCtx& c, int q) {
@@ -282,6 +356,7 @@ __device__ __forceinline__ void rt_release(RtCtx& c, int upto) {   // this wave 
     // its own dword of a scratch row — one conflict-free ds_write_b32
     rt_lds_write<int>(c.donev, upto);
     asm volatile("" ::: "memory");
+    TRACE(3, upto);
 }
 
 // accumulator start: the bias of this lane's 16 channels (forward) / zero (backward: the gather dgrad has no bias)
@@ -334,13 +409,12 @@ __device__ __forceinline__ void rt_load_mask(const ssr_rdb_desc& d, const RtPix&
     for (int q4 = 0; q4 < 4; ++q4) mk[q4] = *reinterpret_cast<const rt_u32x2*>(mp + 8 * q4);
 }
 
-// cooperative write of the 8 x TW core of LDS slice K (32 channels) to the dense buffer: 16-B vectors, 256 threads
+// cooperative write of the 8 x TW core of LDS slice K (32 channels) to the dense buffer: 16-B vectors, by the `nthr` threads
+// (rank `rk`) of the waves that wait for the slice
 template <int TW, int K, bool BWD>
-__device__ __forceinline__ void rt_flush_core(const ssr_rdb_desc& d, unsigned lds0, int n, int ty0, int tx0, int tid) {
+__device__ __forceinline__ void rt_flush_core(const ssr_rdb_desc& d, unsigned lds0, int n, int ty0, int tx0, int rk, int nthr) {
     using G = RtGeo<TW>;
-#pragma unroll
-    for (int rep = 0; rep < TW / 8; ++rep) {
-        const int v = tid + rep * 256;
+    for (int v = rk; v < 32 * TW; v += nthr) {
         const int q = v >> 2, part = v & 3;
         const int cy = q / TW, cx = q - cy * TW;
         const int Y = cy + 5, X = cx + 5;
@@ -355,36 +429,52 @@ __device__ __forceinline__ void rt_flush_core(const ssr_rdb_desc& d, unsigned ld
     }
 }
 
-// One growth conv (K = 1..4) for NMT M-tiles of this wave, as ONE software pipeline over its (K+1)*18 k-steps
-// (chunk j, kernel row ky, column kx, 16-channel k-substep kk); k-step n consumes weight slab Q0 + 3j + ky.
-// There is one MFMA wave per SIMD beside a producer wave, so LDS latency is hidden inside the wave: operand reads run PF
-// k-steps ahead of the MFMAs that consume them and the sched_barrier fences pin that order (left alone, hipcc sinks every
-// ds_read next to its MFMA).  Ring hand-over rides in the same stream: slab q is acquired right before its first operand
-// read and released right after its last one (LDS executes a wave's operations in order, so the flag write cannot overtake
-// the reads); the ready counter of the next slab is sampled two k-steps early.  The last chunk (j = K) reads slice K-1,
-// which the previous stage may still be writing: its first read waits for the slice and sends the slice's core to the
-// dense buffer first.
 template <int TW, int S> __device__ __forceinline__ unsigned rt_chunk_base(unsigned lds0, int Y, int X) {
     // tap (0,0) neighbour of frame pixel (Y, X) in slice S (plane 0)
     using G = RtGeo<TW>;
     return lds0 + G::base(S) + 64 * ((Y - S - 1) * G::pitch(S) + (X - S - 1));
 }
-template <int TW, int K, int NMT, bool BWD>
-__device__ __forceinline__ void rt_stage(RtCtx& c, const int (&ent)[NMT], const bool (&real)[NMT]) {
-    using G = RtGeo<TW>;
-    constexpr int NS = (K + 1) * 18, PF = NMT >= 3 ? RT_PF3 : RT_PF2, NB = PF + 1, Q0 = rt_q0(K);
-    TPROBE2(K, 0);
+
+// ---- a wave's share of growth conv K (1..4): NMT M-tiles.  State lives across the segments of the stage. ----
+template <int NMT> struct RtGrow {   // what survives between the segments of a stage: accumulators, the map entries (pixels)
     f32x16 acc[NMT];
-    RtPix px[NMT];
+    int ent[NMT];
+    rt_u32x2 mk[NMT][4];             // backward: the epilogue's masks (loaded in the last segment)
+};
+template <int TW, int K, int NMT, bool BWD>
+__device__ __forceinline__ void rt_grow_begin(RtCtx& c, RtGrow<NMT>& st, const int (&ent)[NMT]) {
+    TPROBE2(K, 0);
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) st.ent[m] = ent[m];
+    rt_acc_init<BWD>(st.acc[0], c.bias_lds + 32 * (K - 1), c.g);
+#pragma unroll
+    for (int m = 1; m < NMT; ++m) st.acc[m] = st.acc[0];
+}
+// Chunks [J0, J1) of growth conv K as ONE software pipeline over their 18 k-steps each (kernel row ky, column kx,
+// 16-channel k-substep kk); k-step n consumes weight slab rt_qg(K, j, ky).  LDS latency is hidden inside the wave and by
+// the other MFMA wave of the SIMD: operand reads run PF k-steps ahead of the MFMAs that consume them and the sched_barrier
+// fences pin that order (left alone, hipcc sinks every ds_read next to its MFMA).  Ring hand-over rides in the same
+// stream: a slab is acquired right before its first operand read and released right after its last one (LDS executes a
+// wave's operations in order, so the flag write cannot overtake the reads); the ready word of the next slab of the segment is
+// sampled two k-steps early.  The last chunk (j = K) reads slice K-1, which the previous stage may still be writing: its first
+// read waits for the slice and sends the slice's core to the dense buffer first.
+template <int TW, int K, int NMT, bool BWD, int J0, int J1>
+__device__ __forceinline__ void rt_grow_run(RtCtx& c, RtGrow<NMT>& st) {
+    using G = RtGeo<TW>;
+    constexpr int N0 = J0 * 18, N1 = J1 * 18, PF = NMT >= 2 ? RT_PF2 : RT_PF1, NB = PF + 1;
+    rt_release(c, rt_qg(K, J0, 0));     // finished with every earlier slab (those of segments this wave had no part in included)
+    c.hint = 0;
     // operand addresses of the current chunk, per M-tile: A[kk][t] = chunk base + ((kk*2 + g) ^ f_t) << 4 for the 7 values
     // t = 2(ky-1) + (kx-1) + 3 of a tap's swizzle; a read is A + immediate (tap row/column, plane of x).  Pinned registers.
     unsigned A0[NMT][7], A1[NMT][7];
-    rt_u32x2 mk[NMT][4];
+    int PY[NMT], PX[NMT];
+    constexpr int SJ0 = J0 < 2 ? 0 : J0 - 1;
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
-        px[m] = rt_pix(ent[m], real[m], c.n, c.ty0, c.tx0, c.d.H, c.d.W);
-        const int v0 = 2 * px[m].Y + px[m].X;
-        const unsigned cb = rt_chunk_base<TW, 0>(c.lds0, px[m].Y, px[m].X);
+        PY[m] = st.ent[m] & 31;
+        PX[m] = (st.ent[m] >> 5) & 31;
+        const int v0 = 2 * PY[m] + PX[m];
+        const unsigned cb = rt_chunk_base<TW, SJ0>(c.lds0, PY[m], PX[m]);
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             A0[m][t] = cb + ((c.g ^ (((v0 + t - 3) >> 2) & 3)) << 4);
@@ -393,36 +483,33 @@ __device__ __forceinline__ void rt_stage(RtCtx& c, const int (&ent)[NMT], const 
             rt_pin(A1[m][t]);
         }
     }
-    rt_acc_init<BWD>(acc[0], c.bias_lds + 32 * (K - 1), c.g);
-#pragma unroll
-    for (int m = 1; m < NMT; ++m) acc[m] = acc[0];
     u32x4 bq[NB], aq[NB][NMT];
     auto issue = [&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
-        constexpr int j = n / 18, r = n % 18, ky = r / 6, kx = (r % 6) / 2, kk = r % 2, q = Q0 + 3 * j + ky;
-        constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
+        constexpr int j = n / 18, r = n % 18, ky = r / 6, q = rt_qg(K, j, ky);
+        constexpr int S = j < 2 ? 0 : j - 1;
         if constexpr (r == 0 && j > 0) {
             if constexpr (j == K && K > 1) {
 #ifdef SSR_PROBE
                 const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-                rt_wait_ge(c.ctl + RT_CTL_SLICE + (K - 1), 4);
+                rt_wait_ge(c.ctl + RT_CTL_SLICE + (K - 1), G::npart(K - 1));
 #ifdef SSR_PROBE
                 c.slice_ticks += __builtin_amdgcn_s_memtime() - ts0;
 #endif
-                rt_flush_core<TW, K - 1, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.tid);
+                rt_flush_core<TW, K - 1, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.prank * 64 + c.lane, G::npart(K) * 64);
             }
-            if constexpr (j == K && BWD) {   // the epilogue's masks: requested one chunk (54 MFMAs or more) ahead
+            if constexpr (j == K && BWD) {   // the epilogue's masks: requested one chunk ahead
 #pragma unroll
-                for (int m = 0; m < NMT; ++m) rt_load_mask<K>(c.d, px[m], c.g, mk[m]);
+                for (int m = 0; m < NMT; ++m) rt_load_mask<K>(c.d, rt_pix(st.ent[m], true, c.n, c.ty0, c.tx0, c.d.H, c.d.W), c.g, st.mk[m]);
             }
             // chunk 1 is plane 1 of x: same registers, the plane is an immediate.  A later chunk moves every address by the
             // distance between the two slices' bases for this lane's pixel (a multiple of 64: the swizzle bits stay).
-            if constexpr (j >= 2) {
+            if constexpr (j >= 2 && n > N0) {
                 constexpr int SP = j == 2 ? 0 : j - 2;
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) {
-                    const unsigned delta = rt_chunk_base<TW, S>(0u, px[m].Y, px[m].X) - rt_chunk_base<TW, SP>(0u, px[m].Y, px[m].X);
+                    const unsigned delta = rt_chunk_base<TW, S>(0u, PY[m], PX[m]) - rt_chunk_base<TW, SP>(0u, PY[m], PX[m]);
 #pragma unroll
                     for (int t = 0; t < 7; ++t) {
                         A0[m][t] += delta;
@@ -435,28 +522,18 @@ __device__ __forceinline__ void rt_stage(RtCtx& c, const int (&ent)[NMT], const 
         }
         if constexpr (r % 6 == 0) rt_acquire<TW>(c, q);
     };
-    // the reads of k-step n: part 0 = the weight fragment (+ the flag traffic of a slab boundary), part 1 + m = the pixel
-    // fragment of M-tile m.  Parts are issued one per MFMA gap (RT_INTERLEAVE) or together before the k-step's MFMAs.
     auto issue_part = [&](auto n_c, auto p_c) {
         constexpr int n = decltype(n_c)::value, part = decltype(p_c)::value;
-        constexpr int j = n / 18, r = n % 18, ky = r / 6, kx = (r % 6) / 2, kk = r % 2, q = Q0 + 3 * j + ky;
+        constexpr int j = n / 18, r = n % 18, ky = r / 6, kx = (r % 6) / 2, kk = r % 2, q = rt_qg(K, j, ky);
         constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
         constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
         if constexpr (part == 0) {
-#ifdef RT_X_NOB   // probe: no weight-fragment reads (wrong results)
-            bq[n % NB] = u32x4{0x3c003c00u + (unsigned)c.wb0, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-#else
             bq[n % NB] = rt_lds_read<u32x4>((kk ? c.wb1 : c.wb0) + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048));
-#endif
         } else {
             constexpr int m = part - 1;
-#ifdef RT_X_NOA   // probe: no pixel-fragment reads (wrong results)
-            aq[n % NB][m] = u32x4{0x3c003c00u + A0[m][t], 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-#else
             aq[n % NB][m] = rt_lds_read<u32x4>((kk ? A1[m][t] : A0[m][t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
-#endif
             if constexpr (m == NMT - 1) {
-                if constexpr (r % 6 == 3 && q + 1 < RT_NSLAB) rt_sample<TW>(c, q + 1);
+                if constexpr (r % 6 == 3 && n + 3 < N1) rt_sample<TW>(c, rt_qg(K, (n + 3) / 18, ((n + 3) % 18) / 6));
                 if constexpr (r % 6 == 5) rt_release(c, q + 1);
             }
         }
@@ -465,47 +542,44 @@ __device__ __forceinline__ void rt_stage(RtCtx& c, const int (&ent)[NMT], const 
         issue(n_c);
         static_for<0, NMT + 1>([&](auto p_c) { issue_part(n_c, p_c); });
     };
-    static_for<0, PF>(issue_all);
-    TPROBE2(K, 1);
-    static_for<0, NS>([&](auto n_c) {
+    static_for<N0, N0 + PF>(issue_all);
+    if constexpr (J0 == 0) TPROBE2(K, 1);
+    static_for<N0, N1>([&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
         using NX = std::integral_constant<int, n + PF>;
-#ifdef RT_INTERLEAVE
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + PF < NS) { issue(NX{}); issue_part(NX{}, std::integral_constant<int, 0>{}); }
-        static_for<0, NMT>([&](auto m_c) {
-            constexpr int m = decltype(m_c)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            mma16<__bf16>(acc[m], bq[n % NB], aq[n % NB][m]);   // A = weights (rows = co), B = pixels
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (n + PF < NS) issue_part(NX{}, std::integral_constant<int, m + 1>{});
-        });
-#else
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + PF < NS) issue_all(NX{});
+        if constexpr (n + PF < N1) issue_all(NX{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) mma16<__bf16>(acc[m], bq[n % NB], aq[n % NB][m]);   // A = weights (rows = co), B = pixels
-#endif
+        for (int m = 0; m < NMT; ++m) mma16<__bf16>(st.acc[m], bq[n % NB], aq[n % NB][m]);   // A = weights (rows = co), B = pixels
     });
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int TW, int K, int NMT, bool BWD>
+__device__ __forceinline__ void rt_grow_end(RtCtx& c, RtGrow<NMT>& st) {
     TPROBE2(K, 2);
+    TRACE(7, K);
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) rt_store_slice<TW, K, BWD>(acc[m], px[m], mk[m], c.lds0, c.g);
+    for (int m = 0; m < NMT; ++m) rt_store_slice<TW, K, BWD>(st.acc[m], rt_pix(st.ent[m], true, c.n, c.ty0, c.tx0, c.d.H, c.d.W), st.mk[m], c.lds0, c.g);
     if (c.lane == 0) rt_inc(c.ctl + RT_CTL_SLICE + K);   // LDS ops of a wave execute in order
+    TRACE(8, K);
     TPROBE2(K, 3);
 }
 
-// conv5 over the 8 x TW core: this wave's M-tile x NT5 N-tiles of 32 output channels; 108 k-steps (chunk j, 16-channel
-// half h, ky, kx), slab 42 + 6j + 3h + ky; chunk 5 reads slice 4.
-template <int TW, bool BWD>
-__device__ __forceinline__ void rt_stage5(RtCtx& c, f32x16 (&acc)[RtGeo<TW>::NT5], const RtPix& px, int nt0) {
+// conv5 over the 8 x TW core: this wave's (M-tile, N-tile of 32 output channels); chunk c = 18 k-steps (16-channel half h,
+// ky, kx), slab rt_q5(c, h, ky); chunk c >= 2 reads slice c-1.  One accumulator, alive from E1 to the end of the block.
+template <int TW, bool BWD, int C0, int C1>
+__device__ __forceinline__ void rt_c5_run(RtCtx& c, f32x16& acc, int e5) {
     using G = RtGeo<TW>;
-    constexpr int NT5 = G::NT5, NS = 108, PF = RT_PF5, NB = PF + 1;
+    constexpr int N0 = C0 * 18, N1 = C1 * 18, PF = RT_PF5, NB = PF + 1;
+    constexpr int S0 = C0 < 2 ? 0 : C0 - 1;
+    rt_release(c, rt_q5(C0, 0, 0));
+    c.hint = 0;
+    const int Y = e5 & 31, X = (e5 >> 5) & 31;
     unsigned A0[7], A1[7];
     {
-        const int v0 = 2 * px.Y + px.X;
-        const unsigned cb = rt_chunk_base<TW, 0>(c.lds0, px.Y, px.X);
+        const int v0 = 2 * Y + X;
+        const unsigned cb = rt_chunk_base<TW, S0>(c.lds0, Y, X);
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             A0[t] = cb + ((c.g ^ (((v0 + t - 3) >> 2) & 3)) << 4);
@@ -514,25 +588,25 @@ __device__ __forceinline__ void rt_stage5(RtCtx& c, f32x16 (&acc)[RtGeo<TW>::NT5
             rt_pin(A1[t]);
         }
     }
-    u32x4 bq[NB][NT5], aq[NB];
+    u32x4 bq[NB], aq[NB];
     auto issue = [&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
-        constexpr int j = n / 18, r = n % 18, h = r / 9, ky = (r % 9) / 3, kx = r % 3, q = 42 + n / 3;
+        constexpr int j = n / 18, r = n % 18, h = r / 9, ky = (r % 9) / 3, kx = r % 3, q = rt_q5(j, h, ky);
         constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
-        if constexpr (r == 0 && j > 0) {
-            if constexpr (j == 5) {
+        if constexpr (r == 0) {
+            if constexpr (j >= 2) {   // slice j-1 must be complete (a wave without a tile in growth stage j has not waited for it yet)
 #ifdef SSR_PROBE
                 const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-                rt_wait_ge(c.ctl + RT_CTL_SLICE + 4, 4);
+                rt_wait_ge(c.ctl + RT_CTL_SLICE + (j - 1), G::npart(j - 1));
 #ifdef SSR_PROBE
                 c.slice_ticks += __builtin_amdgcn_s_memtime() - ts0;
 #endif
-                rt_flush_core<TW, 4, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.tid);
+                if constexpr (j == 5) rt_flush_core<TW, 4, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.prank * 64 + c.lane, G::npart(5) * 64);
             }
-            if constexpr (j >= 2) {
+            if constexpr (n > N0 && j >= 2) {
                 constexpr int SP = j == 2 ? 0 : j - 2;
-                const unsigned delta = rt_chunk_base<TW, S>(0u, px.Y, px.X) - rt_chunk_base<TW, SP>(0u, px.Y, px.X);
+                const unsigned delta = rt_chunk_base<TW, S>(0u, Y, X) - rt_chunk_base<TW, SP>(0u, Y, X);
 #pragma unroll
                 for (int t = 0; t < 7; ++t) {
                     A0[t] += delta;
@@ -544,21 +618,18 @@ __device__ __forceinline__ void rt_stage5(RtCtx& c, f32x16 (&acc)[RtGeo<TW>::NT5
         }
         if constexpr (kx == 0) rt_acquire<TW>(c, q);
         constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
-#pragma unroll
-        for (int u = 0; u < NT5; ++u)
-            bq[n % NB][u] = rt_lds_read<u32x4>(c.wb5 + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048 + u * 1024));
+        bq[n % NB] = rt_lds_read<u32x4>(c.wb5 + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048));
         aq[n % NB] = rt_lds_read<u32x4>((h ? A1[t] : A0[t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
-        if constexpr (kx == 1 && q + 1 < RT_NSLAB) rt_sample<TW>(c, q + 1);
+        if constexpr (kx == 1 && n + 2 < N1) rt_sample<TW>(c, rt_q5((n + 2) / 18, ((n + 2) % 18) / 9, (((n + 2) % 18) % 9) / 3));
         if constexpr (kx == 2) rt_release(c, q + 1);
     };
-    static_for<0, PF>(issue);
-    static_for<0, NS>([&](auto n_c) {
+    static_for<N0, N0 + PF>(issue);
+    static_for<N0, N1>([&](auto n_c) {
         constexpr int n = decltype(n_c)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + PF < NS) issue(std::integral_constant<int, n + PF>{});
+        if constexpr (n + PF < N1) issue(std::integral_constant<int, n + PF>{});
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < NT5; ++u) mma16<__bf16>(acc[u], bq[n % NB][u], aq[n % NB]);
+        mma16<__bf16>(acc, bq[n % NB], aq[n % NB]);
     });
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -583,8 +654,8 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
     int* ctl = reinterpret_cast<int*>(smem + G::CTL);
     float* bias_lds = reinterpret_cast<float*>(smem + G::BIAS);
     TPROBE(0);
-    const bool producer = wave >= 4;
-    const int pw = wave - 4;
+    const bool producer = wave >= RT_NCONS;
+    const int pw = wave - RT_NCONS;
     {
         const int k = tid < 128 ? tid >> 5 : 4, cc = tid < 128 ? tid & 31 : tid - 128;   // 4 x 32 + 64 entries
         const float* bp = k == 0 ? d.bias[0] : k == 1 ? d.bias[1] : k == 2 ? d.bias[2] : k == 3 ? d.bias[3] : d.bias[4];   // no indexed access: the
@@ -630,26 +701,29 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         // ready word has ONE writer and a slab costs one decode, six loads, six stores and one flag; a queue of RT_RQ whole
         // slabs (6 KiB: six 16-byte vectors per lane) lives in registers.  (r03: dealing 1-KiB pieces round-robin made the
         // producers instruction bound — ~100 mostly scalar instructions per piece — and they paced the whole block.)
-        constexpr int RT_RQ = 3, NSP = (RT_NSLAB + RT_NPROD - 1) / RT_NPROD;    // up to 20 slabs per producer
+#ifndef RT_RQ_DEPTH
+#define RT_RQ_DEPTH 3
+#endif
+        constexpr int RT_RQ = RT_RQ_DEPTH, NSP = (RT_NSLAB + RT_NPROD - 1) / RT_NPROD;    // up to 20 slabs per producer
         static_assert(G::NST % RT_NPROD == 0, "a ring stage belongs to one producer");
         u32x4 wq[RT_RQ][6];
         // lane's 16 bytes inside a 1-KiB piece: conv1..4 rows of 64 B (part swizzled by (row >> 2) & 3), conv5 rows of 32 B
         // (by (row >> 3) & 1); the row phase of a piece is a multiple of 16 rows, so the pattern is the same for every piece
         const int lo14 = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
         const int lo5 = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-        auto load_from = [&](unsigned long long src64, int q, u32x4 (&r)[6]) {
-            rt_gptr src = (rt_gptr)src64;
-            const int lo = q >= 42 ? lo5 : lo14;
+        auto load_from = [&](unsigned long long src64, u32x4 (&r)[6]) {
+            rt_gptr src = (rt_gptr)(src64 & ~1ull);
+            const int lo = (src64 & 1ull) ? lo5 : lo14;                        // bit 0 of a table entry: conv5 layout
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
         };
-        // slab q >= 12: its source comes from the LDS table (beyond the end: the last slab again, never stored)
+        // a slab's source comes from the LDS table (beyond the end: the last slab again, never stored)
         auto load_slab = [&](int q, u32x4 (&r)[6]) {
             const int qc = min(q, RT_NSLAB - 1);
             unsigned long long a;
             asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"((int)lds0 + G::SRC + 8 * qc) : "memory");
             const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-            load_from(((unsigned long long)ahi << 32) | alo, qc, r);
+            load_from(((unsigned long long)ahi << 32) | alo, r);
         };
         // the first RT_RQ slabs go out before the barrier (the table is not there yet): decoded on the vector unit from an
         // opaque copy of q, so that the pointer pick stays a v_cndmask chain
@@ -659,10 +733,14 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             rt_pin(qv);
             const unsigned long long a = rt_slab_src<BWD>(d, qv);
             const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-            load_from(((unsigned long long)ahi << 32) | alo, q, wq[decltype(uc)::value]);
+            load_from(((unsigned long long)ahi << 32) | alo, wq[decltype(uc)::value]);
         });
         x0_store(rx);
         __syncthreads();   // the only barrier: X0, bias table, source table, zeroed control words
+#ifndef RT_PRIO_PROD
+#define RT_PRIO_PROD 0
+#endif
+        __builtin_amdgcn_s_setprio(RT_PRIO_PROD);
 #ifdef RT_X_NOPROD   // probe: the MFMA waves alone (with RT_X_NOSYNC)
         return;
 #endif
@@ -678,29 +756,32 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
 #define RT_PADD(k, a, b)
 #endif
         unsigned stv = lds0 + G::RING + lane * 16;             // + stage * RT_SLAB + e * 1024
-        unsigned flagv = lane == 0 ? lds0 + G::CTL : lds0 + G::SCR + 256 * wave + 4 * lane;   // lane 0: the ready words; others: scratch
+        unsigned flagv = lane == 0 ? lds0 + G::CTL : lds0 + G::SCR + 4 * lane;   // lane 0: the ready words; others: scratch
         rt_pin(stv);
         rt_pin(flagv);
         auto put = [&](int q, const u32x4 (&r)[6]) {
             RT_PT(tp0);
+            TRACE(4, q);
 #ifndef RT_X_NOSYNC
             if (q >= G::NST) {
                 for (;;) {
                     // inline asm: a compiler-visible LDS read here would make hipcc drain the refill loads first
-                    u32x4 dn;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
-                    const int dmin = (int)min(min(dn[0], dn[1]), min(dn[2], dn[3]));
+                    u32x4 dn, dm;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn), "=v"(dm) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
+                    const int dmin = (int)min(min(min(dn[0], dn[1]), min(dn[2], dn[3])), min(min(dm[0], dm[1]), min(dm[2], dm[3])));
                     if (__builtin_amdgcn_readfirstlane(dmin) >= q - (G::NST - 1)) break;
                     __builtin_amdgcn_s_sleep(RT_POLL_SLEEP);   // the ring is normally full: a poll per ~200 cycles is plenty and costs the MFMA wave of this SIMD nothing
                 }
             }
 #endif
             RT_PT(tp1);
+            TRACE(5, q);
             const int st = q % G::NST;
 #pragma unroll
             for (int e = 0; e < 6; ++e) rt_lds_write<u32x4>(stv + st * RT_SLAB + e * 1024, r[e]);
             rt_lds_write<int>(flagv + (lane == 0 ? 4 * ctl_ready(0) + 4 * st : 0), q / G::NST + 1);
             asm volatile("" ::: "memory");
+            TRACE(6, q);
             RT_PT(tp2);
             RT_PADD(0, tp0, tp1);
             RT_PADD(1, tp1, tp2);
@@ -715,129 +796,148 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
                 load_slab(q + RT_NPROD * RT_RQ, wq[u]);
             });
 #ifdef SSR_PROBE
-        if (tid == 256) { g_probe[blockIdx.x * 16 + 11] = pacc[0]; g_probe[blockIdx.x * 16 + 12] = pacc[1]; }
+        if (tid == 64 * RT_NCONS) { g_probe[blockIdx.x * 16 + 11] = pacc[0]; g_probe[blockIdx.x * 16 + 12] = pacc[1]; }
 #endif
         return;
     }
     // ---------------- MFMA waves ----------------
     u32x4 rx0[NQ];
     x0_load(rx0);
-    // this lane's pixels (rt_map) for every stage, requested now
-    const int w4 = wave & 3;
-    int ent1[G::nmt(1)], ent2[G::nmt(2)], ent3[G::nmt(3)], ent4[G::nmt(4)];
-    bool real1[G::nmt(1)], real2[G::nmt(2)], real3[G::nmt(3)], real4[G::nmt(4)];
-    auto fetch = [&](int K, int m, int& e, bool& rl) {
-        int t = 0;
-        // tile_of is constexpr in (K, w, m); w is a run-time value: select over the four waves
-        const int t0 = G::tile_of(K, 0, m), t1 = G::tile_of(K, 1, m), t2 = G::tile_of(K, 2, m), t3 = G::tile_of(K, 3, m);
-        t = w4 == 0 ? t0 : w4 == 1 ? t1 : w4 == 2 ? t2 : t3;
-        rl = t >= 0;
-        e = rt_map_entry<TW>(K, rl ? t : 0, i);
+    // this lane's pixels (rt_map) for every stage, requested now; tile_of is constexpr in (K, w, m), the wave index is a
+    // run-time (scalar) value: select over the eight waves
+    auto pick8 = [&](auto f) {
+        const int v0 = f(0), v1 = f(1), v2 = f(2), v3 = f(3), v4 = f(4), v5 = f(5), v6 = f(6), v7 = f(7);
+        return wave == 0 ? v0 : wave == 1 ? v1 : wave == 2 ? v2 : wave == 3 ? v3 : wave == 4 ? v4 : wave == 5 ? v5 : wave == 6 ? v6 : v7;
     };
+    int ent[4][2], ntl[4], prk[5];
 #pragma unroll
-    for (int m = 0; m < G::nmt(1); ++m) fetch(1, m, ent1[m], real1[m]);
+    for (int K = 1; K <= 4; ++K) {
+        ntl[K - 1] = pick8([&](int w) { return G::ntl(K, w); });
 #pragma unroll
-    for (int m = 0; m < G::nmt(2); ++m) fetch(2, m, ent2[m], real2[m]);
+        for (int m = 0; m < G::nmt(K); ++m) {
+            const int t = pick8([&](int w) { return G::tile_of(K, w, m); });
+            ent[K - 1][m] = rt_map_entry<TW>(K, t >= 0 ? t : 0, i);
+        }
+    }
 #pragma unroll
-    for (int m = 0; m < G::nmt(3); ++m) fetch(3, m, ent3[m], real3[m]);
-#pragma unroll
-    for (int m = 0; m < G::nmt(4); ++m) fetch(4, m, ent4[m], real4[m]);
-    const int mt5 = TW == 16 ? w4 : (w4 & 1), nt0 = TW == 16 ? 0 : (w4 >> 1);
+    for (int K = 1; K <= 5; ++K) prk[K - 1] = pick8([&](int w) { return G::prank(K, w); });
+    const int mt5 = pick8([&](int w) { return G::m5(w); }), nt5 = pick8([&](int w) { return G::n5(w); });
     const int e5 = rt_map_entry<TW>(5, mt5, i);
-    // rows of the output transpose slab this lane sends to memory: v = h*64 + lane -> row v >> 3 (TW=16: 64 co = 8 parts)
-    // or v >> 2 (TW=8: 32 co = 4 parts)
-    constexpr int OPARTS = G::NT5 * 4, OVEC = 32 * OPARTS / 64;
-    int e5s[OVEC];
+    // rows of the output transpose slab this lane sends to memory: v = h*64 + lane -> row v >> 2 (32 co = 4 parts)
+    int e5s[2];
 #pragma unroll
-    for (int hh = 0; hh < OVEC; ++hh) e5s[hh] = rt_map_entry<TW>(5, mt5, (hh * 64 + lane) / OPARTS);
+    for (int hh = 0; hh < 2; ++hh) e5s[hh] = rt_map_entry<TW>(5, mt5, (hh * 64 + lane) >> 2);
     x0_store(rx0);
     TPROBE(1);
     __syncthreads();   // the only barrier (see the producer branch)
+    TRACE(9, 0);
 #ifndef RT_PRIO_MFMA
 #define RT_PRIO_MFMA 1
 #endif
     __builtin_amdgcn_s_setprio(RT_PRIO_MFMA);
     const int bsw = (i >> 2) & 3;
-    RtCtx c{d, lds0, ctl, bias_lds, n, ty0, tx0, tid, lane, wave, i, g,
+    RtCtx c{d, lds0, ctl, bias_lds, n, ty0, tx0, tid, lane, wave, i, g, 0,
             (int)lds0 + i * 64 + ((g ^ bsw) << 4), (int)lds0 + i * 64 + (((g ^ bsw) ^ 2) << 4),
-            (int)lds0 + nt0 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4), 0, lds0 + G::CTL, lane == 0 ? lds0 + G::CTL + 4 * (RT_CTL_DONE + w4) : lds0 + G::SCR + 256 * wave + 4 * lane};
+            (int)lds0 + nt5 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4), 0, lds0 + G::CTL,
+            lane == 0 ? lds0 + G::CTL + 4 * (RT_CTL_DONE + wave) : lds0 + G::SCR + 4 * lane};
     rt_pin(c.ctlv);
     rt_pin(c.donev);
     rt_pin(c.wb0);
     rt_pin(c.wb1);
     rt_pin(c.wb5);
-    rt_stage<TW, 1, G::nmt(1), BWD>(c, ent1, real1);
-    TPROBE(2);
-    rt_stage<TW, 2, G::nmt(2), BWD>(c, ent2, real2);
-    TPROBE(3);
-    rt_stage<TW, 3, G::nmt(3), BWD>(c, ent3, real3);
-    TPROBE(4);
-    rt_stage<TW, 4, G::nmt(4), BWD>(c, ent4, real4);
-    TPROBE(5);
-    // ================= stage 5: the core x 64 channels ======
-    {
-        constexpr int NT5 = G::NT5;
-        f32x16 acc[NT5];
-        const RtPix px = rt_pix(e5, true, n, ty0, tx0, H, W);       // always a core pixel
-        // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
-        // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
-        //                 + beta1*d_out + beta2*d_out_rrdb
-        // (alpha5 multiplies the bias too: the accumulator starts at b5 and is scaled as a whole)
+    // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
+    // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
+    //                 + beta1*d_out + beta2*d_out_rrdb
+    // (alpha5 multiplies the bias too: the accumulator starts at b5 and is scaled as a whole)
+    f32x16 acc5;
+    rt_acc_init<BWD>(acc5, bias_lds + 128 + nt5 * 32, g);
+    // extended stages E1..E4: growth conv K (the instantiation for the number of tiles this wave owns; none: it only hands the
+    // slabs back) with conv5's chunk K-1 in front of the growth chunk that needs the newest slice
+    static_for<1, 5>([&](auto K_c) {
+        constexpr int K = decltype(K_c)::value;
+        c.prank = prk[K - 1];
+        const int nt = ntl[K - 1];
+        RtGrow<G::nmt(K)> sa;       // this wave owns nmt(K) tiles ...
+        RtGrow<1> sb;               // ... or one (only one of the two states is ever live)
+        int ea[G::nmt(K)], eb[1] = {ent[K - 1][0]};
 #pragma unroll
-        for (int u = 0; u < NT5; ++u) rt_acc_init<BWD>(acc[u], bias_lds + 128 + (nt0 + u) * 32, g);
-        // residual r2 (x_rrdb / d out_rrdb): this lane's pixel, 16 channels per N-tile = four 8-byte loads, issued now and
-        // consumed in the epilogue
-        const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
-        rt_u32x2 r2v[NT5][4];
-        if (r2p) {
-            const __bf16* rp = r2p + px.gpix * d.r2.cs + d.r2.coff + 4 * g;
-#pragma unroll
-            for (int u = 0; u < NT5; ++u)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) r2v[u][q4] = *reinterpret_cast<const rt_u32x2*>(rp + (nt0 + u) * 32 + 8 * q4);
+        for (int m = 0; m < G::nmt(K); ++m) ea[m] = ent[K - 1][m];
+        constexpr bool TWO = G::nmt(K) == 2;
+        constexpr int JA = K == 1 ? 2 : K;      // growth chunks in front of the stage's conv5 chunk (conv1: both, then its epilogue)
+#if !RT_INTERLEAVE5
+        if (TWO && nt == 2) { rt_grow_begin<TW, K, G::nmt(K), BWD>(c, sa, ea); rt_grow_run<TW, K, G::nmt(K), BWD, 0, K + 1>(c, sa); rt_grow_end<TW, K, G::nmt(K), BWD>(c, sa); }
+        else if (nt >= 1) { rt_grow_begin<TW, K, 1, BWD>(c, sb, eb); rt_grow_run<TW, K, 1, BWD, 0, K + 1>(c, sb); rt_grow_end<TW, K, 1, BWD>(c, sb); }
+        (void)JA;
+        if constexpr (false) {
+#else
+        if (TWO && nt == 2) { rt_grow_begin<TW, K, G::nmt(K), BWD>(c, sa, ea); rt_grow_run<TW, K, G::nmt(K), BWD, 0, JA>(c, sa); if constexpr (K == 1) rt_grow_end<TW, K, G::nmt(K), BWD>(c, sa); }
+        else if (nt >= 1) { rt_grow_begin<TW, K, 1, BWD>(c, sb, eb); rt_grow_run<TW, K, 1, BWD, 0, JA>(c, sb); if constexpr (K == 1) rt_grow_end<TW, K, 1, BWD>(c, sb); }
+        rt_c5_run<TW, BWD, K - 1, K>(c, acc5, e5);
+        if constexpr (K > 1) {
+#endif
+            if (TWO && nt == 2) { rt_grow_run<TW, K, G::nmt(K), BWD, K, K + 1>(c, sa); rt_grow_end<TW, K, G::nmt(K), BWD>(c, sa); }
+            else if (nt >= 1) { rt_grow_run<TW, K, 1, BWD, K, K + 1>(c, sb); rt_grow_end<TW, K, 1, BWD>(c, sb); }
         }
-        rt_stage5<TW, BWD>(c, acc, px, nt0);
+        TPROBE(K + 1);
+    });
+    // ================= E5: conv5 chunks 4 (slice 3) and 5 (slice 4) ======
+    c.prank = prk[4];
+    {
+        const RtPix px = rt_pix(e5, true, n, ty0, tx0, H, W);       // always a core pixel
+        // residual r2 (x_rrdb / d out_rrdb): this lane's pixel, 16 channels = four 8-byte loads, issued now and consumed in
+        // the epilogue
+        const __bf16* __restrict__ r2p = reinterpret_cast<const __bf16*>(d.r2.p);
+        rt_u32x2 r2v[4];
+        if (r2p) {
+            const __bf16* rp = r2p + px.gpix * d.r2.cs + d.r2.coff + nt5 * 32 + 4 * g;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) r2v[q4] = *reinterpret_cast<const rt_u32x2*>(rp + 8 * q4);
+        }
+#if RT_INTERLEAVE5
+        rt_c5_run<TW, BWD, 4, 6>(c, acc5, e5);
+#else
+        rt_c5_run<TW, BWD, 0, 6>(c, acc5, e5);
+#endif
         TPROBE(6);
         if (lane == 0) rt_inc(ctl + RT_CTL_SLICE + 5);
-        rt_wait_ge(ctl + RT_CTL_SLICE + 5, 4);   // every wave is finished with the ring: it becomes the output transpose slabs
+        rt_wait_ge(ctl + RT_CTL_SLICE + 5, G::npart(5));   // every wave is finished with the ring: it becomes the output transpose slabs
         {
             const int f0 = rt_f(px.Y, px.X);
             const int xrow = 64 * (px.Y * G::pitch(0) + px.X);
-            const unsigned slabw = lds0 + G::RING + w4 * (32 * G::TROW);     // [32 px][NT5*32 co] bf16, TROW-byte rows
+            const unsigned slabw = lds0 + G::RING + wave * (32 * G::TROW);     // [32 px][32 co] bf16, TROW-byte rows
 #pragma unroll
-            for (int u = 0; u < NT5; ++u)
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const rt_u32x2 xw = rt_lds_read<rt_u32x2>(lds0 + G::base(0) + nt5 * G::PLANE + xrow + ((q4 ^ f0) << 4) + 8 * g);
+                const float xv[4] = {rt_bf_lo(xw[0]), rt_bf_hi(xw[0]), rt_bf_lo(xw[1]), rt_bf_hi(xw[1])};
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r2p) { rv[0] = rt_bf_lo(r2v[q4][0]); rv[1] = rt_bf_hi(r2v[q4][0]); rv[2] = rt_bf_lo(r2v[q4][1]); rv[3] = rt_bf_hi(r2v[q4][1]); }
+                rt_bf16x4 o;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const rt_u32x2 xw = rt_lds_read<rt_u32x2>(lds0 + G::base(0) + (nt0 + u) * G::PLANE + xrow + ((q4 ^ f0) << 4) + 8 * g);
-                    const float xv[4] = {rt_bf_lo(xw[0]), rt_bf_hi(xw[0]), rt_bf_lo(xw[1]), rt_bf_hi(xw[1])};
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (r2p) { rv[0] = rt_bf_lo(r2v[u][q4][0]); rv[1] = rt_bf_hi(r2v[u][q4][0]); rv[2] = rt_bf_lo(r2v[u][q4][1]); rv[3] = rt_bf_hi(r2v[u][q4][1]); }
-                    rt_bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = d.alpha5 * acc[u][4 * q4 + e] + d.beta1 * xv[e];
-                        if (r2p) v += d.beta2 * rv[e];
-                        o[e] = (__bf16)v;
-                    }
-                    rt_lds_write<rt_bf16x4>(slabw + i * G::TROW + u * 64 + 16 * q4 + 8 * g, o);
+                for (int e = 0; e < 4; ++e) {
+                    float v = d.alpha5 * acc5[4 * q4 + e] + d.beta1 * xv[e];
+                    if (r2p) v += d.beta2 * rv[e];
+                    o[e] = (__bf16)v;
                 }
-            // the wave's 32 px x (NT5*64 B) tile -> 16-byte vectors (row = the lane of the M-tile that owns the pixel)
+                rt_lds_write<rt_bf16x4>(slabw + i * G::TROW + 16 * q4 + 8 * g, o);
+            }
+            // the wave's 32 px x 64 B tile -> 16-byte vectors (row = the lane of the M-tile that owns the pixel)
 #pragma unroll
-            for (int hh = 0; hh < OVEC; ++hh) {
+            for (int hh = 0; hh < 2; ++hh) {
                 const int v = hh * 64 + lane;
-                const int row = v / OPARTS, part = v - row * OPARTS;
+                const int row = v >> 2, part = v & 3;
                 const int es = e5s[hh];
                 const int oy = ty0 - 5 + (es & 31), ox = tx0 - 5 + ((es >> 5) & 31);
                 const u32x4 val = rt_lds_read<u32x4>(slabw + row * G::TROW + part * 16);
                 if (oy < H && ox < W) {
                     __bf16* dst = reinterpret_cast<__bf16*>(d.out.p) + ((size_t)(n * H + oy) * W + ox) * d.out.cs +
-                                  d.out.coff + nt0 * 32 + part * 8;
+                                  d.out.coff + nt5 * 32 + part * 8;
                     *reinterpret_cast<u32x4*>(dst) = val;
                 }
             }
         }
     }
     TPROBE(7);
+    TRACE(10, 0);
 #ifdef SSR_PROBE
     if (threadIdx.x == 0) { g_probe[blockIdx.x * 16 + 13] = c.slice_ticks; g_probe[blockIdx.x * 16 + 14] = c.wait_ticks; g_probe[blockIdx.x * 16 + 15] = c.wait_n; }
 #endif
@@ -862,7 +962,8 @@ int rdbt_launch_tw(const ssr_rdb_desc& d, void* stream, bool bwd) {
 
 }  // namespace
 
-// tile width 16 or 8; descriptor already validated by the caller (csrc/rdb_fwd.hip: rdb_launch)
+// descriptor already validated by the caller (csrc/rdb_fwd.hip: rdb_launch)
 int rdbt_launch(const ssr_rdb_desc& d, void* stream, bool bwd, int tw) {
-    return tw == 16 ? rdbt_launch_tw<16>(d, stream, bwd) : rdbt_launch_tw<8>(d, stream, bwd);
+    (void)tw;                                      // 8 x 16 tiles only
+    return rdbt_launch_tw<16>(d, stream, bwd);
 }

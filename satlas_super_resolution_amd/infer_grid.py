@@ -41,7 +41,10 @@ def load_generator(opt: Dict, device) -> torch.nn.Module:
     else:
         state_dict = torch.load(path["pretrain_network_g"], map_location="cpu")
         model.load_state_dict(state_dict[path["param_key_g"]], strict=path["strict_load_g"])
-    return model.to(device).eval()
+    model = model.to(device).eval()
+    if torch.device(device).type == "cuda":
+        model.freeze_packed()          # fixed weights for the whole run: pack once, not per chunk batch (HipNet.pack_if_stale)
+    return model
 
 
 def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, rank: int = 0, world: int = 1,

@@ -230,7 +230,7 @@ class SSRESRGANModel:
         if ts is not None:
             st.data.copy_(ts.opt_g.ema if ts.opt_g.ema is not None else ts.g_store.data)
         st.pack()
-        plan.load_input((self.lr * 255).contiguous(), 1.0 / 255)
+        plan.load_input(self.lr.contiguous(), 1.0)      # self.lr = lr/255 already (one rounding, as :107 of the reference)
         plan.fwd.run()
         self.output = plan.read_output()
 
@@ -354,26 +354,28 @@ class SSRESRGANModel:
             rec.setdefault(m, dict(better=better, val=float("-inf") if better == "higher" else float("inf"), iter=-1))
         n = 0
         self._validating = True
-        for idx, val_data in enumerate(dataloader):
-            self.feed_data(val_data)
-            self.test()
-            sr = M.tensor2img_u8(self.output)                 # [B,H,W,3] uint8 RGB on the device (tensor2img: clamp, *255, round)
-            gt = M.tensor2img_u8(self.gt) if self.gt is not None else None
-            if save_img:
-                vis = self.opt.get("path", {}).get("visualization", "experiments/visualization")
-                base = os.path.join(vis, str(idx)) if self.opt.get("is_train", True) else os.path.join(vis, dataset_name)
-                os.makedirs(base, exist_ok=True)
-                tag = f"{idx}_{current_iter}" if self.opt.get("is_train", True) else f"{idx}_{self.opt.get('name', 'run')}"
-                M.imwrite_rgb(sr[0].cpu().numpy(), os.path.join(base, tag + ".png"))
+        try:       # an exception below (bad image, unsupported metric option, OOM) must not leave the model in validation mode
+            for idx, val_data in enumerate(dataloader):
+                self.feed_data(val_data)
+                self.test()
+                sr = M.tensor2img_u8(self.output)                 # [B,H,W,3] uint8 RGB on the device (tensor2img: clamp, *255, round)
+                gt = M.tensor2img_u8(self.gt) if self.gt is not None else None
+                if save_img:
+                    vis = self.opt.get("path", {}).get("visualization", "experiments/visualization")
+                    base = os.path.join(vis, str(idx)) if self.opt.get("is_train", True) else os.path.join(vis, dataset_name)
+                    os.makedirs(base, exist_ok=True)
+                    tag = f"{idx}_{current_iter}" if self.opt.get("is_train", True) else f"{idx}_{self.opt.get('name', 'run')}"
+                    M.imwrite_rgb(sr[0].cpu().numpy(), os.path.join(base, tag + ".png"))
+                    if gt is not None:
+                        M.imwrite_rgb(gt[0].cpu().numpy(), os.path.join(base, tag + "_gt.png"))
                 if gt is not None:
-                    M.imwrite_rgb(gt[0].cpu().numpy(), os.path.join(base, tag + "_gt.png"))
-            if gt is not None:
-                for name, mo in metrics2run.items():
-                    kw = {k: v for k, v in mo.items() if k not in ("type", "better")}
-                    self.metric_results[name] += float(M.METRICS[mo["type"]](sr[:1], gt[:1], **kw))
-            n += 1
-            self.gt = self.output = None
-        self._validating = False
+                    for name, mo in metrics2run.items():
+                        kw = {k: v for k, v in mo.items() if k not in ("type", "better")}
+                        self.metric_results[name] += float(M.METRICS[mo["type"]](sr[:1], gt[:1], **kw))
+                n += 1
+                self.gt = self.output = None
+        finally:
+            self._validating = False
         for name in self.metric_results:
             self.metric_results[name] /= max(n, 1)
             r = rec[name]

@@ -48,6 +48,8 @@ def train(opt: Dict, max_iters: Optional[int] = None, resume_state: Optional[Dic
     logger_opt = opt.get("logger", {})
     t0, seen = time.time(), 0
     while current_iter < total_iters:
+        if hasattr(loader.sampler, "set_epoch"):
+            loader.sampler.set_epoch(epoch)
         for batch in loader:
             current_iter += 1
             if current_iter > total_iters:
@@ -56,10 +58,14 @@ def train(opt: Dict, max_iters: Optional[int] = None, resume_state: Optional[Dic
             model.feed_data(batch)
             model.optimize_parameters(current_iter)
             seen += batch["lr"].shape[0]
-            if current_iter % int(logger_opt.get("print_freq", 100)) == 0 and rank == 0:
-                msg = {"epoch": epoch, "iter": current_iter, "lrs": model.get_current_learning_rate(),
-                       "img_per_s": round(world * seen / (time.time() - t0), 1), **model.get_current_log()}
-                log(json.dumps(msg))
+            if current_iter % int(logger_opt.get("print_freq", 100)) == 0:
+                # get_current_log() reduces the loss scalars over the ranks (a collective): EVERY rank calls it, as the
+                # reference's loop does (ssr/train.py:111-117 -> reduce_loss_dict); only rank 0 prints
+                cur_log = model.get_current_log()
+                if rank == 0:
+                    msg = {"epoch": epoch, "iter": current_iter, "lrs": model.get_current_learning_rate(),
+                           "img_per_s": round(world * seen / (time.time() - t0), 1), **cur_log}
+                    log(json.dumps(msg))
             if current_iter % int(float(logger_opt.get("save_checkpoint_freq", 5e3))) == 0:
                 model.save(epoch, current_iter)
             if opt.get("val") is not None and current_iter % int(float(opt["val"]["val_freq"])) == 0:
@@ -92,7 +98,16 @@ def main():
     opt["path"].setdefault("training_states", os.path.join(root, "training_states"))
     opt["path"].setdefault("visualization", os.path.join(root, "visualization"))
     resume = None
-    if args.auto_resume and os.path.isdir(opt["path"]["training_states"]):
+    if opt["path"].get("resume_state"):
+        # BasicSR's load_resume_state + check_resume: an explicit state file also redirects the network checkpoints to the
+        # state's iteration (the reference's option files resume this way)
+        resume = torch.load(opt["path"]["resume_state"], map_location="cpu", weights_only=False)
+        it = resume["iter"]
+        for net in ("g", "d"):
+            cand = os.path.join(opt["path"]["models"], f"net_{net}_{it}.pth")
+            if os.path.exists(cand) or not opt["path"].get(f"pretrain_network_{net}"):
+                opt["path"][f"pretrain_network_{net}"] = cand
+    elif args.auto_resume and os.path.isdir(opt["path"]["training_states"]):
         states = [f for f in os.listdir(opt["path"]["training_states"]) if f.endswith(".state") and f[:-6].isdigit()]
         if states:
             it = max(int(f[:-6]) for f in states)

@@ -118,7 +118,12 @@ class ESRGANTrainStep:
         # single-wave-per-CU kernels: the fused dense blocks (bf16, nf = 64, gc = 32) at batches of two full rounds or more
         # r02g, two boxes, B = 32 8xS2 bf16: 14.40 -> 13.97 ms and 13.78 -> 13.53 ms per step with two chains; four chains
         # (half-chip launches): 14.9 ms — slower; B = 16 (one round per launch already): no difference
-        n_split = int(os.environ.get("SSR_G_SPLIT", "2"))
+        # r03: the 8 x 16-tile dense-block kernel (csrc/rdb_tile.hip) wants the WHOLE batch in one launch (one workgroup per CU at
+        # B = 32, 32 x 32 tiles) and brings its own second wave per SIMD; measured 12.49 ms (one chain, new kernel) vs 12.68 (two
+        # chains, new kernel) vs 13.32 (two chains, 8 x 8 kernel).  "auto" = split only where the 8 x 8 kernel will run.
+        env_split = os.environ.get("SSR_G_SPLIT", "auto")
+        wide = B * ((h + 7) // 8) * ((w + 15) // 16) >= 192 and os.environ.get("SSR_RDB_TILE", "auto") not in ("0",)
+        n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
         split = n_split > 1 and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
             and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
         if split:

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <cstdint>
 #include <vector>
+#ifdef RT_TRACE
+__device__ unsigned long long* g_trace;
+#endif
 #ifdef SSR_PROBE
 __device__ unsigned long long* g_probe;
 __device__ unsigned long long* g_probe2;
@@ -216,9 +219,32 @@ static void probe_case(int N, int tile, bool bwd) {
 }
 #endif
 
+#ifdef RT_TRACE
+static void trace_case(int N, bool bwd) {
+    Bufs b = make(N, 32, 32);
+    g_rdb_tile_override = 16;
+    unsigned long long* tr; hipMalloc(&tr, 12 * 512 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &tr, sizeof(tr));
+    ssr_rdb_desc d = bwd ? desc_bwd(b, false) : desc_fwd(b, false);
+    for (int it = 0; it < 3; ++it) { hipMemset(tr, 0, 12 * 512 * 8); bwd ? ssr_rdb_backward(&d, 0) : ssr_rdb_forward(&d, 0); hipDeviceSynchronize(); }
+    std::vector<unsigned long long> h(12 * 512);
+    hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < 12; ++w) for (unsigned long long k = 0; k < h[w * 512]; ++k) { unsigned long long t = h[w * 512 + 1 + k] & 0xffffffffffffull; if (t < t0) t0 = t; }
+    for (int w = 0; w < 12; ++w)
+        for (unsigned long long k = 0; k < h[w * 512]; ++k) {
+            const unsigned long long e = h[w * 512 + 1 + k];
+            printf("T %d %d %d %llu\n", w, (int)(e >> 56), (int)((e >> 48) & 0xff), (e & 0xffffffffffffull) - t0);
+        }
+}
+#endif
+
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "all";
     int fails = 0;
+#ifdef RT_TRACE
+    if (!strcmp(mode, "trace")) { trace_case(32, argc > 2); return 0; }
+#endif
 #ifdef SSR_PROBE
     if (!strcmp(mode, "probe")) {
         for (int tile : {16, 8}) for (int bwd = 0; bwd < 2; ++bwd) probe_case(32, tile, bwd);

@@ -152,6 +152,8 @@ int ssr_rdb_backward(const ssr_rdb_desc* d, void* stream);
  * 0 = 8 x 8 tiles, 16 = 8 x 16 tiles.  Both kernels add the same products in the same order: their results are bit-identical
  * (tests/test_gpu_rdb_tile.py).  Returns the previous setting. */
 int ssr_rdb_set_tile(int32_t tile);
+/* the kernel ssr_rdb_forward / ssr_rdb_backward would run for this descriptor now: 0 = 8 x 8 tiles, 16 = 8 x 16 tiles */
+int ssr_rdb_tile_of(const ssr_rdb_desc* d);
 
 /*
  * Weight gradient (autograd's convolution_backward weight/bias part, triggered at

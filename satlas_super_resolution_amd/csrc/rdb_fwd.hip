@@ -787,5 +787,6 @@ extern "C" int ssr_rdb_set_tile(int32_t tile) {
     g_rdb_tile_override = (tile == 0 || tile == 16) ? tile : -1;
     return prev;
 }
+extern "C" int ssr_rdb_tile_of(const ssr_rdb_desc* d) { return d ? rdb_pick_tile(*d) : SSR_EINVAL; }
 extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, false); }
 extern "C" int ssr_rdb_backward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, true); }

@@ -448,6 +448,42 @@ def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
     _vs_truth(plan.read_input_grad(), fx["dx"], x64.grad, "dx", mode, is_input_grad=True)
     for k, gr in fx["grads"].items():
         _vs_truth(st.tensor(k, st.grad), gr, sd64[k].grad, k, mode)
+    # ... and the ASSERTED criterion for both modes: with the device's own LeakyReLU decisions (sign of its stored activations) the
+    # float64 oracle is the same piecewise-linear function the device differentiated, so every gradient must agree to arithmetic
+    # rounding.  279 activations: conv1..4 of the 69 dense blocks, conv_up1, conv_up2, conv_hr (oracle call order).
+    nf, gc = kw.get("num_feat", 64), kw.get("num_grow_ch", 32)
+    masks = [_nchw(plan.bufs[r], nf + gc * (k - 1), nf + gc * k) > 0 for r in range(len(plan.bufs)) for k in range(1, 5)]
+    masks += [_nchw(u, 0, nf) > 0 for u in plan.ups] + [_nchw(plan.hr, 0, nf) > 0]
+    _masked_gradient_check(lambda sdm, xm, prec: O.generator_forward(sdm, xm, 4, prec=prec), sd, x, r, masks,
+                           {"dx": plan.read_input_grad(), **{k: st.tensor(k, st.grad) for k in fx["grads"]}}, mode)
+
+
+def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
+    from oracle import esrgan_oracle as O
+    prec = O.MaskedPrec([m.cpu() for m in masks])
+    keys = [k for k in sd if (param_keys is None or k in param_keys)]
+    sdm = OrderedDict((k, (v.double().requires_grad_(True) if k in keys and v.is_floating_point() else v.double() if v.is_floating_point() else v))
+                      for k, v in sd.items())
+    xm = x.double().requires_grad_(True)
+    (fwd(sdm, xm, prec) * r.double()).sum().backward()
+    assert prec.k == len(masks), (prec.k, len(masks))
+    flips, total = sum(prec.flips), sum(prec.sizes)
+    worst = max(range(len(prec.flips)), key=lambda i: prec.flips[i] / prec.sizes[i])
+    print(f"[{mode} masked] LeakyReLU decisions that differ from the float64 oracle's own: {flips} of {total} ({flips / total:.2e}); "
+          f"worst activation #{worst}: {prec.flips[worst]} of {prec.sizes[worst]}")
+    tol = 2e-4 if mode == "fp32x3" else 1e-4          # of max|ref| per tensor; measured: see the printed lines
+    worst_err = 0.0
+    for k, g in got.items():
+        ref = xm.grad if k.startswith("dx") else sdm[k].grad
+        if k == "dx[:3]":
+            ref = ref[:, :3]
+        elif k == "dx[-3:]":
+            ref = ref[:, -3:]
+        g = g.detach().double().cpu()
+        e = float((g - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        worst_err = max(worst_err, e)
+        assert e <= tol, (mode, k, e)
+    print(f"[{mode} masked] worst parameter / input gradient deviation from the mask-conditioned float64 oracle: {worst_err:.2e} of max|ref| (asserted <= {tol:.0e})")
 
 
 @pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3")])                    # full_d27 pins the oracle (CPU test)
@@ -491,3 +527,8 @@ def test_discriminator_vs_reference_class_at_full_size(mode, name):
     _vs_truth(dx[:, -3:], fx["dx_last3"], x64.grad[:, -3:], "dx[-3:]", mode, is_input_grad=True)
     for k, gr in fx["grads"].items():
         _vs_truth(st.tensor(k, st.grad), gr, sd64[k].grad, k, mode)
+    # asserted: the device's nine LeakyReLU decisions (conv0..conv8, oracle call order) imposed on the float64 oracle
+    masks = [_nchw(t, 0, t.shape[-1]) > 0 for t in (plan.x0, plan.x1, plan.x2, plan.x3, plan.a4, plan.a5, plan.a6, plan.o7, plan.o8)]
+    sd_before = O.discriminator_init(c_d, 64, seed=fx["seed"])      # u / v before the power iteration, as the device started
+    _masked_gradient_check(lambda sdm, xm, prec: O.discriminator_forward(sdm, xm, train=True, prec=prec), sd_before, x, r, masks,
+                           {"dx[:3]": dx[:, :3], "dx[-3:]": dx[:, -3:], **{k: st.tensor(k, st.grad) for k in fx["grads"]}}, mode, O.D_PARAM_KEYS)

@@ -399,3 +399,46 @@ def test_test_pipeline_generator_only(tmp_path):
     bad = dict(opt, test={"save_img": False, "metrics": {"lpips": {"type": "calculate_lpips", "lpips_model": "vgg"}}})
     with pytest.raises(NotImplementedError, match="calculate_lpips"):
         test_pipeline(bad, log=lambda *_: None)
+
+
+@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated"])
+def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
+    """The MODEL_REGISTRY plugin driven like ssr/train.py drives the reference model (feed_data(uint8 batch) ->
+    optimize_parameters(it) -> get_current_log(); test()) against fixtures produced by EXECUTING the unmodified
+    SSRESRGANModel.feed_data / optimize_parameters / test of /root/reference/ssr/models/ssr_esrgan_model.py:104-244
+    (oracle/make_golden_refstep.py)."""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden(name)
+    opt = _opt(tmp_path, fx, feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)))
+    opt["train"].update({"ema_decay": fx["ema_decay"], "net_d_iters": fx["net_d_iters"], "net_d_init_iters": fx["net_d_init_iters"],
+                         "optim_d": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])},
+                         "optim_g": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])}})
+    opt["train"].pop("scheduler", None)
+    torch.save({"params": fx["g0"], "params_ema": fx["g0"]}, tmp_path / "g0.pth")
+    torch.save({"params": fx["d0"]}, tmp_path / "d0.pth")
+    opt["path"].update({"pretrain_network_g": str(tmp_path / "g0.pth"), "pretrain_network_d": str(tmp_path / "d0.pth"),
+                        "param_key_g": "params", "strict_load_g": True})
+    m = build_model(opt)
+    for it, batch in enumerate(fx["data"], start=1):
+        m.feed_data(batch)
+        m.optimize_parameters(it)
+        log, ref = m.get_current_log(), fx["logs"][it - 1]
+        for k, v in ref.items():
+            assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, log[k], v)
+        if "l_g_pix" not in ref:                  # a gated iteration: the reference's log has no generator terms
+            assert log.get("l_g_pix", 0.0) == 0.0
+    n = len(fx["data"])
+    for k, v in fx["g_final"].items():
+        _close_update(m.ts.g_store.tensor(k).cpu(), v, fx["g0"][k], ("G", k), 5e-2)
+    sd_d = m.ts.d_store.state_dict()
+    for k, v in fx["d_final"].items():
+        if k.endswith("_u") or k.endswith("_v"):
+            assert rel_err(sd_d[k].cpu(), v) < 1e-3, ("D buffer", k)
+        else:
+            _close_update(sd_d[k].cpu(), v, fx["d0"][k], ("D", k), 5e-2)
+    ema = m.ts.ema_state_dict()
+    for k, v in fx["g_ema_final"].items():
+        _close_update(ema[k].cpu(), v, fx["g0"][k], ("EMA", k), 5e-2)
+    m.test()                                      # :235-244: net_g_ema under no_grad on the last batch
+    assert parity_close(m.output.cpu(), fx["test_output"]), rel_err(m.output.cpu(), fx["test_output"])

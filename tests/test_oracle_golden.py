@@ -82,6 +82,45 @@ def test_train_step(name):
     assert rel_err(m.output, fx["output_last"]) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated"])
+def test_train_step_against_the_unmodified_reference_method(name):
+    """The oracle's step against fixtures produced by EXECUTING the reference's own SSRESRGANModel.feed_data /
+    optimize_parameters / test (ssr_esrgan_model.py:104-244; oracle/make_golden_refstep.py) — not a re-typed loop: freeze /
+    unfreeze, detach().clone(), the two D backwards, the gate, the discriminator-input channel order and the EMA placement are
+    the reference's text."""
+    fx = load_golden(name)
+    cfg = O.StepConfig(l1_weight=fx["l1_weight"], gan_weight=fx["gan_weight"], lr_g=fx["lr"], lr_d=fx["lr"],
+                       betas=tuple(fx["betas"]), ema_decay=fx["ema_decay"], feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)),
+                       net_d_iters=fx["net_d_iters"], net_d_init_iters=fx["net_d_init_iters"])
+    m = O.ESRGANOracle(fx["g0"], fx["d0"], cfg)
+    for it, batch in enumerate(fx["data"], start=1):
+        lr, gt = batch["lr"].float() / 255, batch["hr"].float() / 255            # feed_data :107-109
+        old = batch["old_hr"].float() / 255 if "old_hr" in batch else None
+        log = m.step(lr, gt, it, old_hr=old)
+        ref = fx["logs"][it - 1]
+        g_on = it % fx["net_d_iters"] == 0 and it > fx["net_d_init_iters"]
+        assert ("l_g_pix" in ref) == g_on == ("l_g_pix" in log), (it, list(ref), list(log))
+        for k, v in ref.items():
+            assert abs(log[k] - v) <= 2e-5 * max(1.0, abs(v)), (it, k, log[k], v)
+        if fx["g_grads_first"] is not None and it == fx["g_grads_first"][0]:
+            for k, g in fx["g_grads_first"][1].items():
+                assert rel_err(m.g_grads[k], g) < 1e-4, k
+        if it == 1:
+            for k, g in fx["d_grads_iter1"].items():
+                assert rel_err(m.d_grads[k], g) < 1e-4, k
+    for k, v in fx["g_final"].items():
+        upd_ref, upd = v - fx["g0"][k], m.g[k] - fx["g0"][k]
+        assert (upd - upd_ref).abs().max() <= 2e-2 * upd_ref.abs().max() + 1e-9, k
+    for k, v in fx["d_final"].items():
+        assert (m.d[k] - v).abs().max() <= 2e-2 * (v - fx["d0"][k]).abs().max() + 1e-6, k
+    for k, v in fx["g_ema_final"].items():
+        assert rel_err(m.g_ema[k], v) < 1e-5, k
+    # test(): net_g_ema on the last lr batch
+    with torch.no_grad():
+        out = O.generator_forward(m.g_ema, fx["data"][-1]["lr"].float() / 255, 4)
+    assert rel_err(out, fx["test_output"]) < 1e-4
+
+
 def test_index_maps():
     fx = load_golden("index_maps")
     for key, ref in fx.items():

@@ -603,7 +603,8 @@ class GeneratorPlan:
 
     def __init__(self, store: ParamStore, B: int, H: int, W: int, *, num_in_ch, num_out_ch=3, scale=4, num_feat=64,
                  num_block=23, num_grow_ch=32, training=True, out_buf: Optional[torch.Tensor] = None,
-                 d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False, wgrad_atomic: bool = False):
+                 d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False, wgrad_atomic: bool = False,
+                 bwd_segments: int = 1):
         self.store, self.B, self.dt = store, B, store.dtype
         self.scale, self.nf, self.nb, self.gc = scale, num_feat, num_block, num_grow_ch
         self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
@@ -702,20 +703,39 @@ class GeneratorPlan:
         # weight gradients: ONE batched launch after the last dgrad (default), or SSR_WGRAD_CHUNKS = n batches, each forked onto
         # a side stream as soon as the gradient buffers it reads are final, beside the remaining (strictly sequential) dgrad chain
         n_chunks = max(1, int(os.environ.get("SSR_WGRAD_CHUNKS", "1")))
+        # data parallel (bwd_segments > 1): the backward is cut into SEGMENTS, each = a stretch of the dgrad chain followed IN LINE
+        # by the weight-gradient batch of the layers it has finished; the caller exchanges a segment's slice of the gradient arena
+        # while the next segment runs (train_step: one all-reduce per segment on the comm stream) — the bucketed overlap of the
+        # reference's DDP (README.md:159, options.py:65-81) on flat arenas.  Arena order is the state_dict's (conv_first, body.0 ..
+        # body.nb-1, conv_body, conv_up*, conv_hr, conv_last) and the backward walks it from the end, so a segment's parameters
+        # are one contiguous range.
+        n_seg = max(1, int(bwd_segments))
+        if n_seg > 1:
+            n_chunks = n_seg
         cuts = {round(n_rdb * q / n_chunks) for q in range(1, n_chunks)}     # close a batch before RDB index r in `cuts`
         batches = [WgradBatch(self.dt, 3, 1, wgrad_atomic)]
+        self.bwd_segments = []        # [(Launcher, arena offset, arena elements)]
+        seg_state = {"launcher": Bk, "hi": st.numel}
 
         def add_wg(name, x: View, dy: View, hi, wi, up, gh, gw, alpha=1.0, cin=None):
             s = st.specs[name]
             batches[-1].add(x, dy, B, hi, wi, up, rup(s.cin, 8) if cin is None else cin, s.cout, gh, gw, alpha,
                             st.ptr(name + ".weight", st.grad), s.cin, st.ptr(name + ".bias", st.grad) if s.bias else None)
 
-        def close_batch():
+        def close_batch(next_first_key=None):
+            nonlocal Bk
             wgb = batches[-1]
             wgb.finalize()
-            sub = Launcher()
-            wgb.launch(sub)
-            Bk.fork(sub, what="wgrad chunk")
+            if n_seg > 1:
+                wgb.launch(Bk)                      # in line: the segment ends when its weight gradients are final
+                lo = st.offsets[next_first_key][0] if next_first_key else 0
+                self.bwd_segments.append((Bk, lo, seg_state["hi"] - lo))
+                seg_state["hi"] = lo
+                Bk = Launcher()
+            else:
+                sub = Launcher()
+                wgb.launch(sub)
+                Bk.fork(sub, what="wgrad chunk")
             batches.append(WgradBatch(self.dt, 3, 1, wgrad_atomic))
 
         Ho, Wo = self.Ho, self.Wo
@@ -757,7 +777,8 @@ class GeneratorPlan:
                 a5, b5 = 0.2, 1.0
             fused_bwd = self.fused_rdb and os.environ.get("SSR_FUSED_RDB_BWD", "1") != "0"
             if n_chunks > 1 and (r + 1) in cuts:      # everything recorded so far reads buffers of blocks > r: final by now
-                close_batch()
+                ir, jr = divmod(r + 1, 3)
+                close_batch(f"body.{ir}.rdb{jr + 1}.conv1.weight")   # first parameter (arena order) of the blocks finished so far
             store.add_rdb_gather(p, nf, gc, a5, ck0=16 if fused_bwd else 0)
             add_wg(f"{p}.conv5", view(cur, 0), d_out_r, H, W, 1, H, W, alpha=a5, cin=cd)
             for k in (4, 3, 2, 1):
@@ -797,13 +818,21 @@ class GeneratorPlan:
                      cin_dy=nf)
         if n_chunks > 1:
             close_batch()
-            Bk.join()
+            if n_seg == 1:
+                Bk.join()
             batches.pop()
         else:
             batches[0].finalize()
             batches[0].launch(Bk)
         self._wg_batches = batches
-        self.bwd = Bk
+        if n_seg > 1:          # the whole backward = the segments in order (eager / instrumented runs; the step runs them one by one)
+            whole = Launcher()
+            for L, _, _ in self.bwd_segments:
+                whole.calls.extend(L.calls)
+            self.bwd = whole
+            assert sum(n for _, _, n in self.bwd_segments) == st.numel and self.bwd_segments[-1][1] == 0
+        else:
+            self.bwd = Bk
 
     # ---- boundary: NCHW fp32 tensors of the reference API ----
     def load_input(self, x_nchw: torch.Tensor, scale: float = 1.0):

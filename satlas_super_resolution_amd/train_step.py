@@ -130,8 +130,11 @@ class ESRGANTrainStep:
             self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
                                                     parts=n_split, **g_kwargs)
         else:
+            # data parallel: G's backward in segments, so that a segment's slice of the gradient arena is on the wire while the next
+            # segment computes (step(): one all-reduce per segment).  SSR_DP_SEGMENTS=1: one exchange behind the whole backward.
+            n_seg = max(1, int(os.environ.get("SSR_DP_SEGMENTS", "3"))) if (dp is not None and dp.active) else 1
             self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
-                                               **g_kwargs)
+                                               bwd_segments=n_seg, **g_kwargs)
         self.p_plan = None
         if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
             from .perceptual import PerceptualPlan
@@ -372,13 +375,20 @@ class ESRGANTrainStep:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._run("d", self._phase_d)
-                hd = self.dp.all_reduce_async(self.d_store.grad)
-            self._run("g_bwd", self.g_plan.bwd.run)
-            hg = self.dp.all_reduce_async(self.g_store.grad)
+            # G's backward, segment by segment: the exchange of segment k (the last layers first) runs on the comm stream while
+            # segment k+1 computes; D's single exchange is ISSUED after them (the comm stream executes in issue order and must
+            # not hold G's early slices behind the end of the D phases).  Same issue order on every rank.
+            segs = getattr(self.g_plan, "bwd_segments", None) or [(self.g_plan.bwd, 0, self.g_store.numel)]
+            hgs = []
+            for k, (L, off, n) in enumerate(segs):
+                self._run(f"g_bwd{k}" if len(segs) > 1 else "g_bwd", L.run)
+                hgs.append(self.dp.all_reduce_async(self.g_store.grad[off:off + n]))
             with torch.cuda.stream(side):
+                hd = self.dp.all_reduce_async(self.d_store.grad)
                 self.dp.wait(hd)
                 self._run("opt_d", self._phase_opt_d)
-            self.dp.wait(hg)
+            for hg in hgs:
+                self.dp.wait(hg)
             self._run("opt_g", self._phase_opt_g)
             cur.wait_stream(side)
         elif self.dp.active:

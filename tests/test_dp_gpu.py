@@ -157,7 +157,8 @@ def _rccl_worker(port, outdir):
                 logs.append(dict(ts.log()))
         torch.cuda.synchronize()
         if dp.active:
-            assert set(ts._graphs) == {"g_pre", "g_bwd", "d", "opt_g", "opt_d"}, set(ts._graphs)
+            assert set(ts._graphs) == {"g_pre", "g_bwd0", "g_bwd1", "g_bwd2", "d", "opt_g", "opt_d"}, set(ts._graphs)   # G's backward in 3 segments, one exchange each
+            assert sum(n for _, _, n in ts.g_plan.bwd_segments) == ts.g_store.numel
         res[name] = (logs, ts.g_store.data.cpu().clone(), ts.d_store.data.cpu().clone(), ts.opt_g.ema.cpu().clone())
     torch.save(res, os.path.join(outdir, "rccl.pt"))
     torch.distributed.destroy_process_group()

@@ -214,7 +214,15 @@ def cpu_baseline(args, c_in, c_d):
                     break
     except OSError:
         pass
-    return {"value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": ncores, "kind": "port",
+    ref = None
+    rp = os.path.join(ROOT, "profiles", "cpu_reference_step.json")
+    if os.path.exists(rp):       # the UNMODIFIED reference classes + optimize_parameters, timed where the reference exists (the build
+        try:                     # container; oracle/time_reference_cpu.py) — quoted beside the port, never mixed into `value`
+            ref = json.load(open(rp))
+        except (OSError, ValueError):
+            ref = None
+    return {"reference_in_build_container": ref,
+            "value": B / t, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": ncores, "kind": "port",
             "sample": f"{n_steps} timed G+D steps (median) at batch {B}, fp32, same architecture/shapes, "
                       f"after 1 warm-up, torch.set_num_threads({torch.get_num_threads()}) of {ncores} host cores; host CPU: {cpu}; "
                       f"oracle/esrgan_oracle.py (PyTorch CPU restatement; the reference itself is not on this box)"}

@@ -142,61 +142,6 @@ class ParamStore:
             self.sn_max_elems = max(self.specs[n].cout * self.specs[n].cin * self.specs[n].k ** 2
                                     for n in self.sn_names)
 
-    # ---- weight contexts: further sets of packed weights with their own sigma (and a snapshot of u, v) ----
-    def add_context(self) -> int:
-        """Context k >= 1 of a spectral-normalised store: its own packed forward / dgrad weights, its own sigma and a snapshot
-        of (u, v) as they were right after ITS power iteration.  The power iteration depends on the weights only, not on any
-        activation, so the three iterations of a train step (generator-phase forward, real phase, fake phase:
-        ssr_esrgan_model.py:181,217,224) can all be advanced up front — u, v evolve in place in that order — each leaving its
-        sigma / packed W/sigma / (u, v) in its own context; the phases that use them are then free to run in any order or
-        concurrently.  Context 0 is the store's own set."""
-        assert self.sn_names, "contexts exist for spectral-normalised stores"
-        if not hasattr(self, "ctx"):
-            self.ctx = [dict(packed_fwd=self.packed_fwd, packed_dgrad=self.packed_dgrad, sigma=self.sigma, u=self.u, v=self.v,
-                             pack_table=None, sn_table=None, sn_bwd_table=None)]
-        sigma = torch.ones_like(self.sigma)
-        pf = {n: torch.zeros_like(t) for n, t in self.packed_fwd.items()}
-        pd = {n: torch.zeros_like(t) for n, t in self.packed_dgrad.items()}
-        u = {n: torch.zeros_like(t) for n, t in self.u.items()}
-        v = {n: torch.zeros_like(t) for n, t in self.v.items()}
-        items, sn_items, bwd_items = [], [], []
-        names = list(self.specs)
-        assert len(self._pack_items) == len(names), "contexts are created before any extra packing is registered"
-        for it, n in zip(self._pack_items, names):
-            s = self.specs[n]
-            inv = (sigma.data_ptr() + 4 * self.sn_names.index(n)) if s.sn else None
-            items.append(PackItem(it.src, inv, pf[n].data_ptr(), pd[n].data_ptr() if s.dgrad_packed else None, it.Cout, it.Cin, it.KH,
-                                  it.KW, it.stride, it.CoutPad, it.CinPad, it.CinPadO, it.CoutPadI, it.ck_fwd, it.ck_dgrad, it.fwd_s2d))
-        for j, n in enumerate(self.sn_names):
-            s = self.specs[n]
-            woff, _ = self.offsets[n + ".weight_orig"]
-            rows, cols = s.cout, s.cin * s.k * s.k
-            sn_items.append(SNItem(self.data.data_ptr() + 4 * woff, self.u[n].data_ptr(), self.v[n].data_ptr(),      # live u, v
-                                   sigma.data_ptr() + 4 * j, self.sn_tmp[j].data_ptr(), rows, cols))
-            bwd_items.append(SNBwdItem(self.grad_sn.data_ptr() + 4 * woff, self.data.data_ptr() + 4 * woff, u[n].data_ptr(),
-                                       v[n].data_ptr(), sigma.data_ptr() + 4 * j, self.grad.data_ptr() + 4 * woff,
-                                       self.sn_dot[j].data_ptr(), rows, cols))
-        self.ctx.append(dict(packed_fwd=pf, packed_dgrad=pd, sigma=sigma, u=u, v=v, pack_table=hip.device_table(items),
-                             n_pack=len(items), sn_table=hip.device_table(sn_items), sn_bwd_table=hip.device_table(bwd_items)))
-        return len(self.ctx) - 1
-
-    def advance_context(self, k: int):
-        """One train-mode power iteration (u, v in place) -> sigma_k, packed W / sigma_k, snapshot of (u, v) for the backward."""
-        c = self.ctx[k]
-        L = hip.lib()
-        hip.check(L.ssr_spectral_norm(c["sn_table"].data_ptr(), len(self.sn_names), self.sn_max_rows, self.sn_max_cols, 1,
-                                      hip.stream_ptr()), "ssr_spectral_norm")
-        hip.check(L.ssr_pack_weights(c["pack_table"].data_ptr(), c["n_pack"], self.dtype, hip.stream_ptr()), "ssr_pack_weights")
-        dst = [c["u"][n] for n in self.sn_names] + [c["v"][n] for n in self.sn_names]
-        src = [self.u[n] for n in self.sn_names] + [self.v[n] for n in self.sn_names]
-        torch._foreach_copy_(dst, src)          # one multi-tensor launch instead of 16 small copies
-
-    def spectral_norm_backward_context(self, k: int):
-        self.sn_dot.zero_()
-        hip.check(hip.lib().ssr_spectral_norm_bwd(self.ctx[k]["sn_bwd_table"].data_ptr(), len(self.sn_names), self.sn_max_elems,
-                                                  hip.stream_ptr()), "ssr_spectral_norm_bwd")
-        self.grad_sn.zero_()
-
     # ---- tensor views in the reference layout ----
     def tensor(self, key: str, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
         off, shape = self.offsets[key]
@@ -368,12 +313,10 @@ class Launcher:
 class _ConvBuilder:
     """Fills ssr_conv_desc records; keeps them alive."""
 
-    def __init__(self, store: ParamStore, N: int, ctx: int = 0):
+    def __init__(self, store: ParamStore, N: int):
         self.store, self.N, self.dt = store, N, store.dtype
         self.keep = []
-        c = store.ctx[ctx] if ctx else None          # which set of packed weights the descriptors point at
-        self.packed_fwd = c["packed_fwd"] if c else store.packed_fwd
-        self.packed_dgrad = c["packed_dgrad"] if c else store.packed_dgrad
+        self.packed_fwd, self.packed_dgrad = store.packed_fwd, store.packed_dgrad
 
     def conv(self, L: Launcher, name: str, x: View, hi: int, wi: int, y: View, *, up=1, act=hip.ACT_NONE, alpha=1.0,
              y0: View = hip.NULL_VIEW, r1: View = hip.NULL_VIEW, r1_nc=0, beta1=0.0, r2: View = hip.NULL_VIEW,
@@ -955,7 +898,6 @@ class DiscriminatorPlan:
         self.o7, self.o8 = z(B, H, W, nf), z(B, H, W, nf)
         self.logits = z(B, H, W, 8)
         self._cb = _ConvBuilder(store, B)
-        self._cbs = {0: self._cb}
         self._fwd_cache: Dict[Tuple[int, int], Launcher] = {}
         self._bwd_cache: Dict[Tuple, Launcher] = {}
         self.training = training
@@ -971,17 +913,12 @@ class DiscriminatorPlan:
             self.g3, self.g2, self.g1, self.g0 = z(B, H8, W8, 8 * nf), z(B, H4, W4, 4 * nf), z(B, H2, W2, 2 * nf), z(B, H, W, nf)
             self.g_in = z(B, H, W, self.cdp)
 
-    def _builder(self, ctx: int) -> "_ConvBuilder":
-        if ctx not in self._cbs:
-            self._cbs[ctx] = _ConvBuilder(self.store, self.B, ctx)
-        return self._cbs[ctx]
-
-    def forward_plan(self, x_buf: torch.Tensor, ctx: int = 0) -> Launcher:
-        key = (x_buf.data_ptr(), ctx)
+    def forward_plan(self, x_buf: torch.Tensor) -> Launcher:
+        key = x_buf.data_ptr()
         if key in self._fwd_cache:
             return self._fwd_cache[key]
         assert tuple(x_buf.shape) == (self.B, self.H, self.W, self.cdp), (x_buf.shape, self.cdp)
-        cb, nf, B, H, W, dt = self._builder(ctx), self.nf, self.B, self.H, self.W, self.dt
+        cb, nf, B, H, W, dt = self._cb, self.nf, self.B, self.H, self.W, self.dt
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         L = Launcher()
         lib = hip.lib()
@@ -1011,13 +948,13 @@ class DiscriminatorPlan:
         return L
 
     def backward_plan(self, x_buf: torch.Tensor, param_grads: bool, input_grad: bool,
-                      in_residual: Optional[torch.Tensor] = None, ctx: int = 0) -> Launcher:
+                      in_residual: Optional[torch.Tensor] = None) -> Launcher:
         """Backward from self.d_logits.  param_grads=False reproduces the generator phase where D's
         parameters are frozen (ssr_esrgan_model.py:136-137): dgrad only."""
-        key = (x_buf.data_ptr(), param_grads, 1 if input_grad else 0, 0 if in_residual is None else in_residual.data_ptr(), ctx)
+        key = (x_buf.data_ptr(), param_grads, 1 if input_grad else 0, 0 if in_residual is None else in_residual.data_ptr())
         if key in self._bwd_cache:
             return self._bwd_cache[key]
-        cb, st, nf, B, H, W, dt = self._builder(ctx), self.store, self.nf, self.B, self.H, self.W, self.dt
+        cb, st, nf, B, H, W, dt = self._cb, self.store, self.nf, self.B, self.H, self.W, self.dt
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         lib = hip.lib()
         L = Launcher()

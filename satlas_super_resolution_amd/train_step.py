@@ -150,14 +150,6 @@ class ESRGANTrainStep:
         # r02c, same box, B=32 8xS2 bf16: 13.94 -> 13.27 ms per step with the fork (two pairs, +-0.02)
         self.overlap_d = os.environ.get("SSR_OVERLAP_D", "1") == "1"
         self.dp_fork = os.environ.get("SSR_DP_FORK", "1") == "1"
-        # the real-phase discriminator pass ahead of its place in the reference's order, beside G's forward (see _step_d_ahead)
-        # (r02k, same box: 13.25 -> 13.15 ms at B = 32, 7.31 -> 7.45 ms at B = 16: the two forward chains mostly take CUs from
-        # each other; correct — the golden / oracle step tests pass with it — and left off)
-        self.d_ahead = os.environ.get("SSR_D_AHEAD", "0") == "1" and self.overlap_d and not self.dp.active
-        if self.d_ahead:
-            self.ctx_real, self.ctx_fake = self.d_store.add_context(), self.d_store.add_context()
-            self.d_plan_real = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd, num_feat=d_kwargs.get("num_feat", 64),
-                                                        skip_connection=d_kwargs.get("skip_connection", True))
         self.iter = 0
 
     # ------------------------------------------------------------------ state
@@ -249,59 +241,6 @@ class ESRGANTrainStep:
                                   in_residual=self.grad_l1).run()          # :192, D frozen (:136-137)
         if run_bwd:
             self.g_plan.bwd.run()
-
-    def _step_d_ahead(self):
-        """The whole step with the discriminator's REAL phase (:217-221) running beside the generator's forward.
-
-        Nothing in the real phase depends on this iteration's generator: it reads the ground truth and D's parameters.  What
-        ties it to its place in the reference's order is the hook-style spectral norm, whose power iteration advances u, v once per
-        forward — generator-phase forward, real, fake — but that iteration depends on the WEIGHTS only.  So the three iterations
-        are advanced up front, in that order, each leaving sigma / packed W/sigma / (u, v) in its own context
-        (engine.ParamStore.add_context); every forward then uses exactly the weights it would have seen, and the real phase (own
-        activation buffers) starts at once on the side stream, the fake phase follows there as soon as D's input gradient has been
-        handed to the generator, beside G's backward.  Gradients accumulate real-then-fake as in the reference."""
-        cfg, ds = self.cfg, self.d_store
-        self.g_store.grad.zero_()
-        ds.grad.zero_()
-        ds.grad_sn.zero_()
-        self.losses.zero_()
-        ds.spectral_norm(power_iter=True)          # iteration 1 -> context 0 (generator-phase forward, D frozen)
-        ds.pack()
-        ds.advance_context(self.ctx_real)          # iteration 2
-        ds.advance_context(self.ctx_fake)          # iteration 3: u, v now hold what the reference holds after the step
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        side = self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            pr = self.d_plan_real
-            pr.forward_plan(self.real_in, self.ctx_real).run()                                   # :217
-            self._bce(cfg.real_label, 1.0, 2, 3, plan=pr)                                        # :218-220
-            pr.backward_plan(self.real_in, param_grads=True, input_grad=False, ctx=self.ctx_real).run()   # :221
-            ds.spectral_norm_backward_context(self.ctx_real)
-        self.g_store.pack()
-        self.g_plan.fwd.run()                                                                    # :140
-        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.dt,
-                                        self.B * self.H * self.W, self.cout, cfg.l1_weight, self.losses.data_ptr(),
-                                        hip.stream_ptr()), "ssr_l1_loss")
-        if self.p_plan is not None:
-            self.p_plan.fwd_target.run()
-            self.p_plan.fwd.run()
-            self.p_plan.bwd.run()
-        self.d_plan.forward_plan(self.fake_in).run()                                             # :181 (context 0)
-        self._bce(cfg.real_label, cfg.gan_weight, 1, None)
-        self.d_plan.backward_plan(self.fake_in, param_grads=False, input_grad=True, in_residual=self.grad_l1).run()   # :192
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            self.d_plan.forward_plan(self.fake_in, self.ctx_fake).run()                          # :224
-            self._bce(cfg.fake_label, 1.0, 4, 5)
-            self.d_plan.backward_plan(self.fake_in, param_grads=True, input_grad=False, ctx=self.ctx_fake).run()   # :227
-            ds.spectral_norm_backward_context(self.ctx_fake)
-            self._phase_opt_d()                                                                  # :228
-        self.g_plan.bwd.run()
-        self._phase_opt_g()                                                                      # :193, :230-231
-        cur.wait_stream(side)
 
     def _phase_g_skipped(self):
         """current_iter fails the gate at :144: only the forward runs (self.output is still needed)."""
@@ -409,8 +348,6 @@ class ESRGANTrainStep:
             self._run("opt_d", self._phase_opt_d)
         else:
             def whole():
-                if self.d_ahead:
-                    return self._step_d_ahead()
                 if not self.overlap_d:
                     self._phase_g()
                     self._phase_opt_g()

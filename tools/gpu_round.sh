@@ -21,3 +21,9 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
       --kernel-trace --output-format csv -d /tmp/pmc_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmc_$TAG.log 2>&1)
   python tools/pmc_sq.py /tmp/pmc_$TAG $O/${TAG}_pmc_sq.json || tail -20 /tmp/pmc_$TAG.log
 fi
+if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then
+  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcf_$TAG.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcw_$TAG.log 2>&1)
+  python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic.json > /dev/null && python -c "
+import json; d=json.load(open('$O/${TAG}_traffic.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
+fi

@@ -176,6 +176,10 @@ typedef struct ssr_wgrad_layer {
 
 typedef struct ssr_wgrad_item {
     int32_t layer, co0, ci0, tile_begin, tile_end, atomic;
+    /* second 32-channel block of output gradients contracted with the SAME input patch (kernels with
+     * ssr_wgrad_co_tile() == 64 only): nco == 2 -> channels co0_b.. of layer_b, which must read the same x view, ci0 and
+     * geometry as `layer` (it may be `layer` itself: the other half of a 64-output conv).  nco == 0 or 1: single. */
+    int32_t nco, layer_b, co0_b;
 } ssr_wgrad_item;
 
 int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
@@ -184,6 +188,8 @@ int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* it
 int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH);
 /* input-channel width of a work item (ci0 must be a multiple of it; co0 a multiple of 32) for that kernel */
 int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH);
+/* 64 when that kernel takes paired items (nco == 2), else 32 */
+int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH);
 
 /*
  * Weight packing (once per optimizer step; replaces cuDNN's internal filter transforms).

@@ -711,9 +711,14 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         // (by (row >> 3) & 1); the row phase of a piece is a multiple of 16 rows, so the pattern is the same for every piece
         const int lo14 = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
         const int lo5 = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+        int dlo = lo5 - lo14;
+        rt_pin(dlo);
         auto load_from = [&](unsigned long long src64, u32x4 (&r)[6]) {
             rt_gptr src = (rt_gptr)(src64 & ~1ull);
-            const int lo = (src64 & 1ull) ? lo5 : lo14;                        // bit 0 of a table entry: conv5 layout
+            // bit 0 of a table entry: conv5 layout.  Arithmetic, not `bit ? lo5 : lo14`: hipcc turned that select into a table
+            // of two stack addresses — a scratch load, a flat load and s_waitcnt vmcnt(0) lgkmcnt(0) in front of EVERY slab's
+            // loads, i.e. no slab load in flight while the next was issued
+            const int lo = lo14 + (int)(src64 & 1ull) * dlo;
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
         };

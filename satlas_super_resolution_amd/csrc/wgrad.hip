@@ -158,6 +158,7 @@ extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dt
 
 // width of the input-channel tile of one work item (host helper for building items)
 extern "C" int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH) { return (dtype == SSR_BF16 && KH == 3) ? 64 : 32; }
+extern "C" int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH) { return (dtype == SSR_BF16 && KH == 3) ? 64 : 32; }
 
 extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
                                 int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream) {

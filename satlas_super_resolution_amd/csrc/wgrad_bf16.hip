@@ -322,53 +322,91 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 3x3 stride 1: 32 co x 64 ci per workgroup, the 18 (tap, 32-channel half) units dealt to the four MFMA waves.
-// Why (tools/wgrad_probe.hip): with 32 x 32 tiles the loaders had to deliver a 37 KB tile per 1280 MFMA cycles and got
+// 3x3 stride 1: (32 or 64) co x 64 ci per workgroup, the 18 (tap, 32-channel half) units dealt to the four MFMA waves.
+// Why 64 ci (tools/wgrad_probe.hip): with 32 x 32 tiles the loaders had to deliver a 37 KB tile per 1280 MFMA cycles and got
 // 16.8 B/clk — they fetch 64-byte slices of 384-byte NHWC pixels (half of every 128-byte line is wasted) — so the
-// MFMA waves idled half the time.  A 64-channel X patch is whole lines, the dY tile is shared by twice the MFMAs
-// (22 B/clk needed), every wave sees ALL pixels of the tile for its 4..5 units (80 accumulator registers, no cross-wave
-// reduction at the end), and the X patch sits in LDS as two dense 64-byte-row planes (conflict-free transpose reads).
+// MFMA waves idled half the time.  A 64-channel X patch is whole lines, every wave sees ALL pixels of the tile for its
+// 4..5 units (no cross-wave reduction at the end), and the X patch sits in LDS as two dense 64-byte-row planes.
+// Why 64 co (round 3, tools/wgrad_body_probe.hip): at 32 co the kernel ran at ~4400 cycles per tile with EITHER the global
+// loads or 4/5 of the MFMAs removed (3980 / 3940): the bound is the LDS pipe — a wave reads 1 dY + 5 X fragments (1 KB each,
+// 8 LDS cycles as two ds_read_b64_tr_b16) for 5 MFMAs, 4 x 48 = 192 LDS cycles per k-step against 160 MFMA cycles.  With a
+// SECOND 32-channel dY plane every X fragment feeds two MFMAs: 2 + 5 reads for 10 MFMAs, 208 LDS cycles against 320.  The two
+// planes may belong to different layers that read the same input (a dense block's conv1..conv4 share x and write dpre1..4;
+// conv5's 64 outputs are the two halves of one layer): the host pairs items (engine.WgradBatch.finalize).
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef WG3_PF
+#define WG3_PF 6      // operand fragments read ahead of their MFMAs
+#endif
 struct Wg3 {
     static constexpr int TH = 16, PH = 18, PW = 18, ROW = 32;
-    static constexpr int NDYV = TH * WG_TW * 4;              // 1024 vectors: dY tile [256 px][32 co]
+    static constexpr int DYPLANE = TH * WG_TW * 64;          // bytes of one dY plane [256 px][32 co]
+    static constexpr int NDYV = TH * WG_TW * 8;              // 2048 vectors: two planes
     static constexpr int NXV = PH * PW * 8;                  // 2592 vectors: X patch [324 px][64 ci]
-    static constexpr int NLV = (NDYV + NXV + 255) / 256;     // 15 per loader thread
+    static constexpr int NLV = (NDYV + NXV + 255) / 256;     // 19 per loader thread
     static constexpr int XPLANE = PH * PW * 64;              // bytes of one 32-channel plane
-    static constexpr int STAGE = NDYV * 16 + 2 * XPLANE;     // 57,856 B
+    static constexpr int STAGE = 2 * DYPLANE + 2 * XPLANE;   // 74,240 B
     static constexpr int NST = 2;
     static constexpr int CTL = NST * STAGE;
-    static constexpr int LDS = CTL + 256;
+    static constexpr int LDS = CTL + 512;
     static_assert(LDS <= 160 * 1024 && 32 * 64 * 9 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
 };
+constexpr int W3C_BIAS = 16;
+typedef const __attribute__((address_space(1))) char* wg_gptr;          // global memory, explicitly: never a flat access
+typedef const __attribute__((address_space(1))) u32x4* wg_gvec;
+__device__ const u32x4 g_wg_zero16 = {0u, 0u, 0u, 0u};                  // where the loads of lanes outside the image go
+    // [64] floats: bias-gradient partial sums of the loader threads, both planes
 
-template <int NU>
-__device__ __forceinline__ void wg3_contract(f32x16 (&acc)[5], const __bf16* ldy, const int (&uoff)[5], int src_px, int src_ch,
-                                             int* done_word, int k, int lane) {
-    constexpr int NOP = Wg3::TH * (1 + NU), PF = 8;
+// One wave's share of a tile: NR tile rows (k-steps of 16 pixels), ONE dY plane, ONE 32-channel half of the X patch, all nine
+// taps.  The X fragment of patch row r and column shift kx serves three k-steps (tile row r with ky = 0, r - 1 with ky = 1,
+// r - 2 with ky = 2), so the wave keeps a rolling window of three patch rows in registers and reads per k-step only the
+// new row (3 fragments) and the dY fragment: 4 reads for 9 MFMAs.  (Units dealt by (tap, half) with all rows per wave needed
+// 7 reads for 9-10 MFMAs and the LDS pipe — 128 B/clk for ds_read_b64_tr_b16 — was as busy as the MFMA pipe: 6600 cycles
+// per 36-product tile for 4600 of MFMAs; tools/wgrad_body_probe.hip.)
+//   lap: this lane's source address in the wave's dY plane at its first row; lbp: same in its X half plane.
+template <int NR>
+__device__ __forceinline__ void wg3_rows(f32x16 (&acc)[9], const __bf16* lap, const __bf16* lbp, int* done_word, int k, int lane) {
+    constexpr int ROW = Wg3::ROW, PW = Wg3::PW;
+    constexpr int NOP = 6 + 4 * NR, PF = WG3_PF;              // read stream: patch rows 0, 1; then per k-step dY, patch row i + 2
+    static_assert(NOP - 1 - PF >= 0, "prefetch distance");
     bf16x8 op[NOP];
-    const __bf16* lxb = ldy + Wg3::NDYV * 8;                  // X planes behind the dY tile
     auto issue = [&](auto nc) {
-        constexpr int n = decltype(nc)::value, s = n / (1 + NU), r = n % (1 + NU);
-        if constexpr (r == 0) {
-            const __bf16* ap = ldy + (s * WG_TW + src_px) * Wg3::ROW + src_ch;
-            op[n] = tr_pair(ap, ap + 4 * Wg3::ROW);
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 6) {
+            const __bf16* bp = lbp + ((n / 3) * PW + n % 3) * ROW;
+            op[n] = tr_pair(bp, bp + 4 * ROW);
+        } else if constexpr ((n - 6) % 4 == 0) {
+            const __bf16* ap = lap + ((n - 6) / 4) * WG_TW * ROW;
+            op[n] = tr_pair(ap, ap + 4 * ROW);
         } else {
-            const __bf16* bp = lxb + uoff[r - 1] + (s * Wg3::PW + src_px) * Wg3::ROW + src_ch;
-            op[n] = tr_pair(bp, bp + 4 * Wg3::ROW);
+            const __bf16* bp = lbp + (((n - 6) / 4 + 2) * PW + (n - 6) % 4 - 1) * ROW;
+            op[n] = tr_pair(bp, bp + 4 * ROW);
         }
     };
     static_for<0, PF>([&](auto nc) { issue(nc); });
     static_for<0, NOP>([&](auto nc) {
-        constexpr int n = decltype(nc)::value, s = n / (1 + NU), r = n % (1 + NU);
+        constexpr int n = decltype(nc)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
         if constexpr (n + PF == NOP - 1) {
             if (lane == 0) __atomic_store_n(done_word, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (r != 0)
-            acc[r - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[s * (1 + NU)], op[n], acc[r - 1], 0, 0, 0);
+        if constexpr (n >= 6) {
+            constexpr int i = (n - 6) / 4, r = (n - 6) % 4, a = 6 + 4 * i;
+            // r = 0: dY(i) has arrived -> ky = 0 (patch row i); r = 1: ky = 1; r = 3: the new patch row is complete -> ky = 2
+            constexpr int ky = r == 3 ? 2 : r;
+            if constexpr (r != 2) {
+                constexpr int prow = i + ky;                   // patch row relative to the wave's first
+                static_for<0, 3>([&](auto kc) {
+                    constexpr int kx = decltype(kc)::value;
+                    constexpr int bi = prow < 2 ? prow * 3 + kx : 6 + 4 * (prow - 2) + 1 + kx;
+#ifdef WG_X_NOMFMA
+                    if constexpr (kx == 0 && ky == 0)
+#endif
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[bi], acc[ky * 3 + kx], 0, 0, 0);
+                });
+            }
+        }
     });
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -380,11 +418,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* ctl = reinterpret_cast<int*>(smem + C::CTL);
     const ssr_wgrad_item it = items[blockIdx.x];
+    const bool pair = it.nco == 2;
     const ssr_wgrad_layer L = layers[it.layer];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ssr_wgrad_layer LB = layers[pair ? it.layer_b : it.layer];   // layer of the second dY plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar unit tables
     const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
     const int ntile = it.tile_end - it.tile_begin;
-    if (tid < 64) ctl[tid] = 0;
+    if (tid < 128) ctl[tid] = 0;
     GPROBE(0);
     __syncthreads();   // the only barrier
 
@@ -394,53 +434,84 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
         const int upshift = L.up == 2 ? 1 : 0;
         const int LH = L.Hi << upshift, LW = L.Wi << upshift;
         const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(L.x.p);
-        const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(L.dy.p);
-        constexpr int QDY = C::NDYV / 256;                     // vector q of a thread is a dY vector iff q < QDY
-        int rel[C::NLV], yx[C::NLV], lo[C::NLV];               // global offset rel. to the tile origin, (y, x), LDS offset
+        // the dY vectors of a thread: vector v = lt + 256 q (q < QDY) is pixel v >> 3, part v & 7 = lt & 7 — always the same
+        // plane (part >> 2) and channel octet (part & 3)
+        constexpr int QDY = C::NDYV / 256;
+        const int hb = (lt >> 2) & 1, oct = lt & 3;
+        const ssr_view dyv = hb ? LB.dy : L.dy;
+        const int dy_co0 = hb ? it.co0_b : it.co0;
+        const bool dy_ok = (hb == 0 || pair) && dy_co0 + oct * 8 < (hb ? LB.Cout : L.Cout);
+        const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(dyv.p) + dyv.coff + dy_co0;
+        // per vector only (y, x) relative to the tile origin is kept (yx; 0x7fff7fff = never inside): the global offset follows
+        // from it and the LDS offset is lo0 + q * 2048 (vector v = lt + 256 q: pixel (lt >> 3) + 32 q, part lt & 7).  Three
+        // tables of 19 registers next to 2 x 19 x 4 data registers spilled.
+        int yx[C::NLV];
 #pragma unroll
         for (int q = 0; q < C::NLV; ++q) {
             const int v = lt + q * 256;
             if (q < QDY) {
-                const int pix = v >> 2, part = v & 3;
-                const int y = pix >> 4, x = pix & 15;
-                rel[q] = (y * L.Gw + x) * L.dy.cs + part * 8;
-                yx[q] = (it.co0 + part * 8 < L.Cout) ? (y | (x << 16)) : 0x7fff7fff;   // never inside
-                lo[q] = v * 16;
+                const int pix = v >> 3;
+                yx[q] = dy_ok ? ((pix >> 4) | ((pix & 15) << 16)) : 0x7fff7fff;
             } else {
                 const int vx = v - C::NDYV;
                 const int pix = vx >> 3, part = vx & 7;        // 8 x 16 B = the 64 channels of one pixel: a whole line
                 const int py = pix / PW, px = pix - py * PW;
                 const int y = py - L.pad_y, x = px - L.pad_x;
-                rel[q] = ((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + part * 8;
                 yx[q] = (vx < C::NXV && it.ci0 + part * 8 < L.Cin) ? ((y & 0xffff) | (x << 16)) : 0x7fff7fff;
-                lo[q] = vx < C::NXV ? C::NDYV * 16 + (part >> 2) * C::XPLANE + pix * 64 + (part & 3) * 16 : -1;
             }
         }
-        const bool do_bias = L.db != nullptr && it.ci0 == 0;
+        const int lo_dy = hb * C::DYPLANE + (lt >> 3) * 64 + oct * 16;
+        const int lo_x = 2 * C::DYPLANE + ((lt >> 2) & 1) * C::XPLANE + (lt >> 3) * 64 + oct * 16;
+        const bool wr_dy = hb == 0 || pair;
+        const int x_c8 = (lt & 7) * 8;
+        const bool bias_a = L.db != nullptr && it.ci0 == 0, bias_b = pair && LB.db != nullptr && it.ci0 == 0;
+        const bool do_bias = hb ? bias_b : bias_a;
         float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 ra[C::NLV], rb[C::NLV];
+        // The loads are issued through inline asm and waited for by hand (wait_tile), every lane loads (outside the image: a
+        // zero block).  Left to the compiler — a branch around each load, flat loads (pointers that come out of the layer table
+        // are generic), and even plain global loads in a straight-line loop body — every store of a tile into LDS was preceded
+        // by s_waitcnt vmcnt(0): the loaders had NO load in flight while they stored and then waited a full memory latency,
+        // 4700 cycles per tile whatever its size (tools/wgrad_body_probe.hip: the same with 64 or 256 CUs busy; 2200 with the
+        // loads removed).  Now exactly one tile (NLV loads per lane) stays in flight across every store.
+        const wg_gptr zero16 = (wg_gptr)&g_wg_zero16;
+        const wg_gptr dyg1 = (wg_gptr)dyg, xg1 = (wg_gptr)xg;
         auto load_tile = [&](int k, u32x4 (&r)[C::NLV]) {
             int b = it.tile_begin + k;
             const int tx_i = b % tiles_x; b /= tiles_x;
             const int ty_i = b % tiles_y;
             const int n = b / tiles_y;
             const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
-            const __bf16* dyb = dyg + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs + L.dy.coff + it.co0;
-            const __bf16* xb = xg + ((size_t)(n * L.Hi + (gy0 >> upshift)) * L.Wi + (gx0 >> upshift)) * L.x.cs + L.x.coff + it.ci0;
+            const wg_gptr dyb = dyg1 + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * dyv.cs * 2;
+            const wg_gptr xb = xg1 + (((size_t)(n * L.Hi + (gy0 >> upshift)) * L.Wi + (gx0 >> upshift)) * L.x.cs + L.x.coff + it.ci0) * 2;
 #pragma unroll
             for (int q = 0; q < C::NLV; ++q) {
-                const int y = (int)(short)(yx[q] & 0xffff), x = yx[q] >> 16;
-                u32x4 val = {0u, 0u, 0u, 0u};
-                if (q < QDY) {
-                    if (gy0 + y < L.Gh && gx0 + x < L.Gw) val = *reinterpret_cast<const u32x4*>(dyb + rel[q]);
-                } else {
-                    if ((unsigned)(gy0 + y) < (unsigned)LH && (unsigned)(gx0 + x) < (unsigned)LW)
-                        val = *reinterpret_cast<const u32x4*>(xb + rel[q]);
-                }
-                r[q] = val;
+                int yxq = yx[q];
+                asm volatile("" : "+v"(yxq));                  // keeps the offsets below from being hoisted into 19 more registers (spills)
+                const int y = (int)(short)(yxq & 0xffff), x = yxq >> 16;
+                wg_gptr src;
+                if (q < QDY) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyb + ((y * L.Gw + x) * dyv.cs + oct * 8) * 2 : zero16;
+                else src = ((unsigned)(gy0 + y) < (unsigned)LH && (unsigned)(gx0 + x) < (unsigned)LW)
+                               ? xb + (((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + x_c8) * 2 : zero16;
+#ifndef WG_X_NOLOAD
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[q]) : "v"(src) : "memory");
+#else
+                r[q] = u32x4{(unsigned)(size_t)src, 0u, 0u, 0u};
+#endif
             }
         };
-        auto put = [&](int k, int st, const u32x4 (&r)[C::NLV]) {
+        // every load older than the newest NLV has landed; the registers pass through the asm so that no use can move above it
+        auto wait_tile = [&](u32x4 (&r)[C::NLV]) {
+            static_assert(C::NLV == 19, "operand lists below");
+#ifndef WG_X_NOLOAD
+            asm volatile("s_waitcnt vmcnt(19)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]),
+                         "+v"(r[7]), "+v"(r[8]), "+v"(r[9]) :: "memory");
+            asm volatile("" : "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]),
+                         "+v"(r[18]) :: "memory");
+#endif
+        };
+        auto put = [&](int k, int st, u32x4 (&r)[C::NLV]) {
+            wait_tile(r);
             if (k >= NST) {
                 for (;;) {
                     u32x4 dn;
@@ -450,8 +521,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
             }
             char* base = smem + st * C::STAGE;
 #pragma unroll
-            for (int q = 0; q < C::NLV; ++q)
-                if (lo[q] >= 0) *reinterpret_cast<u32x4*>(base + lo[q]) = r[q];
+            for (int q = 0; q < C::NLV; ++q) {
+                if (q < QDY) {
+                    if (wr_dy) *reinterpret_cast<u32x4*>(base + lo_dy + q * 2048) = r[q];
+                } else if (lt + (q - QDY) * 256 < C::NXV) {
+                    *reinterpret_cast<u32x4*>(base + lo_x + (q - QDY) * 2048) = r[q];
+                }
+            }
             if (do_bias) {
 #pragma unroll
                 for (int q = 0; q < QDY; ++q)
@@ -463,25 +539,42 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
             }
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WGC_READY + st))), "v"(1) : "memory");
         };
-        if (ntile > 0) load_tile(0, ra);
-        int st = 0;
-        for (int k = 0; k < ntile; k += 2) {
-            if (k + 1 < ntile) load_tile(k + 1, rb);
-            put(k, st, ra);
-            st ^= 1;
-            if (k + 2 < ntile) load_tile(k + 2, ra);
-            if (k + 1 < ntile) {
-                put(k + 1, st, rb);
-                st ^= 1;
-            }
+        // two tiles in flight, no branch around a load (past the end the last tile is loaded again and never stored)
+        const int last = ntile - 1;
+        if (ntile > 0) {
+            load_tile(0, ra);
+            load_tile(min(1, last), rb);
         }
-        if (do_bias) {
-            float* bl = reinterpret_cast<float*>(ctl + WGC_BIAS);
+        int k = 0;
+        for (; k + 1 < ntile; k += 2) {                        // even tiles -> stage 0 from ra, odd tiles -> stage 1 from rb
+            put(k, 0, ra);
+            load_tile(min(k + 2, last), ra);
+            put(k + 1, 1, rb);
+            load_tile(min(k + 3, last), rb);
+        }
+        if (k < ntile) put(k, 0, ra);
+        // the loads past the end: their registers stay allocated until they have landed
+        auto hold = [&](u32x4 (&r)[C::NLV]) {
+            asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
+            asm volatile("" : "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]));
+        };
+        hold(ra); hold(rb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        hold(ra); hold(rb);
+        if (bias_a || bias_b) {   // 32 threads share each channel octet of a plane: LDS float atomics, then one global atomic per channel
+            float* bl = reinterpret_cast<float*>(ctl + W3C_BIAS);
+            if (do_bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(bl + (lt & 3) * 8 + e, bacc[e]);
+                for (int e = 0; e < 8; ++e) atomicAdd(bl + hb * 32 + oct * 8 + e, bacc[e]);
+            }
             if (lane == 0) __atomic_fetch_add(ctl + WGC_LSYNC, 1, __ATOMIC_RELAXED);
             while (wg_ld(ctl + WGC_LSYNC) < 4) {}
-            if (lt < 32 && it.co0 + lt < L.Cout) atomicAdd(L.db + it.co0 + lt, L.alpha * bl[lt]);
+            if (lt < 64) {
+                const int h = lt >> 5, c = lt & 31;
+                const ssr_wgrad_layer& LC = h ? LB : L;
+                const int co = (h ? it.co0_b : it.co0) + c;
+                if ((h ? bias_b : bias_a) && co < LC.Cout) atomicAdd(LC.db + co, LC.alpha * bl[lt]);
+            }
         }
         return;
     }
@@ -491,66 +584,82 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
     const int t16 = lane & 15;
     const int src_px = 8 * g + (t16 >> 2);
     const int src_ch = 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
-    // units u = tap + 9 * half; wave w owns u = w, w + 4, ...; a tile with <= 32 valid input channels has no second half
-    const int nci = min(64, L.Cin_w - it.ci0);
-    const int nunit = nci > 32 ? 18 : 9;
-    int uoff[5], utap[5], usub[5];
-    int nu = 0;
+    // wave -> (dY plane p, 32-channel half h of the X patch, share q of nq of the tile's 16 rows): always nine taps = nine
+    // accumulators.  paired, 64 ci: (w & 1, w >> 1, all rows); paired, <= 32 ci: (w & 1, 0, rows halved); single, 64 ci:
+    // (0, w & 1, rows halved); single, <= 32 ci: (0, 0, rows quartered).  Row shares are summed in the write-out.
+    const int nci_a = min(64, L.Cin_w - it.ci0), nci_b = min(64, LB.Cin_w - it.ci0);
+    const bool full = max(nci_a, nci_b) > 32;
+    const int wp = pair ? (wave & 1) : 0;
+    const int wh = !full ? 0 : pair ? (wave >> 1) : (wave & 1);
+    const int nq = pair ? (full ? 1 : 2) : (full ? 2 : 4);
+    const int wq = nq == 1 ? 0 : nq == 2 ? (wave >> 1) : wave;
+    const int r0 = wq * (TH / nq);
+    const int la_off = wp * (C::DYPLANE / 2) + (r0 * WG_TW + src_px) * C::ROW + src_ch;                  // bf16 elements from the stage base
+    const int lb_off = C::DYPLANE + wh * (C::XPLANE / 2) + (r0 * PW + src_px) * C::ROW + src_ch;
+    f32x16 acc[9];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int u = wave + 4 * j;
-        const bool ok = u < nunit;
-        const int uu = ok ? u : wave;                          // harmless duplicate address for unused slots
-        utap[j] = uu % 9; usub[j] = uu / 9;
-        uoff[j] = usub[j] * (C::XPLANE / 2) + ((utap[j] / 3) * PW + utap[j] % 3) * C::ROW;   // bf16 elements
-        nu += ok ? 1 : 0;
-    }
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int st = 0, target = 4;
-    for (int k = 0; k < ntile; ++k) {
-        GPROBE_K(2);
-        while (wg_ld(ctl + WGC_READY + st) < target) {}
-        GPROBE_K(3);
-        const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+    // one tile loop per instance (with the instances inside ONE loop the register allocator spilled accumulators at every join)
+    auto run = [&](auto nrc) {
+        int st = 0, target = 4;
         int* dw_ = ctl + WGC_DONE + wave;
-        if (nu == 5) wg3_contract<5>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
-        else if (nu == 4) wg3_contract<4>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
-        else if (nu == 3) wg3_contract<3>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
-        else wg3_contract<2>(acc, ldy, uoff, src_px, src_ch, dw_, k, lane);
-        GPROBE_K(4);
-        if (st == 1) target += 4;
-        st ^= 1;
-    }
+        for (int k = 0; k < ntile; ++k) {
+            GPROBE_K(2);
+            while (wg_ld(ctl + WGC_READY + st) < target) {}
+            GPROBE_K(3);
+            const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+            wg3_rows<decltype(nrc)::value>(acc, ldy + la_off, ldy + lb_off, dw_, k, lane);
+            GPROBE_K(4);
+            if (st == 1) target += 4;
+            st ^= 1;
+        }
+    };
+    if (nq == 1) run(std::integral_constant<int, 16>{});
+    else if (nq == 2) run(std::integral_constant<int, 8>{});
+    else run(std::integral_constant<int, 4>{});
     GPROBE(7);
     // =============================== write-out ===============================
-    // every wave holds complete sums for its units: D[row = co][col = ci] -> LDS tile [co][64 ci][9 taps] (stride 9 floats
-    // between lanes: conflict-free) -> contiguous fp32 atomic adds (each co row of the tile is 64 * 9 consecutive floats)
+    // D[row = co][col = ci] of the nine taps -> LDS tile [32 co][64 ci][9 taps] (stride 9 floats between lanes: conflict-free),
+    // the row shares one after the other (the first stores, the others add) -> contiguous fp32 atomic adds (each co row of
+    // the tile is 64 * 9 consecutive floats); one dY plane after the other through the same 73.7 KB
     float* red = reinterpret_cast<float*>(smem);
     int phase = 0;
     wg_sync4(ctl + WGC_SYNC, phase, lane);   // all four waves are finished reading the ring
     const int i = lane & 31;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j < nu) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                red[(mfma32_row(r, g) * 64 + usub[j] * 32 + i) * 9 + utap[j]] = L.alpha * acc[j][r];
-        }
-    }
-    wg_sync4(ctl + WGC_SYNC, phase, lane);
-    float* __restrict__ dw = L.dw;
     constexpr int NOUT = 32 * 64 * 9;
+    static_for<0, 2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c == 0 || pair) {
+            const ssr_wgrad_layer& LC = c ? LB : L;
+            const int co0 = c ? it.co0_b : it.co0, nci = c ? nci_b : nci_a;
+            const float alpha = c ? LB.alpha : L.alpha;
+            for (int qq = 0; qq < nq; ++qq) {
+                if (wp == c && wq == qq) {
+                    float al = alpha;
+                    asm volatile("" : "+v"(al));               // the 144 products are not loop invariants to be kept (and spilled)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float* dst = red + (mfma32_row(r, g) * 64 + wh * 32 + i) * 9 + t;
+                            *dst = qq == 0 ? al * acc[t][r] : *dst + al * acc[t][r];
+                        }
+                }
+                wg_sync4(ctl + WGC_SYNC, phase, lane);
+            }
+            float* __restrict__ dw = LC.dw;
 #pragma unroll 8
-    for (int q = 0; q < NOUT / 256; ++q) {
-        const int e = tid + q * 256;
-        const int co = e / 576, rem = e - co * 576;
-        if (it.co0 + co < L.Cout && rem < nci * 9)
-            atomicAdd(dw + ((size_t)(it.co0 + co) * L.Cin_w + it.ci0) * 9 + rem, red[e]);
-    }
+            for (int q = 0; q < NOUT / 256; ++q) {
+                const int e = tid + q * 256;
+                const int co = e / 576, rem = e - co * 576;
+                if (co0 + co < LC.Cout && rem < nci * 9)
+                    atomicAdd(dw + ((size_t)(co0 + co) * LC.Cin_w + it.ci0) * 9 + rem, red[e]);
+            }
+            if (c == 0 && pair) wg_sync4(ctl + WGC_SYNC, phase, lane);   // the tile is read before the second plane overwrites it
+        }
+    });
     GPROBE(8);
 }
 

@@ -455,7 +455,99 @@ class WgradBatch:
                 for sp in range(splits):
                     b, e = sp * per, min(tiles, (sp + 1) * per)
                     if b < e:
-                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if (splits > 1 or self.force_atomic) else 0))
+                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if (splits > 1 or self.force_atomic) else 0, 1, li, co0))
+
+    def _weight(self, it):
+        """MFMA work of an item in (tile, 32-ci half, 32-co plane) units"""
+        L = self.layers[it.layer]
+        return (it.tile_end - it.tile_begin) * (2 if L.Cin_w - it.ci0 > 32 else 1) * max(1, it.nco)
+
+    # cycles per 16 x 16-pixel tile and per write-out of the bf16 3x3 kernel (tools/wgrad_body_probe.hip, MI355X): the loaders'
+    # fetch rate (~12.5 B/clk per CU) bounds both kinds of item, so a single costs 3/4 of a pair for at most half of its products
+    COST_TILE = {2: 5900, 1: 4300}
+    COST_WRITEOUT = 25000
+    N_CU = 256
+
+    def _cost(self, it):
+        nco = max(1, it.nco)
+        return (it.tile_end - it.tile_begin) * self.COST_TILE[nco] + nco * self.COST_WRITEOUT
+
+    def _makespan(self, items):
+        """workgroups are handed to the CUs in index order as CUs become free: list scheduling, longest first"""
+        import heapq
+        free = [0] * self.N_CU
+        for c in sorted((self._cost(it) for it in items), reverse=True):
+            heapq.heapreplace(free, free[0] + c)
+        return max(free)
+
+    def _balance(self, items):
+        """Pixel-range granularity of the items, chosen by simulating the launch: a generator launch is ~2.2 paired items per
+        CU, and whole items left 19 % of the CU time idle at the end (the singles, 3/4 of a pair each, are dealt last).  Finer
+        items cost a write-out each (fp32 atomics of the whole (co, ci) tile), so the cut is as coarse as the simulation allows."""
+        def cut(its, t_pair, t_single):
+            out = []
+            for it in its:
+                n, t = it.tile_end - it.tile_begin, (t_pair if it.nco == 2 else t_single)
+                parts = max(1, -(-n // t))
+                per = -(-n // parts)
+                for b in range(it.tile_begin, it.tile_end, per):
+                    out.append(WgradItem(it.layer, it.co0, it.ci0, b, min(it.tile_end, b + per), 1 if parts > 1 else it.atomic,
+                                         it.nco, it.layer_b, it.co0_b))
+            return out
+        best = None
+        for t_pair in (128, 64, 32):
+            for t_single in (128, 64, 32, 16):
+                cand = cut(items, t_pair, t_single)
+                m = self._makespan(cand)
+                if best is None or m < best[0] * 0.98:         # finer only if it buys 2 %
+                    best = (m, cand, t_pair, t_single)
+        self.balance_choice = best[2:] + (best[0], self._makespan(items))
+        return best[1]
+
+    def _pair(self, items):
+        """Two 32-channel blocks of output gradients that are contracted with the SAME input patch share one work item
+        (csrc/wgrad_bf16.hip, Wg3: every X fragment read from LDS then feeds two MFMAs).  Same x view, ci0, geometry, pixel
+        tiles and the same number of valid input channels; the blocks may belong to different layers — a dense block's
+        conv1..conv4 all read x and produce dpre1..dpre4 (rrdbnet_arch.py:37-41) — or be the halves of one 64-output conv."""
+        groups = {}
+        for it in items:
+            L = self.layers[it.layer]
+            key = (L.x.p, L.x.cs, L.x.coff, it.ci0, it.tile_begin, it.tile_end, L.N, L.Hi, L.Wi, L.up, L.Gh, L.Gw, L.pad_y, L.pad_x,
+                   min(64, L.Cin_w - it.ci0) > 32, min(64, L.Cin - it.ci0), it.atomic)
+            groups.setdefault(key, []).append(it)
+        out = []
+        for g in groups.values():
+            for a, b in zip(g[0::2], g[1::2]):
+                out.append(WgradItem(a.layer, a.co0, a.ci0, a.tile_begin, a.tile_end, a.atomic, 2, b.layer, b.co0))
+            if len(g) % 2:
+                out.append(g[-1])
+        return out
+
+    N_XCD = 8
+
+    def _xcd_order(self, items):
+        """Workgroup b runs on XCD b % 8 and every XCD has its own L2.  Items that read the same input buffer over the same
+        pixel tiles (a dense block: 14 (conv, co, ci) items over one 192-channel buffer and its gradient) are dealt to ONE
+        XCD, next to each other in its queue, so that they walk the tiles together and a line of x / dy is fetched once per
+        group instead of once per item (layer-major order spread the 14 over all eight L2s: 3.39 GB per launch for
+        ~0.6 GB of distinct lines, profiles/r03k_traffic.json)."""
+        weight = self._weight
+        groups = {}
+        for it in items:
+            groups.setdefault((self.layers[it.layer].x.p, it.tile_begin, it.tile_end), []).append(it)
+        queues, load = [[] for _ in range(self.N_XCD)], [0] * self.N_XCD
+        for g in sorted(groups.values(), key=lambda g: -sum(weight(i) for i in g)):      # heaviest group first, to the least loaded XCD
+            q = min(range(self.N_XCD), key=lambda j: (load[j], j))
+            queues[q] += sorted(g, key=lambda i: -weight(i))
+            load[q] += sum(weight(i) for i in g)
+        # block index = 8 * position + xcd has to be dense: level the queue lengths with items from the tails
+        while True:
+            lo, hi = min(queues, key=len), max(queues, key=len)
+            if len(hi) - len(lo) <= 1:
+                break
+            lo.append(hi.pop())
+        queues.sort(key=lambda q: -len(q))
+        return [q[j] for j in range(len(queues[0])) for q in queues if j < len(q)]
 
     def _twin(self, v: View, which: int) -> View:
         parent = hip.parent_of(v)
@@ -470,8 +562,12 @@ class WgradBatch:
     def finalize(self):
         if not self.layers:
             return
-        # heavy items first: better tail behaviour on 256 CUs
-        self.items.sort(key=lambda it: -(it.tile_end - it.tile_begin))
+        if hip.lib().ssr_wgrad_co_tile(self.kdt, self.k) == 64 and os.environ.get("SSR_WGRAD_PAIR", "1") == "1":
+            self.items = self._pair(self.items)
+            if os.environ.get("SSR_WGRAD_BALANCE", "0") == "1":
+                self.items = self._balance(self.items)
+        self.items = self._xcd_order(self.items) if os.environ.get("SSR_WGRAD_ORDER", "heavy") == "xcd" else \
+            sorted(self.items, key=lambda it: -self._cost(it))                    # longest items first
         self.item_tab = hip.device_table(self.items)
         if self.dtype != hip.F32X3:
             self.layer_tab = hip.device_table(self.layers)

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     const int tiles = N * (H / 16) * (W / 16);
     for (int r = 0; r < nrep; ++r) {
         L[r] = ssr_wgrad_layer{{x, CS, 0}, {dy, CS, 64}, N, H, W, 1, cin, cout, 1, 1, H, W, 1.f, dw + (size_t)r * cout * cin * 9, cin, nullptr};
-        for (int co = 0; co < cout; co += 32) for (int ci = 0; ci < cin; ci += 64) I.push_back({r, co, ci, 0, tiles, 0});
+        for (int co = 0; co < cout; co += 32) for (int ci = 0; ci < cin; ci += 64) I.push_back({r, co, ci, 0, tiles, 0, 1, 0, 0});
     }
     ssr_wgrad_layer* Ld; ssr_wgrad_item* Id;
     hipMalloc(&Ld, L.size() * sizeof(L[0])); hipMalloc(&Id, I.size() * sizeof(I[0]));

@@ -177,6 +177,36 @@ static void time_case(int N, int H, int W) {
     hipFree(b.cur); hipFree(b.out); hipFree(b.dout); hipFree(b.dcur); hipFree(b.r2);
 }
 
+// The step's launch sequence: NB dense blocks back to back, each with its OWN buffers; weights distinct per block (as in
+// the network: cold in L2 when the launch starts) or shared (hot after the first launch).  Forward only, 8 x 16 kernel.
+static void chain_case(int NB, int N) {
+    std::vector<Bufs> bs;
+    for (int k = 0; k < NB; ++k) bs.push_back(make(N, 32, 32));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    g_rdb_tile_override = 16;
+    const int cin[5] = {64, 96, 128, 160, 192}, cp[5] = {32, 32, 32, 32, 64};
+    for (int shared = 0; shared < 3; ++shared) {             // 2: distinct weights, each launch warms L2 for the next
+        std::vector<ssr_rdb_desc> ds;
+        for (int k = 0; k < NB; ++k) {
+            ssr_rdb_desc d = desc_fwd(bs[k], false);
+            if (shared == 1) for (int j = 0; j < 5; ++j) d.w[j] = bs[0].w[0][j];
+            if (shared == 2) for (int j = 0; j < 5; ++j) { d.w_next[j] = bs[(k + 1) % NB].w[0][j]; d.w_next_bytes[j] = cin[j] * 9 * cp[j] * 2; }
+            ds.push_back(d);
+        }
+        for (int k = 0; k < NB; ++k) ssr_rdb_forward(&ds[k], 0);
+        hipDeviceSynchronize();
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(e0);
+            for (int k = 0; k < NB; ++k) ssr_rdb_forward(&ds[k], 0);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        printf("  chain of %d blocks, N=%d, weights %s: %.2f us per launch\n", NB, N, shared == 1 ? "shared (hot)" : shared == 2 ? "distinct + w_next warm-up" : "distinct (cold)", best * 1000 / NB);
+    }
+}
+
 #ifdef SSR_PROBE
 // phase timing (s_memtime ticks of wave 0 / producer wave 4, averaged over the blocks of one launch) of the new kernel
 static void probe_case(int N, int tile, bool bwd) {
@@ -257,6 +287,7 @@ int main(int argc, char** argv) {
         printf("check: %d failing variant(s)\n", fails);
     }
     if (!strcmp(mode, "time32")) time_case(32, 32, 32);
+    if (!strcmp(mode, "chain")) chain_case(argc > 2 ? atoi(argv[2]) : 69, 32);
     if (!strcmp(mode, "timen")) for (int a = 2; a < argc; ++a) time_case(atoi(argv[a]), 32, 32);
     if (!strcmp(mode, "time") || !strcmp(mode, "all")) {
         time_case(32, 32, 32);

@@ -857,6 +857,12 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
     // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
     //                 + beta1*d_out + beta2*d_out_rrdb
     // (alpha5 multiplies the bias too: the accumulator starts at b5 and is scaled as a whole)
+    // What bounds conv5 (r03, tools/rdbt_check probe): 15.5 k of the block's 59 k ticks with the hand-over, 7.7 k with it switched
+    // off (-DRT_X_NOSYNC) - the MFMA waves wait for slabs half of the time.  Not for want of buffering: four more ring stages in
+    // the rows of x that conv5 never reads (frame rows 0..3 / 14..17, dead once conv4 is done: eight slabs in flight) gave 14.0 k;
+    // not LDS bandwidth either: splitting K between the two waves of a SIMD so that each X fragment feeds both N-tiles (1.5 KB
+    // of reads per MFMA instead of 2) gave 14.7 k.  All 256 workgroups reach conv5 together and each streams its 221 KB of
+    // conv5 weights in ~14 k ticks: 8.5 TB/s out of the L2s.  Neither variant is kept.
     f32x16 acc5;
     rt_acc_init<BWD>(acc5, bias_lds + 128 + nt5 * 32, g);
     // extended stages E1..E4: growth conv K (the instantiation for the number of tiles this wave owns; none: it only hands the

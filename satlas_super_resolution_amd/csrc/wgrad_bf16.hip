@@ -56,6 +56,10 @@ __device__ __forceinline__ void wg_sync4(int* cnt, int& phase, int lane) {   // 
     while (wg_ld(cnt) < phase) {}
 }
 
+typedef const __attribute__((address_space(1))) char* wg_gptr;          // global memory, explicitly: never a flat access
+typedef const __attribute__((address_space(1))) u32x4* wg_gvec;
+__device__ const u32x4 g_wg_zero16 = {0u, 0u, 0u, 0u};                  // where the loads of lanes outside the image go
+
 template <int KH, int KW, int S, bool SPLIT_TAPS>
 struct WgCfg {
     static constexpr int TH = wgrad_bf16_th(KH);             // pixel-tile rows: 16 for 3x3, 8 for 4x4
@@ -128,35 +132,43 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
         const bool do_bias = L.db != nullptr && it.ci0 == 0;
         float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 ra[C::NLV], rb[C::NLV];
+        // hand-issued, hand-waited global loads, every lane loads (see wgrad_bf16_k3_kernel): one tile stays in flight across the
+        // LDS stores of the previous one
+        const wg_gptr zero16 = (wg_gptr)&g_wg_zero16;
+        const wg_gptr dyg1 = (wg_gptr)dyg, xg1 = (wg_gptr)xg;
         auto load_tile = [&](int k, u32x4 (&r)[C::NLV]) {
             int b = it.tile_begin + k;
             const int tx_i = b % tiles_x; b /= tiles_x;
             const int ty_i = b % tiles_y;
             const int n = b / tiles_y;
             const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
-            const __bf16* dyb = dyg + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs + L.dy.coff + it.co0;
-            const __bf16* xb = xg + ((size_t)(n * L.Hi + ((gy0 * S) >> upshift)) * L.Wi + ((gx0 * S) >> upshift)) * L.x.cs +
-                               L.x.coff + it.ci0;
+            const wg_gptr dyb = dyg1 + (((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs + L.dy.coff + it.co0) * 2;
+            const wg_gptr xb = xg1 + (((size_t)(n * L.Hi + ((gy0 * S) >> upshift)) * L.Wi + ((gx0 * S) >> upshift)) * L.x.cs +
+                                      L.x.coff + it.ci0) * 2;
 #pragma unroll
             for (int q = 0; q < C::NLV; ++q) {
                 const int y = (int)(short)(yx[q] & 0xffff), x = yx[q] >> 16;
-                u32x4 val = {0u, 0u, 0u, 0u};
-                if (q < QDY) {
+                wg_gptr src;
+                if (q < QDY) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyb + rel[q] * 2 : zero16;
+                else src = ((unsigned)(gy0 * S + y) < (unsigned)LH && (unsigned)(gx0 * S + x) < (unsigned)LW) ? xb + rel[q] * 2 : zero16;
 #ifndef WG_X_NOLOAD
-                    if (gy0 + y < L.Gh && gx0 + x < L.Gw) val = *reinterpret_cast<const u32x4*>(dyb + rel[q]);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[q]) : "v"(src) : "memory");
+#else
+                r[q] = u32x4{(unsigned)(size_t)src, 0u, 0u, 0u};
 #endif
-                } else {
-#ifndef WG_X_NOLOAD
-                    if ((unsigned)(gy0 * S + y) < (unsigned)LH && (unsigned)(gx0 * S + x) < (unsigned)LW)
-                        val = *reinterpret_cast<const u32x4*>(xb + rel[q]);
-#endif
-                }
-                r[q] = val;
             }
+        };
+        auto wait_tile = [&](u32x4 (&r)[C::NLV]) {   // every load older than the newest NLV has landed
+            static_assert(C::NLV == 12, "operand list and vmcnt below");
+#ifndef WG_X_NOLOAD
+            asm volatile("s_waitcnt vmcnt(12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]),
+                         "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]) :: "memory");
+#endif
         };
         // tile k -> stage k % NST once every MFMA wave is finished with tile k - NST; LDS operations of a wave execute
         // in order, so the counter increment follows the data
-        auto put = [&](int k, int st, const u32x4 (&r)[C::NLV]) {
+        auto put = [&](int k, int st, u32x4 (&r)[C::NLV]) {
+            wait_tile(r);
             if (k >= NST) {
                 for (;;) {
                     u32x4 dn;
@@ -185,16 +197,31 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
             }
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WGC_READY + st))), "v"(1) : "memory");
         };
-        if (ntile > 0) load_tile(0, ra);
-        int st = 0;
-        for (int k = 0; k < ntile; k += 2) {
-            if (k + 1 < ntile) load_tile(k + 1, rb);
+        // two tiles in flight, no branch around a load (past the end the last tile is loaded again and never stored)
+        const int last = ntile - 1;
+        if (ntile > 0) {
+            load_tile(0, ra);
+            load_tile(min(1, last), rb);
+        }
+        int st = 0, k = 0;
+        for (; k + 1 < ntile; k += 2) {
             put(k, st, ra);
             st = st + 1 == NST ? 0 : st + 1;
-            if (k + 2 < ntile) load_tile(k + 2, ra);
-            if (k + 1 < ntile) {
-                put(k + 1, st, rb);
-                st = st + 1 == NST ? 0 : st + 1;
+            load_tile(min(k + 2, last), ra);
+            put(k + 1, st, rb);
+            st = st + 1 == NST ? 0 : st + 1;
+            load_tile(min(k + 3, last), rb);
+        }
+        if (k < ntile) put(k, st, ra);
+        {   // the loads past the end: their registers stay allocated until they have landed
+            auto hold = [&](u32x4 (&r)[C::NLV]) {
+                asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                             "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+            };
+            if (ntile > 0) {
+                hold(ra); hold(rb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                hold(ra); hold(rb);
             }
         }
         if (do_bias) {   // 64 threads share each channel octet: LDS float atomics, then one global atomic per channel
@@ -351,9 +378,6 @@ struct Wg3 {
     static_assert(LDS <= 160 * 1024 && 32 * 64 * 9 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
 };
 constexpr int W3C_BIAS = 16;
-typedef const __attribute__((address_space(1))) char* wg_gptr;          // global memory, explicitly: never a flat access
-typedef const __attribute__((address_space(1))) u32x4* wg_gvec;
-__device__ const u32x4 g_wg_zero16 = {0u, 0u, 0u, 0u};                  // where the loads of lanes outside the image go
     // [64] floats: bias-gradient partial sums of the loader threads, both planes
 
 // One wave's share of a tile: NR tile rows (k-steps of 16 pixels), ONE dY plane, ONE 32-channel half of the X patch, all nine

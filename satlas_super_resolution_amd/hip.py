@@ -104,7 +104,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_set_tile", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_set_tile", "ssr_bilinear_set_flat", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_set_tile.argtypes = [C.c_int32]
+    l.ssr_bilinear_set_flat.argtypes = [C.c_int32]
     l.ssr_rdb_tile_of.argtypes = [C.POINTER(RdbDesc)]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     l.ssr_wgrad_ci_tile.argtypes = [i32, i32]

@@ -252,8 +252,8 @@ int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_
 /* s1 = bilinear2x^T(dy) (+ r if r.p) -> y1 (optional); y = s1 * lrelu'(m) (m optional) */
 int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,
                        int32_t H, int32_t W, int32_t C, void* stream);
-/* 1: per-pixel kernels for every shape; 0 (default): bf16 layers with C % 64 == 0 use the LDS-tile kernels (same arithmetic,
- * same order: identical bytes).  Returns the previous setting.  Environment: SSR_BILINEAR_FLAT=1. */
+/* 1: per-pixel kernels for every shape; 0 (default): layers whose channels are whole groups of eight 16-byte vectors (64 in
+ * bf16, 32 in fp32 storage) use the LDS-tile kernels (same arithmetic, same order: identical bytes in bf16).  Returns the previous setting.  Environment: SSR_BILINEAR_FLAT=1. */
 int32_t ssr_bilinear_set_flat(int32_t on);
 /* nearest x2 backward (2x2 sum) with the same epilogue: rrdbnet_arch.py:127-128 backward */
 int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,

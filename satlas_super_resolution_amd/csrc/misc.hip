@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16, C % 64 == 0 (the U-Net discriminator's three x2 steps, discriminator_arch.py:47,52,57): the same arithmetic in the
+// C a multiple of 8 vectors of 16 bytes - 64 channels in bf16, 32 in fp32 storage - (the U-Net discriminator's three x2 steps,
+// discriminator_arch.py:47,52,57): the same arithmetic in the
 // same order as the kernels above, but the 3 x 3 (forward) / 4 x 4 (backward) neighbourhoods come out of an LDS tile.
 // The per-pixel kernels above fetch every input vector 9 (16) times, and a wave covers only 1..4 pixels of 128..512
 // channels, so the reuse is across waves and mostly misses L1: 0.40 + 0.41 ms per step at ~2.2 TB/s of useful traffic,
@@ -366,35 +367,39 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(ssr_view dy, ssr_view r, 
 // exactly as the index clamps above do.
 // ------------------------------------------------------------------------------------------------
 constexpr int BF_IH = 4, BF_IW = 16, BF_PH = BF_IH + 2, BF_PW = BF_IW + 2, BF_NPX = BF_PH * BF_PW;   // 108 patch pixels
+// a workgroup covers 8 channel vectors of 16 bytes: 64 channels (bf16) / 32 channels (fp32 storage)
+template <typename T>
 __global__ __launch_bounds__(256) void bilinear2x_fwd_tile_kernel(ssr_view a, ssr_view b, ssr_view y, int N, int H, int W) {
-    // fp32 sums a + b: [half of the 8-channel vector][pixel][vector * 4 + e] - 128-byte pixel rows: the 16 lanes the LDS serves
-    // together (4 vectors of 4 consecutive pixels) read four different 64-byte bank groups
-    __shared__ __attribute__((aligned(16))) float patch[2][BF_NPX][32];
+    constexpr int V = VecIO<T>::N, NPL = V / 4;
+    // fp32 sums a + b: [4-float part of the channel vector][pixel][vector * 4 + e] - 128-byte pixel rows: the 16 lanes the LDS
+    // serves together (4 vectors of 4 consecutive pixels) read four different 64-byte bank groups
+    __shared__ __attribute__((aligned(16))) float patch[NPL][BF_NPX][32];
     const int tid = threadIdx.x;
     const int tiles_x = (W + BF_IW - 1) / BF_IW, tiles_y = (H + BF_IH - 1) / BF_IH;
     int t_ = blockIdx.x;
     const int tx = t_ % tiles_x; t_ /= tiles_x;
     const int ty = t_ % tiles_y;
     const int n = t_ / tiles_y;
-    const int c0 = blockIdx.y * 64, iy0 = ty * BF_IH, ix0 = tx * BF_IW;
-    const __bf16* __restrict__ ap = reinterpret_cast<const __bf16*>(a.p);
-    const __bf16* __restrict__ bp = reinterpret_cast<const __bf16*>(b.p);
-    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(y.p);
+    const int c0 = blockIdx.y * 8 * V, iy0 = ty * BF_IH, ix0 = tx * BF_IW;
+    const T* __restrict__ ap = reinterpret_cast<const T*>(a.p);
+    const T* __restrict__ bp = reinterpret_cast<const T*>(b.p);
+    T* __restrict__ yp = reinterpret_cast<T*>(y.p);
     for (int v = tid; v < BF_NPX * 8; v += 256) {
         const int pix = v >> 3, c8 = v & 7;
         const int py = pix / BF_PW, px = pix - py * BF_PW;
         const int sy = min(max(iy0 - 1 + py, 0), H - 1), sx = min(max(ix0 - 1 + px, 0), W - 1);
         const size_t p = (size_t)(n * H + sy) * W + sx;
-        float f[8];
-        VecIO<__bf16>::load(ap + p * a.cs + a.coff + c0 + c8 * 8, f);
+        float f[V];
+        VecIO<T>::load(ap + p * a.cs + a.coff + c0 + c8 * V, f);
         if (bp) {
-            float g[8];
-            VecIO<__bf16>::load(bp + p * b.cs + b.coff + c0 + c8 * 8, g);
+            float g[V];
+            VecIO<T>::load(bp + p * b.cs + b.coff + c0 + c8 * V, g);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] += g[k];
+            for (int k = 0; k < V; ++k) f[k] += g[k];
         }
-        *reinterpret_cast<f32x4*>(&patch[0][pix][c8 * 4]) = f32x4{f[0], f[1], f[2], f[3]};
-        *reinterpret_cast<f32x4*>(&patch[1][pix][c8 * 4]) = f32x4{f[4], f[5], f[6], f[7]};
+#pragma unroll
+        for (int h = 0; h < NPL; ++h)
+            *reinterpret_cast<f32x4*>(&patch[h][pix][c8 * 4]) = f32x4{f[4 * h], f[4 * h + 1], f[4 * h + 2], f[4 * h + 3]};
     }
     __syncthreads();
     const int W2 = 2 * W;
@@ -403,16 +408,18 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_tile_kernel(ssr_view a, ss
         const int cc = q % BF_IW, r = q / BF_IW;
         const int iy = iy0 + r, ix = ix0 + cc;
         if (iy >= H || ix >= W) continue;
-        float t[3][3][8];
+        float t[3][3][V];
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
             for (int c2 = 0; c2 < 3; ++c2) {
                 const int pix = (r + rr) * BF_PW + cc + c2;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(&patch[0][pix][c8 * 4]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(&patch[1][pix][c8 * 4]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { t[rr][c2][k] = lo[k]; t[rr][c2][4 + k] = hi[k]; }
+                for (int h = 0; h < NPL; ++h) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&patch[h][pix][c8 * 4]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[rr][c2][4 * h + k] = w4[k];
+                }
             }
         const float wya[2] = {iy > 0 ? 0.25f : 1.f, 0.75f}, wyb[2] = {iy > 0 ? 0.75f : 0.f, 0.25f};
         const float wxa[2] = {ix > 0 ? 0.25f : 1.f, 0.75f}, wxb[2] = {ix > 0 ? 0.75f : 0.f, 0.25f};
@@ -420,20 +427,22 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_tile_kernel(ssr_view a, ss
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                float o[8];
+                float o[V];
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < V; ++k)
                     o[k] = wya[py] * (wxa[px] * t[py][px][k] + wxb[px] * t[py][px + 1][k]) +
                            wyb[py] * (wxa[px] * t[py + 1][px][k] + wxb[px] * t[py + 1][px + 1][k]);
-                VecIO<__bf16>::store(yp + ((size_t)(n * 2 * H + 2 * iy + py) * W2 + 2 * ix + px) * y.cs + y.coff + c0 + c8 * 8, o);
+                VecIO<T>::store(yp + ((size_t)(n * 2 * H + 2 * iy + py) * W2 + 2 * ix + px) * y.cs + y.coff + c0 + c8 * V, o);
             }
     }
 }
 
 constexpr int BB_IH = 4, BB_IW = 8, BB_PH = 2 * BB_IH + 2, BB_PW = 2 * BB_IW + 2, BB_NPX = BB_PH * BB_PW;   // 180 gradient pixels
 constexpr int BB_PITCH = 192;   // bytes per patch pixel (128 of data): lanes step two pixels, 384 B = half the banks further
+template <typename T>
 __global__ __launch_bounds__(256) void bilinear2x_bwd_tile_kernel(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m,
                                                                   int N, int H, int W) {
+    constexpr int V = VecIO<T>::N;
     __shared__ __attribute__((aligned(16))) char dyp[BB_NPX * BB_PITCH];
     const int tid = threadIdx.x;
     const int H2 = 2 * H, W2 = 2 * W;
@@ -442,56 +451,56 @@ __global__ __launch_bounds__(256) void bilinear2x_bwd_tile_kernel(ssr_view dy, s
     const int tx = t_ % tiles_x; t_ /= tiles_x;
     const int ty = t_ % tiles_y;
     const int n = t_ / tiles_y;
-    const int c0 = blockIdx.y * 64, iy0 = ty * BB_IH, ix0 = tx * BB_IW;
-    const __bf16* __restrict__ dp = reinterpret_cast<const __bf16*>(dy.p);
-    const __bf16* __restrict__ rp = reinterpret_cast<const __bf16*>(r.p);
-    const __bf16* __restrict__ mp = reinterpret_cast<const __bf16*>(m.p);
-    __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(y1.p);
-    __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(y.p);
+    const int c0 = blockIdx.y * 8 * V, iy0 = ty * BB_IH, ix0 = tx * BB_IW;
+    const T* __restrict__ dp = reinterpret_cast<const T*>(dy.p);
+    const T* __restrict__ rp = reinterpret_cast<const T*>(r.p);
+    const T* __restrict__ mp = reinterpret_cast<const T*>(m.p);
+    T* __restrict__ y1p = reinterpret_cast<T*>(y1.p);
+    T* __restrict__ yp = reinterpret_cast<T*>(y.p);
     for (int v = tid; v < BB_NPX * 8; v += 256) {
         const int pix = v >> 3, c8 = v & 7;
         const int py = pix / BB_PW, px = pix - py * BB_PW;
         const int oy = min(max(2 * iy0 - 1 + py, 0), H2 - 1), ox = min(max(2 * ix0 - 1 + px, 0), W2 - 1);
         *reinterpret_cast<u32x4*>(dyp + pix * BB_PITCH + c8 * 16) =
-            *reinterpret_cast<const u32x4*>(dp + ((size_t)(n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c0 + c8 * 8);
+            *reinterpret_cast<const u32x4*>(dp + ((size_t)(n * H2 + oy) * W2 + ox) * dy.cs + dy.coff + c0 + c8 * V);
     }
     __syncthreads();
     const int c8 = tid & 7, cc = (tid >> 3) & 7, rr = tid >> 6;
     const int iy = iy0 + rr, ix = ix0 + cc;
     if (iy >= H || ix >= W) return;
-    const int c = c0 + c8 * 8;
-    float s[8], t[8];
+    const int c = c0 + c8 * V;
+    float s[V], t[V];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
     const float wy[4] = {iy > 0 ? 0.25f : 0.f, iy > 0 ? 0.75f : 1.f, iy < H - 1 ? 0.75f : 1.f, iy < H - 1 ? 0.25f : 0.f};
     const float wx[4] = {ix > 0 ? 0.25f : 0.f, ix > 0 ? 0.75f : 1.f, ix < W - 1 ? 0.75f : 1.f, ix < W - 1 ? 0.25f : 0.f};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float rs[8];
+        float rs[V];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rs[k] = 0.f;
+        for (int k = 0; k < V; ++k) rs[k] = 0.f;
 #pragma unroll
         for (int bq = 0; bq < 4; ++bq) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(dyp + ((2 * rr + a) * BB_PW + 2 * cc + bq) * BB_PITCH + c8 * 16);
+            VecIO<T>::load(reinterpret_cast<const T*>(dyp + ((2 * rr + a) * BB_PW + 2 * cc + bq) * BB_PITCH + c8 * 16), t);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) rs[k] += wx[bq] * (float)v[k];
+            for (int k = 0; k < V; ++k) rs[k] += wx[bq] * t[k];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += wy[a] * rs[k];
+        for (int k = 0; k < V; ++k) s[k] += wy[a] * rs[k];
     }
     const long p = ((long)n * H + iy) * W + ix;
     if (rp) {
-        VecIO<__bf16>::load(rp + p * r.cs + r.coff + c, t);
+        VecIO<T>::load(rp + p * r.cs + r.coff + c, t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += t[k];
+        for (int k = 0; k < V; ++k) s[k] += t[k];
     }
-    if (y1p) VecIO<__bf16>::store(y1p + p * y1.cs + y1.coff + c, s);
+    if (y1p) VecIO<T>::store(y1p + p * y1.cs + y1.coff + c, s);
     if (mp) {
-        VecIO<__bf16>::load(mp + p * m.cs + m.coff + c, t);
+        VecIO<T>::load(mp + p * m.cs + m.coff + c, t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] *= lrelu_grad_from_out(t[k]);
+        for (int k = 0; k < V; ++k) s[k] *= lrelu_grad_from_out(t[k]);
     }
-    if (yp) VecIO<__bf16>::store(yp + p * y.cs + y.coff + c, s);
+    if (yp) VecIO<T>::store(yp + p * y.cs + y.coff + c, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -813,12 +822,14 @@ extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dt
         return SSR_EINVAL;
     const long total = (long)N * H * W * C / (dtype == SSR_F32 ? 4 : 8);   // one thread per input pixel x 16 bytes
     if (total >= (1L << 31)) return SSR_EINVAL;
-    if (dtype == SSR_F32)
+    const dim3 tgrid(N * ((H + BF_IH - 1) / BF_IH) * ((W + BF_IW - 1) / BF_IW), dtype == SSR_F32 ? C / 32 : C / 64);
+    if (dtype == SSR_F32 && (C % 32) == 0 && !g_bilinear_flat)
+        hipLaunchKernelGGL(bilinear2x_fwd_tile_kernel<float>, tgrid, dim3(256), 0, ST(stream), a, b, y, N, H, W);
+    else if (dtype == SSR_F32)
         hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
                            b, y, N, H, W, C);
     else if (dtype == SSR_BF16 && (C % 64) == 0 && !g_bilinear_flat)
-        hipLaunchKernelGGL(bilinear2x_fwd_tile_kernel, dim3(N * ((H + BF_IH - 1) / BF_IH) * ((W + BF_IW - 1) / BF_IW), C / 64),
-                           dim3(256), 0, ST(stream), a, b, y, N, H, W);
+        hipLaunchKernelGGL(bilinear2x_fwd_tile_kernel<__bf16>, tgrid, dim3(256), 0, ST(stream), a, b, y, N, H, W);
     else if (dtype == SSR_BF16)
         hipLaunchKernelGGL(bilinear2x_fwd_kernel<__bf16>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream), a,
                            b, y, N, H, W, C);
@@ -834,12 +845,14 @@ static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m
     if (!dy.p || (!y.p && !y1.p) || (C % 8) != 0 || (dy.cs % 8) || (dy.coff % 8)) return SSR_EINVAL;
     const long total = (long)N * H * W * C / 4;
     if (total >= (1L << 31)) return SSR_EINVAL;               // the kernel indexes in 32 bits
-    if (dtype == SSR_F32)
+    const dim3 tgrid(N * ((H + BB_IH - 1) / BB_IH) * ((W + BB_IW - 1) / BB_IW), dtype == SSR_F32 ? C / 32 : C / 64);
+    if (dtype == SSR_F32 && MODE == 0 && (C % 32) == 0 && !g_bilinear_flat)
+        hipLaunchKernelGGL(bilinear2x_bwd_tile_kernel<float>, tgrid, dim3(256), 0, ST(stream), dy, r, y1, y, m, N, H, W);
+    else if (dtype == SSR_F32)
         hipLaunchKernelGGL((up2x_bwd_kernel<float, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
                            dy, r, y1, y, m, N, H, W, C);
     else if (dtype == SSR_BF16 && MODE == 0 && (C % 64) == 0 && !g_bilinear_flat)
-        hipLaunchKernelGGL(bilinear2x_bwd_tile_kernel, dim3(N * ((H + BB_IH - 1) / BB_IH) * ((W + BB_IW - 1) / BB_IW), C / 64),
-                           dim3(256), 0, ST(stream), dy, r, y1, y, m, N, H, W);
+        hipLaunchKernelGGL(bilinear2x_bwd_tile_kernel<__bf16>, tgrid, dim3(256), 0, ST(stream), dy, r, y1, y, m, N, H, W);
     else if (dtype == SSR_BF16)
         hipLaunchKernelGGL((up2x_bwd_kernel<__bf16, MODE>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST(stream),
                            dy, r, y1, y, m, N, H, W, C);

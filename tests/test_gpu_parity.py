@@ -143,27 +143,30 @@ def test_bilinear_and_nearest_against_torch():
         assert rel_err(_buf_to_nchw(hip, gb, Cc, dt), a2.grad) < 1e-6
 
 
-@pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 16, 128), (1, 7, 21, 64), (3, 9, 4, 192), (2, 32, 32, 256)])
-def test_bilinear_tile_kernels_match_the_per_pixel_kernels(B, H, W, Cc):
-    """bf16 layers with C % 64 == 0 (the U-Net discriminator, discriminator_arch.py:47,52,57) run the LDS-tile kernels:
-    same arithmetic in the same order as the per-pixel kernels -> identical bytes; and both against torch in fp32."""
+@pytest.mark.parametrize("B,H,W,Cc,fp32", [(2, 16, 16, 128, False), (1, 7, 21, 64, False), (3, 9, 4, 192, False), (2, 32, 32, 256, False),
+                                             (2, 16, 16, 128, True), (1, 7, 21, 32, True), (2, 9, 4, 96, True)])
+def test_bilinear_tile_kernels_match_the_per_pixel_kernels(B, H, W, Cc, fp32):
+    """layers whose channels are whole groups of eight 16-byte vectors (the U-Net discriminator, discriminator_arch.py:47,52,57)
+    run the LDS-tile kernels: same arithmetic in the same order as the per-pixel kernels -> identical bytes in bf16, last-bit
+    differences at most in fp32 storage (fused multiply-add choices of the compiler); and against torch."""
     engine, hip = _mods()
     lib = hip.lib()
     g = torch.Generator().manual_seed(B * 100 + H)
     dev = torch.device("cuda:0")
-    rnd = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(dev)
+    tdt, DT, ity, tol = (torch.float32, hip.F32, torch.int32, 2e-6) if fp32 else (torch.bfloat16, hip.BF16, torch.int16, 4e-3)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(tdt).to(dev)
     a, b2 = rnd(B, H, W, Cc), rnd(B, H, W, Cc)
     dy, r, m = rnd(B, 2 * H, 2 * W, Cc), rnd(B, H, W, Cc), rnd(B, H, W, Cc)
 
     def run(flat, with_b, with_rm):
         prev = lib.ssr_bilinear_set_flat(1 if flat else 0)
         try:
-            y = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=torch.bfloat16, device=dev)
-            hip.check(lib.ssr_bilinear2x_fwd(hip.view(a), hip.view(b2) if with_b else hip.NULL_VIEW, hip.view(y), hip.BF16, B, H, W, Cc,
+            y = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=tdt, device=dev)
+            hip.check(lib.ssr_bilinear2x_fwd(hip.view(a), hip.view(b2) if with_b else hip.NULL_VIEW, hip.view(y), DT, B, H, W, Cc,
                                              hip.stream_ptr()), "bil fwd")
             gx, g1 = torch.zeros_like(a), torch.zeros_like(a)
             hip.check(lib.ssr_bilinear2x_bwd(hip.view(dy), hip.view(r) if with_rm else hip.NULL_VIEW, hip.view(g1) if with_rm else hip.NULL_VIEW,
-                                             hip.view(gx), hip.view(m) if with_rm else hip.NULL_VIEW, hip.BF16, B, H, W, Cc,
+                                             hip.view(gx), hip.view(m) if with_rm else hip.NULL_VIEW, DT, B, H, W, Cc,
                                              hip.stream_ptr()), "bil bwd")
             torch.cuda.synchronize()
         finally:
@@ -174,18 +177,21 @@ def test_bilinear_tile_kernels_match_the_per_pixel_kernels(B, H, W, Cc):
         y0, gx0, g10 = run(True, with_b, with_rm)
         y1, gx1, g11 = run(False, with_b, with_rm)
         for u, v, what in ((y0, y1, "forward"), (gx0, gx1, "backward"), (g10, g11, "backward, value before the mask")):
-            assert torch.equal(u.view(torch.int16), v.view(torch.int16)), what
+            if fp32:      # the two kernels may contract different multiply-add pairs: last-bit differences in fp32 storage
+                assert float((u - v).abs().max()) <= 4e-6 * float(u.abs().max()), what
+            else:         # bf16 storage: the final rounding absorbs them - identical bytes
+                assert torch.equal(u.view(ity), v.view(ity)), what
         # and against torch (fp32 on the bf16 inputs; one bf16 rounding at the end)
         xin = (a.float() + (b2.float() if with_b else 0)).permute(0, 3, 1, 2).cpu().requires_grad_(True)
         yr = F.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False)
-        assert rel_err(y1.float().permute(0, 3, 1, 2).cpu(), yr.detach()) < 4e-3
+        assert rel_err(y1.float().permute(0, 3, 1, 2).cpu(), yr.detach()) < tol
         yr.backward(dy.float().permute(0, 3, 1, 2).cpu())
         gref = xin.grad + (r.float().permute(0, 3, 1, 2).cpu() if with_rm else 0)
         if with_rm:
-            assert rel_err(g11.float().permute(0, 3, 1, 2).cpu(), gref) < 4e-3
+            assert rel_err(g11.float().permute(0, 3, 1, 2).cpu(), gref) < tol
             mm = m.float().permute(0, 3, 1, 2).cpu()
             gref = gref * torch.where(mm > 0, torch.ones_like(mm), torch.full_like(mm, 0.2))
-        assert rel_err(gx1.float().permute(0, 3, 1, 2).cpu(), gref) < 4e-3
+        assert rel_err(gx1.float().permute(0, 3, 1, 2).cpu(), gref) < tol
         assert float(gx1.float().abs().max()) > 0.1
 
 

@@ -276,3 +276,46 @@ def test_infer_grid_driver_io_and_sharding(tmp_path):
         assert (sr[384:512, 640:768] == np.asarray(Image.open(save / "7_9" / "3_5.png"))).all()
     assert res == {"chunks": 131, "tiles_stitched": 1}
     assert len(list((outs["two"] / "7_9").glob("[0-9]*_[0-9]*.png"))) == 256
+
+
+def test_wgrad_items_are_paired_without_losing_or_duplicating_work():
+    """Host logic of the batched weight-gradient launch (engine.WgradBatch): blocks of 32 output-gradient channels that are
+    contracted with the same input patch share one work item (two dY planes per X patch, csrc/wgrad_bf16.hip).  The pairing
+    must keep every (layer, co block, ci chunk, pixel range) exactly once, pair only items that read the same x view, ci chunk,
+    geometry and number of valid input channels, and the launch order must start with the longest items."""
+    from satlas_super_resolution_amd import engine, hip
+    V = hip.View
+    wb = engine.WgradBatch(hip.BF16, 3, 1)
+    base = 0x10000000
+    # two dense blocks (conv1..conv5 read one 192-channel buffer: rrdbnet_arch.py:37-42) + one 64 -> 64 layer at 128 x 128
+    for r in range(2):
+        xb = base + r * 0x4000000
+        for k in range(5):
+            cin, cout = 64 + 32 * k, (64 if k == 4 else 32)
+            dy = V(xb + 0x1000000, 192, 64 + 32 * k) if k < 4 else V(xb + 0x2000000, 192, 0)
+            wb.add(V(xb, 192, 0), dy, 4, 32, 32, 1, cin, cout, 32, 32, 1.0, 0x5000 + 64 * k, cin, 0x6000)
+    wb.add(V(base + 0x9000000, 64, 0), V(base + 0xa000000, 64, 0), 4, 128, 128, 1, 64, 64, 128, 128, 1.0, 0x7000, 64, 0x8000)
+    singles = [(it.layer, it.co0, it.ci0, it.tile_begin, it.tile_end) for it in wb.items]
+    assert len(singles) == len(set(singles)) == 2 * 14 + 2 * (4 * 64 // 128)        # 256 tiles of 16 x 16 in two ranges, two co blocks
+    paired = wb._pair(wb.items)
+    seen = []
+    for it in paired:
+        seen.append((it.layer, it.co0, it.ci0, it.tile_begin, it.tile_end))
+        if it.nco == 2:
+            seen.append((it.layer_b, it.co0_b, it.ci0, it.tile_begin, it.tile_end))
+            A, B = wb.layers[it.layer], wb.layers[it.layer_b]
+            assert (A.x.p, A.x.cs, A.x.coff) == (B.x.p, B.x.cs, B.x.coff)
+            assert (A.N, A.Hi, A.Wi, A.up, A.Gh, A.Gw) == (B.N, B.Hi, B.Wi, B.up, B.Gh, B.Gw)
+            assert (min(64, A.Cin_w - it.ci0) > 32) == (min(64, B.Cin_w - it.ci0) > 32)
+            assert (it.layer, it.co0) != (it.layer_b, it.co0_b)
+    assert sorted(seen) == sorted(singles)                       # nothing lost, nothing twice
+    # a dense block: 6 pairs + the two 32-channel leftovers (dpre2 over x1, dpre4 over x3); the 64 -> 64 layer: its two halves
+    per_block = [it for it in paired if it.layer < 5]
+    assert sum(it.nco == 2 for it in per_block) == 6 and sum(it.nco != 2 for it in per_block) == 2
+    assert all(it.nco == 2 and it.layer_b == it.layer and {it.co0, it.co0_b} == {0, 32} for it in paired if it.layer == 10)
+    # launch order: longest first (workgroups are handed out in index order)
+    order = sorted(paired, key=lambda it: -wb._cost(it))
+    costs = [wb._cost(it) for it in order]
+    assert costs == sorted(costs, reverse=True) and order[0].nco == 2
+    # the simulated balance never makes the launch longer
+    assert wb._makespan(wb._balance(paired)) <= wb._makespan(paired)

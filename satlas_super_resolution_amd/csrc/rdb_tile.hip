@@ -711,14 +711,16 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         // (by (row >> 3) & 1); the row phase of a piece is a multiple of 16 rows, so the pattern is the same for every piece
         const int lo14 = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
         const int lo5 = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-        int dlo = lo5 - lo14;
-        rt_pin(dlo);
         auto load_from = [&](unsigned long long src64, u32x4 (&r)[6]) {
             rt_gptr src = (rt_gptr)(src64 & ~1ull);
-            // bit 0 of a table entry: conv5 layout.  Arithmetic, not `bit ? lo5 : lo14`: hipcc turned that select into a table
-            // of two stack addresses — a scratch load, a flat load and s_waitcnt vmcnt(0) lgkmcnt(0) in front of EVERY slab's
-            // loads, i.e. no slab load in flight while the next was issued
-            const int lo = lo14 + (int)(src64 & 1ull) * dlo;
+            // bit 0 of a table entry: conv5 layout.  hipcc turns this select into a table of two stack addresses (a scratch load, a
+            // flat load and s_waitcnt vmcnt(0) lgkmcnt(0) in front of every slab's loads: one slab load in flight per producer).
+            // The arithmetic form `lo14 + bit * (lo5 - lo14)` removes that - RT_RQ slabs really in flight - and the launch is NOT
+            // faster (32.1 us either way: the producers are not what paces the block), but with three slabs in flight the
+            // library build gives wrong block outputs in the lower rows of a tile (tests/test_gpu_rdb_tile.py; queue depths 1
+            // and 2 pass, the stand-alone harness passes at depth 3): a hand-over race that is not understood yet.  Kept
+            // serialized until it is (r03).
+            const int lo = (src64 & 1ull) ? lo5 : lo14;
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
         };

@@ -12,8 +12,8 @@
 // (the tap shift is just a different per-lane pixel address; no alignment constraint).  A 64-byte row
 // (32 bf16) makes the 4 pixel rows of a 32-lane read tile the 64 banks exactly: conflict-free.
 //
-// Work decomposition: device tables, one (layer, 32co, 32ci, pixel-tile range) item per workgroup, all taps in
-// registers.  Structure (r01, tools/wgrad_probe.hip): when the four MFMA waves also fetched their own tiles, an
+// Work decomposition (generic kernel below; the 3x3 stride-1 kernel further down has its own): device tables, one (layer, 32co,
+// 32ci, pixel-tile range) item per workgroup, all taps in registers.  Structure (r01, tools/wgrad_probe.hip): when the four MFMA waves also fetched their own tiles, an
 // iteration took 2580 cycles for 640 cycles of MFMAs — 1330 of them the wave sitting in the ISSUE of its five
 // 16-byte loads: a wave gets only ~6.4 B/clk from L2/HBM (tools/l2_probe.hip) and the tile is 4.9 KB per wave.
 // So the workgroup is 8 waves:
@@ -349,17 +349,20 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 3x3 stride 1: (32 or 64) co x 64 ci per workgroup, the 18 (tap, 32-channel half) units dealt to the four MFMA waves.
-// Why 64 ci (tools/wgrad_probe.hip): with 32 x 32 tiles the loaders had to deliver a 37 KB tile per 1280 MFMA cycles and got
-// 16.8 B/clk — they fetch 64-byte slices of 384-byte NHWC pixels (half of every 128-byte line is wasted) — so the
-// MFMA waves idled half the time.  A 64-channel X patch is whole lines, every wave sees ALL pixels of the tile for its
-// 4..5 units (no cross-wave reduction at the end), and the X patch sits in LDS as two dense 64-byte-row planes.
-// Why 64 co (round 3, tools/wgrad_body_probe.hip): at 32 co the kernel ran at ~4400 cycles per tile with EITHER the global
-// loads or 4/5 of the MFMAs removed (3980 / 3940): the bound is the LDS pipe — a wave reads 1 dY + 5 X fragments (1 KB each,
-// 8 LDS cycles as two ds_read_b64_tr_b16) for 5 MFMAs, 4 x 48 = 192 LDS cycles per k-step against 160 MFMA cycles.  With a
-// SECOND 32-channel dY plane every X fragment feeds two MFMAs: 2 + 5 reads for 10 MFMAs, 208 LDS cycles against 320.  The two
-// planes may belong to different layers that read the same input (a dense block's conv1..conv4 share x and write dpre1..4;
-// conv5's 64 outputs are the two halves of one layer): the host pairs items (engine.WgradBatch.finalize).
+// 3x3 stride 1: (32 or 64) co x 64 ci per workgroup; an MFMA wave owns one 32-co plane of dY, one 32-ci half of the X patch and
+// all nine taps (wg3_rows).  How it got there, each step measured with tools/wgrad_probe.hip / tools/wgrad_body_probe.hip:
+//  * 64 ci: with 32 x 32 tiles the loaders had to deliver a 37 KB tile per 1280 MFMA cycles and got 16.8 B/clk - they fetch
+//    64-byte slices of 384-byte NHWC pixels (half of every 128-byte line is wasted).  A 64-channel X patch is whole lines and
+//    sits in LDS as two dense 64-byte-row planes.
+//  * 64 co (round 3): at 32 co the kernel took ~4400 cycles per tile with EITHER the global loads or 4/5 of the MFMAs removed
+//    (3980 / 3940): the LDS pipe was the bound - a wave read 1 dY + 5 X fragments (1 KB each as two ds_read_b64_tr_b16) for 5
+//    MFMAs.  With a SECOND 32-channel dY plane in the item every X fragment feeds two MFMAs.  The two planes may belong to
+//    different layers that read the same input (a dense block's conv1..conv4 share x and write dpre1..4; conv5's 64 outputs
+//    are the two halves of one layer): the host pairs items (engine.WgradBatch._pair).
+//  * rolling rows (round 3): one X fragment serves three k-steps - 4 LDS reads per 9 MFMAs instead of 7 per 10 (wg3_rows).
+//  * hand-waited loads (round 3): the loaders had no load in flight while they stored (see the loader branch).
+//  Paired item: 6600 -> 5900 cycles per 36-product tile; a dense block's 14 items became 6 pairs + 2 singles; 3x3 weight
+//  gradients 2.56 -> 1.95 ms per step.  What remains: one MFMA wave per SIMD issues an MFMA per ~35 cycles (5040 per tile).
 // ------------------------------------------------------------------------------------------------------------------
 #ifndef WG3_PF
 #define WG3_PF 6      // operand fragments read ahead of their MFMAs

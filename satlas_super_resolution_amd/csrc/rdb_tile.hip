@@ -715,11 +715,13 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             rt_gptr src = (rt_gptr)(src64 & ~1ull);
             // bit 0 of a table entry: conv5 layout.  hipcc turns this select into a table of two stack addresses (a scratch load, a
             // flat load and s_waitcnt vmcnt(0) lgkmcnt(0) in front of every slab's loads: one slab load in flight per producer).
-            // The arithmetic form `lo14 + bit * (lo5 - lo14)` removes that - RT_RQ slabs really in flight - and the launch is NOT
-            // faster (32.1 us either way: the producers are not what paces the block), but with three slabs in flight the
-            // library build gives wrong block outputs in the lower rows of a tile (tests/test_gpu_rdb_tile.py; queue depths 1
-            // and 2 pass, the stand-alone harness passes at depth 3): a hand-over race that is not understood yet.  Kept
-            // serialized until it is (r03).
+            // Forms without the table were tried (r03, DESIGN.md lesson 36): `lo14 + bit * (lo5 - lo14)` compiles to one v_cndmask,
+            // keeps RT_RQ slabs in flight, passes every test - and the launch is NOT faster (32.1 us either way: the producers do
+            // not pace the block).  The same expression with its difference held in a pinned register, or an inline-asm v_cndmask,
+            // gives WRONG block outputs for the waves that own the last M-tiles in the library build (not in the stand-alone
+            // harness; not with queue depth 1 or 2; also with s_waitcnt vmcnt(0) in front of every slab's loads, so it is not the
+            // pipelining): a code-generation sensitivity of this kernel that is not understood.  Kept: the form every test of
+            // rounds 2-3 ran with; tests/test_gpu_rdb_tile.py is the guard for any rebuild.
             const int lo = (src64 & 1ull) ? lo5 : lo14;
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);

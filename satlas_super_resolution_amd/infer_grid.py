@@ -60,56 +60,56 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
         print("Running inference on ", len(pngs), " images.")
     mine = list(range(rank, len(pngs), world))
     batch = int(opt.get("batch", 64))
-    # PNG decode / encode off the critical path: a thread pool (zlib releases the GIL) reads the NEXT batch's files while the
-    # device runs this one, and compresses + writes the PREVIOUS batch's chunks.  Frame selection (format_s2naip_data consumes the
-    # global `random` stream) stays on this thread, in listing order, so the same seed picks the same frames as a serial run.
-    from concurrent.futures import ThreadPoolExecutor
-    from PIL import Image
-    workers = int(opt.get("io_workers", min(16, (os.cpu_count() or 4))))
+    # PNG decode / encode off the critical path, in worker PROCESSES (png_io.py: threads do not scale, Pillow holds the GIL):
+    # they read the NEXT batch's files while the device runs this one and compress + write the PREVIOUS batch's chunks.  Frame
+    # selection (format_s2naip_data consumes the global `random` stream) stays in this process, in listing order, so the same
+    # seed picks the same frames as a serial run.  `io_workers` (option file, our extension): processes per rank; 0 = threads.
+    from . import png_io
+    workers = int(opt.get("io_workers", max(1, min(16, (os.cpu_count() or 4) // max(1, world)))))
     done = 0
 
-    def save_chunk(arr, i):
+    def out_path(i):
         tile, idx = pngs[i].split("/")[-2], pngs[i].split("/")[-1]      # keep tile / index so that the stitch finds them
-        os.makedirs(os.path.join(save_path, tile), exist_ok=True)
-        Image.fromarray(arr).save(os.path.join(save_path, tile, idx))
+        return os.path.join(save_path, tile, idx)
 
-    from .utils.infer_utils import stitch_arrays
     tiles = sorted(t for t in os.listdir(data_dir) if os.path.isdir(os.path.join(data_dir, t)))
     complete = {t for t in tiles if len(os.listdir(os.path.join(data_dir, t))) >= 256}
     keep = {t: {} for t in complete} if world == 1 else {}     # one rank: the mosaics are built from the arrays, not re-read from disk
     raw_keep = {t: {} for t in complete} if world == 1 else {}
     stitched = 0
+    cells = [f"{i}_{j}.png" for i in range(16) for j in range(16)]
 
-    def stitch_tile(tile):
+    def submit_stitch(pool, tile):
         """infer_grid.py:69-85 for one tile: stitched_sr.png (2048) and stitched_s2.png (512, first frame of every stack)"""
+        sr_path, s2_path = os.path.join(save_path, tile, "stitched_sr.png"), os.path.join(save_path, tile, "stitched_s2.png")
         if tile in keep and len(keep[tile]) >= 256:
-            cells = [(i, j) for i in range(16) for j in range(16)]
-            Image.fromarray(stitch_arrays({c: keep[tile][f"{c[0]}_{c[1]}.png"] for c in cells}, 2048)).save(os.path.join(save_path, tile, "stitched_sr.png"))
-            Image.fromarray(stitch_arrays({c: raw_keep[tile][f"{c[0]}_{c[1]}.png"] for c in cells}, 512, sentinel2=True)).save(
-                os.path.join(save_path, tile, "stitched_s2.png"))
+            fs = [pool.submit("stitch_and_save", [keep[tile][c] for c in cells], 2048, sr_path),
+                  pool.submit("stitch_and_save", [raw_keep[tile][c] for c in cells], 512, s2_path, True)]
             keep.pop(tile), raw_keep.pop(tile)
-        else:
-            stitch(os.path.join(save_path, tile), 2048, os.path.join(save_path, tile, "stitched_sr.png"))
-            stitch(os.path.join(data_dir, tile), 512, os.path.join(save_path, tile, "stitched_s2.png"), sentinel2=True)
+            return fs
+        return [pool.submit("stitch_from_dir", os.path.join(save_path, tile), 2048, sr_path),
+                pool.submit("stitch_from_dir", os.path.join(data_dir, tile), 512, s2_path, True)]
 
-    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+    CH = 8                                        # files per task: amortises the hand-over to a worker
+    chunked = lambda seq: [seq[k:k + CH] for k in range(0, len(seq), CH)]
+    with png_io.PngWorkerPool(workers) as pool:
         groups = [mine[b0:b0 + batch] for b0 in range(0, len(mine), batch)]
-        reads = [pool.submit(_read_png, pngs[i]) for i in groups[0]] if groups else []
+        read_group = lambda idxs: [pool.submit("read_many", [pngs[i] for i in part]) for part in chunked(idxs)]
+        reads = read_group(groups[0]) if groups else []
         saves, stitches = [], []
         for g, idxs in enumerate(groups):
-            raw = [f.result() for f in reads]
-            reads = [pool.submit(_read_png, pngs[i]) for i in groups[g + 1]] if g + 1 < len(groups) else []
+            raw = [a for f in reads for a in f.result()]
+            reads = read_group(groups[g + 1]) if g + 1 < len(groups) else []
             inputs = [format_s2naip_data(r, n_lr_images, "cpu")[0] for r in raw]
             out = infer_chunks(model, inputs, batch=len(inputs), device=device)
-            saves += [pool.submit(save_chunk, out[k], i) for k, i in enumerate(idxs)]
+            saves += [pool.submit("save_many", [(out[k], out_path(idxs[k])) for k in part]) for part in chunked(list(range(len(idxs))))]
             done += len(idxs)
             for k, i in enumerate(idxs):          # a tile whose last chunk has just come off the device is stitched in the
                 tile, idx = pngs[i].split("/")[-2], pngs[i].split("/")[-1]      # background while the next tiles run
                 if tile in keep:
                     keep[tile][idx], raw_keep[tile][idx] = out[k], raw[k]
-                    if len(keep[tile]) == 256 and all(f"{a}_{b}.png" in keep[tile] for a in range(16) for b in range(16)):
-                        os.makedirs(os.path.join(save_path, tile), exist_ok=True)
-                        stitches.append(pool.submit(stitch_tile, tile))
+                    if len(keep[tile]) == 256 and all(c in keep[tile] for c in cells):
+                        stitches += submit_stitch(pool, tile)
                         stitched += 1
         for f in saves + stitches:
             f.result()
@@ -122,7 +122,7 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
                     continue
                 if os.path.exists(os.path.join(save_path, tile, "stitched_sr.png")) and world == 1:
                     continue
-                rest.append(pool.submit(stitch_tile, tile))      # several ranks wrote the chunks: read them back, tiles in parallel
+                rest += submit_stitch(pool, tile)      # several ranks wrote the chunks: read them back, tiles in parallel
                 stitched += 1
             for f in rest:
                 f.result()

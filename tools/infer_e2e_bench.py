@@ -43,6 +43,12 @@ def main():
         torch.cuda.synchronize()
         t_e2e = time.perf_counter() - t0
         assert res == {"chunks": 256 * n_tiles, "tiles_stitched": n_tiles}, res
+        # the same run with the PNG work on threads of this process (io_workers = 0: the first version of the driver)
+        shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
+        t0 = time.perf_counter()
+        run_infer_grid(dict(opt, io_workers=0), model=net)
+        torch.cuda.synchronize()
+        t_thr = time.perf_counter() - t0
         x = torch.rand(64, 24, 32, 32, device="cuda")
         with torch.no_grad():
             for _ in range(2):
@@ -56,8 +62,9 @@ def main():
         serial = None
         rec = {"workload": "BASELINE.json configs[4], one GPU's share: 16x16 grid of 8xS2 chunks (PNG on local disk) -> per-chunk 128x128 PNGs + "
                            "stitched_sr.png 2048x2048 + stitched_s2.png 512x512; SSR_RRDBNet(nf=64,nb=23,gc=32), random weights",
-               "compute_dtype": mode, "tiles": n_tiles, "batch": 64, "io_threads": min(16, os.cpu_count() or 4),
+               "compute_dtype": mode, "tiles": n_tiles, "batch": 64, "io_workers": max(1, min(16, os.cpu_count() or 4)), "io": "worker processes (satlas_super_resolution_amd/png_io.py); start-up included",
                "end_to_end": {"seconds_per_tile": t_e2e / n_tiles, "tiles_per_s": n_tiles / t_e2e, "chunks_per_s": 256 * n_tiles / t_e2e},
+               "end_to_end_threads": {"seconds_per_tile": t_thr / n_tiles, "tiles_per_s": n_tiles / t_thr},
                "generator_only": {"ms_per_64_chunks": 1e3 * t_model, "chunks_per_s": 64 / t_model, "tiles_per_s": 64 / t_model / 256,
                                   "tflops": 64 / t_model * 36.739 / 1e3},
                "host_cores": len(os.sched_getaffinity(0))}

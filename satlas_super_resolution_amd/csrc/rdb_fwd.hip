@@ -602,7 +602,7 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
                     // inline asm: for a volatile / atomic LDS read hipcc emits `s_waitcnt vmcnt(0)` first, which would
                     // wait for the refill loads issued a moment ago (one memory latency per slab)
                     u32x4 dn;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(RB_CTL + 4 * CTL_DONE)) : "memory");
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"((int)(RB_CTL + 4 * CTL_DONE)) : "memory");
                     if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= s_ - (RB_NSTAGE - 1)) break;
 #ifdef RB_POLL_SLEEP
                     __builtin_amdgcn_s_sleep(RB_POLL_SLEEP);

@@ -242,6 +242,9 @@ __device__ __forceinline__ unsigned long long rt_slab_src(const ssr_rdb_desc& d,
         base = k == 4 ? (unsigned long long)(uintptr_t)d.w[4] : base;
         const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j;
         const int tapblk = k == 4 ? (2 * c + h) * 9 + 3 * ky : c * 9 + 3 * ky;
+#ifdef RT_X_WCOPIES   // probe (tools/rdbt_check): the workgroups of an XCD read RT_X_WCOPIES different copies of the weights (harness allocates them back to back)
+        base += (unsigned long long)((blockIdx.x >> 3) % RT_X_WCOPIES) * (unsigned long long)((k == 4 ? 192 * 64 : (64 + 32 * k) * 32) * 18);
+#endif
         return (base + (unsigned long long)(tapblk * 2048)) | (k == 4 ? 1ull : 0ull);
     }
 #endif
@@ -711,18 +714,39 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         // (by (row >> 3) & 1); the row phase of a piece is a multiple of 16 rows, so the pattern is the same for every piece
         const int lo14 = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
         const int lo5 = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+#if defined(RT_SEL) && (RT_SEL == 2 || RT_SEL == 3)
+        int dlo = lo5 - lo14, xlo = lo5 ^ lo14;
+        rt_pin(dlo);
+        rt_pin(xlo);
+#endif
         auto load_from = [&](unsigned long long src64, u32x4 (&r)[6]) {
             rt_gptr src = (rt_gptr)(src64 & ~1ull);
-            // bit 0 of a table entry: conv5 layout.  hipcc turns this select into a table of two stack addresses (a scratch load, a
-            // flat load and s_waitcnt vmcnt(0) lgkmcnt(0) in front of every slab's loads: one slab load in flight per producer).
-            // Forms without the table were tried (r03, DESIGN.md lesson 36): `lo14 + bit * (lo5 - lo14)` compiles to one v_cndmask,
-            // keeps RT_RQ slabs in flight, passes every test - and the launch is NOT faster (32.1 us either way: the producers do
-            // not pace the block).  The same expression with its difference held in a pinned register, or an inline-asm v_cndmask,
-            // gives WRONG block outputs for the waves that own the last M-tiles in the library build (not in the stand-alone
-            // harness; not with queue depth 1 or 2; also with s_waitcnt vmcnt(0) in front of every slab's loads, so it is not the
-            // pipelining): a code-generation sensitivity of this kernel that is not understood.  Kept: the form every test of
-            // rounds 2-3 ran with; tests/test_gpu_rdb_tile.py is the guard for any rebuild.
+            // bit 0 of a table entry: conv5 layout -> this lane's offset inside a 1-KiB piece.  RT_SEL picks the form of the select:
+            //   1 (shipped): lo14 + bit * (lo5 - lo14) - one v_cndmask / v_mad, RT_RQ slabs in flight per producer;
+            //   0: `bit ? lo5 : lo14` - hipcc turns it into a table of two stack addresses (scratch load + flat load + s_waitcnt
+            //      vmcnt(0) lgkmcnt(0) in front of every slab's loads: ONE slab load in flight per producer); rounds 2-3 shipped it;
+            //   2: the difference in a pinned register, 3: XOR mask, 4: inline-asm v_cndmask.
+            // Round 3 saw forms 2-4 give wrong outputs in the library build (DESIGN.md lesson 36).  Root cause (round 4): the ring's
+            // done-poll below was a two-instruction inline asm WITHOUT early-clobber outputs; when the poll address is dead after
+            // the asm (forms 2-4 change the allocation so that it is rematerialised per poll) hipcc gave the first ds_read_b128's
+            // destination the address register, and when that read returned before the second one issued (LDS queue backed up) the
+            // second read fetched garbage "done" counts -> a producer refilled a ring stage the slowest MFMA waves were still
+            // reading.  With "=&v" all five forms are byte-identical to the 8x8 kernel (tools/rdbt_check, tests/test_gpu_rdb_stress.py).
+#ifndef RT_SEL
+#define RT_SEL 1
+#endif
+#if RT_SEL == 0
             const int lo = (src64 & 1ull) ? lo5 : lo14;
+#elif RT_SEL == 1
+            const int lo = lo14 + (int)(src64 & 1ull) * (lo5 - lo14);
+#elif RT_SEL == 2
+            const int lo = lo14 + (int)(src64 & 1ull) * dlo;
+#elif RT_SEL == 3
+            const int lo = lo14 ^ (xlo & -(int)(src64 & 1ull));
+#else
+            int lo;
+            asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=&v"(lo) : "v"(lo14), "v"(lo5), "v"((int)(src64 & 1ull)) : "vcc");
+#endif
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
         };
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         auto load_slab = [&](int q, u32x4 (&r)[6]) {
             const int qc = min(q, RT_NSLAB - 1);
             unsigned long long a;
-            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"((int)lds0 + G::SRC + 8 * qc) : "memory");
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"((int)lds0 + G::SRC + 8 * qc) : "memory");
             const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
             load_from(((unsigned long long)ahi << 32) | alo, r);
         };
@@ -776,7 +800,13 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
                 for (;;) {
                     // inline asm: a compiler-visible LDS read here would make hipcc drain the refill loads first
                     u32x4 dn, dm;
+                    // "=&v": the outputs must not share a register with the address - the first read may return before the second
+                    // one issues (lesson 36; RT_X_POLL_NOEARLY rebuilds the round-3 form for the reproduction in tools/gpu_r4a.sh)
+#ifdef RT_X_POLL_NOEARLY
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn), "=v"(dm) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
+#else
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn), "=&v"(dm) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
+#endif
                     const int dmin = (int)min(min(min(dn[0], dn[1]), min(dn[2], dn[3])), min(min(dm[0], dm[1]), min(dm[2], dm[3])));
                     if (__builtin_amdgcn_readfirstlane(dmin) >= q - (G::NST - 1)) break;
                     __builtin_amdgcn_s_sleep(RT_POLL_SLEEP);   // the ring is normally full: a poll per ~200 cycles is plenty and costs the MFMA wave of this SIMD nothing

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
             if (k >= NST) {
                 for (;;) {
                     u32x4 dn;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(C::CTL + 4 * WGC_DONE)) : "memory");
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"((int)(C::CTL + 4 * WGC_DONE)) : "memory");
                     if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= k - NST + 1) break;
                 }
             }
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
             if (k >= NST) {
                 for (;;) {
                     u32x4 dn;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dn) : "v"((int)(C::CTL + 4 * WGC_DONE)) : "memory");
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"((int)(C::CTL + 4 * WGC_DONE)) : "memory");
                     if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= k - NST + 1) break;
                 }
             }

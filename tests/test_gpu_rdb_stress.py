@@ -1,0 +1,128 @@
+"""GPU stress test of the fused dense-block kernel's LDS hand-over (csrc/rdb_tile.hip), for
+/root/reference/ssr/archs/rrdbnet_arch.py:37-44 (+ :68): thousands of launches of the 8 x 16-tile kernel at the benchmarked
+launch shape (B = 32, 32 x 32 pixels: 256 workgroups), every launch byte-compared on the device with the result of the 8 x 8
+kernel (which the layer-local oracle tests pin), alone and while a second stream keeps the CUs / L2 / HBM busy.
+
+Why it exists (DESIGN.md lesson 36, closed in round 4): the producers' ring poll was a two-instruction inline asm without
+early-clobber outputs; in some builds hipcc gave the first `ds_read_b128` the poll's ADDRESS register as destination, and
+whenever that read returned before the second one issued, the second one read garbage "done" counters and a producer refilled
+a ring stage that the slowest MFMA waves were still reading -> wrong bytes in the last M-tiles of a few tiles, rarely.  One
+launch per shape (tests/test_gpu_rdb_tile.py) catches a build in which that is frequent; this test is the guard for "rare".
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CS = 192
+N, H, W = 32, 32, 32
+LAUNCHES = int(os.environ.get("SSR_STRESS_LAUNCHES", "2500"))      # per direction and per load condition: 4 x 2500 = 10 000
+
+
+def _desc(hip, b, bwd, r2, cur, out, dcur):
+    from satlas_super_resolution_amd.hip import RdbDesc, View
+    d = RdbDesc()
+    d.dtype, d.N, d.H, d.W = hip.BF16, N, H, W
+    v = lambda t: View(t.data_ptr(), CS, 0)
+    if not bwd:
+        d.inp, d.slices, d.out, d.mask = v(cur), v(cur), v(out), hip.NULL_VIEW
+        for k in range(5):
+            d.w[k] = b["w"][0][k].data_ptr()
+            d.bias[k] = b["bias"][k].data_ptr()
+        d.alpha5, d.beta1 = (0.04, 0.2) if r2 else (0.2, 1.0)
+    else:
+        d.inp, d.slices, d.out, d.mask = v(b["dout"]), v(dcur), v(dcur), v(cur)
+        for k in range(5):
+            d.w[k] = b["w"][1][k].data_ptr()
+            d.bias[k] = None
+        d.alpha5, d.beta1 = 1.0, (0.2 if r2 else 1.0)
+    d.r2, d.beta2 = (v(b["r2"]), 1.0) if r2 else (hip.NULL_VIEW, 0.0)
+    return d
+
+
+def _bufs(seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dev = torch.device("cuda:0")
+
+    def rnd(*shape, amp=1.0):
+        return ((torch.rand(*shape, generator=g) * 2 - 1) * amp).to(torch.bfloat16).to(dev)
+    cin, cp = (64, 96, 128, 160, 192), (32, 32, 32, 32, 64)
+    return dict(cur=rnd(N, H, W, CS), dout=rnd(N, H, W, CS), r2=rnd(N, H, W, CS),
+                w=[[rnd(cin[k] * 9 * cp[k], amp=0.06) for k in range(5)] for _ in range(2)],
+                bias=[((torch.rand(64, generator=g) * 2 - 1) * 0.1).to(dev) for _ in range(5)])
+
+
+def _side_load(side, ev_stop_after):
+    """Work for the second stream: alternating MFMA-heavy (a torch matmul: any other kernel would do, it is only a disturbance)
+    and HBM-heavy (a 256 MB copy) launches; returns a callable that enqueues one more round."""
+    a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    bm = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    big = torch.empty(64 * 1024 * 1024, device="cuda", dtype=torch.float32)
+    big2 = torch.empty_like(big)
+    state = {"k": 0}
+
+    def more():
+        with torch.cuda.stream(side):
+            if state["k"] & 1:
+                big2.copy_(big, non_blocking=True)
+            else:
+                torch.mm(a, bm)
+        state["k"] += 1
+    return more
+
+
+@pytest.mark.parametrize("loaded", [False, True], ids=["alone", "second_stream_busy"])
+def test_thousands_of_wide_tile_launches_match_the_8x8_kernel(loaded):
+    from satlas_super_resolution_amd import hip
+    lib = hip.lib()
+    b = _bufs(seed=4242 + int(loaded))
+    r2 = True
+    cur0 = b["cur"]
+    zeros = torch.zeros_like(cur0)
+    prev = lib.ssr_rdb_set_tile(0)
+    try:
+        # reference: the 8 x 8 kernel, once per direction
+        cur_ref, out_ref, dcur_ref = cur0.clone(), zeros.clone(), zeros.clone()
+        assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None)), None) == 0
+        torch.cuda.synchronize()
+        assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcur_ref)), None) == 0
+        torch.cuda.synchronize()
+        assert float(out_ref.float().abs().max()) > 0.1 and float(dcur_ref.float().abs().max()) > 0.1
+        lib.ssr_rdb_set_tile(16)
+        assert lib.ssr_rdb_tile_of(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None))) == 16
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        more = _side_load(side, None) if loaded else None
+        # three rotating target sets so that a launch never waits for the previous comparison
+        NSET = 3
+        curs = [cur0.clone() for _ in range(NSET)]
+        outs = [zeros.clone() for _ in range(NSET)]
+        dcurs = [zeros.clone() for _ in range(NSET)]
+        bad = torch.zeros(4, device="cuda", dtype=torch.int64)     # fwd slices, fwd out, bwd, launches counted
+        ref_s, ref_o, ref_g = cur_ref.view(torch.int16), out_ref.view(torch.int16), dcur_ref.view(torch.int16)
+        sp = main.cuda_stream
+        for it in range(LAUNCHES):
+            k = it % NSET
+            if loaded and it % 8 == 0:
+                more()
+            curs[k].copy_(cur0)
+            outs[k].zero_()
+            dcurs[k].zero_()
+            assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, curs[k], outs[k], None)), sp) == 0
+            # the backward takes the REFERENCE forward activations as masks (its own correctness is what is under test)
+            assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcurs[k])), sp) == 0
+            bad[0] += (curs[k].view(torch.int16) != ref_s).sum()
+            bad[1] += (outs[k].view(torch.int16) != ref_o).sum()
+            bad[2] += (dcurs[k].view(torch.int16) != ref_g).sum()
+            bad[3] += 1
+        torch.cuda.synchronize()
+        nb = bad.cpu().tolist()
+        assert nb[3] == LAUNCHES
+        assert nb[:3] == [0, 0, 0], (f"{LAUNCHES} forward + {LAUNCHES} backward launches of the 8x16 kernel "
+                                      f"({'with' if loaded else 'without'} a busy second stream): differing bf16 values "
+                                      f"x1..x4 {nb[0]}, block output {nb[1]}, dpre/dx {nb[2]}")
+    finally:
+        lib.ssr_rdb_set_tile(prev)

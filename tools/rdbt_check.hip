@@ -52,8 +52,14 @@ static Bufs make(int N, int H, int W) {
     for (int f = 0; f < 2; ++f)
         for (int k = 0; k < 5; ++k) {
             const size_t n = (size_t)cin[k] * 9 * cp[k];
+#ifdef RT_X_WCOPIES   // probe: RT_X_WCOPIES identical copies back to back (the kernel deals them to the workgroups of an XCD)
+            hipMalloc(&b.w[f][k], n * 2 * RT_X_WCOPIES);
+            fill_dev(b.w[f][k], n, 0.06f);
+            for (int cpy = 1; cpy < RT_X_WCOPIES; ++cpy) hipMemcpy(b.w[f][k] + n * cpy, b.w[f][k], n * 2, hipMemcpyDeviceToDevice);
+#else
             hipMalloc(&b.w[f][k], n * 2);
             fill_dev(b.w[f][k], n, 0.06f);
+#endif
         }
     for (int k = 0; k < 5; ++k) {
         std::vector<float> h(64);
@@ -277,7 +283,8 @@ int main(int argc, char** argv) {
 #endif
 #ifdef SSR_PROBE
     if (!strcmp(mode, "probe")) {
-        for (int tile : {16, 8}) for (int bwd = 0; bwd < 2; ++bwd) probe_case(32, tile, bwd);
+        const int pn = argc > 2 ? atoi(argv[2]) : 32;
+        for (int bwd = 0; bwd < 2; ++bwd) probe_case(pn, 16, bwd);
         return 0;
     }
 #endif

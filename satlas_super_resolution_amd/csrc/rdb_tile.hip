@@ -56,6 +56,13 @@
 #define TRACE(ev, arg)
 #endif
 
+#ifndef RT_INTERLEAVE5
+#define RT_INTERLEAVE5 0   // 1: conv5's chunks spread over the growth stages (r03 / r04: measured 1-3 us slower per launch); 0: conv5 after conv4
+#endif
+#ifndef RT_C5_DEEP
+#define RT_C5_DEEP 1       // conv5's slabs alternate between the ring and four extra stages in dead rows of x (RtGeo::C5X)
+#endif
+
 namespace {
 
 // LDS accesses by 32-bit LDS address (address space 3): the operand addresses are per-lane integers (XOR swizzle), and a
@@ -96,6 +103,26 @@ template <int TW> struct RtGeo {
     static constexpr int TROW = 80;               // output transpose slab: [32 px][32 co] bf16, 80-B rows, one per wave
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(NST * RT_SLAB >= RT_NCONS * 32 * TROW, "ring doubles as the output transpose slabs");
+    // ---- conv5's deeper ring (round 4).  conv5 consumes a 6-KB slab per 3 k-steps and wave (the growth convs: per 6 .. 18), and
+    // what it waited for was the HAND-OVER, not the weights: with the producers' global loads removed (-DRT_X_NOWLOAD) it
+    // still took 15.3 k of its 7.7 k no-hand-over ticks (a refill = poll + six ds_write_b128 + flag ~ 850 ticks against
+    // 3 x 214 ticks of work in the other three stages).  Once every wave is past the two x chunks of conv4 (slab 32), frame rows
+    // 0..3 and 14..17 of x are dead: conv5 reads rows 4..13 only.  Four more stages live there:
+    //   X0: plane 0 rows 0..3 | X1, X2: plane 0 rows 14..17 + plane 1 rows 0..3 (contiguous) | X3: plane 1 rows 14..17
+    // conv5 slab q (q >= 42) uses ring stage q % 4 when q % 8 < 4 and extra stage q % 4 otherwise: each producer still owns the
+    // slabs q = p (mod 4), now with two places to put them.
+    static constexpr bool C5X = TW == 16 && !RT_INTERLEAVE5 && RT_C5_DEEP;
+    static constexpr int XROWS = 4 * RW0 * 64;                 // four frame rows of one plane
+    static_assert(!C5X || XROWS >= RT_SLAB, "an extra stage fits four dead rows");
+    static constexpr int xstage(int e) { return e == 0 ? ACT : e == 1 ? ACT + 14 * RW0 * 64 : e == 2 ? ACT + 14 * RW0 * 64 + RT_SLAB : ACT + PLANE + 14 * RW0 * 64; }
+    static_assert(!C5X || (pitch(0) == RW0 && xstage(2) + RT_SLAB <= ACT + PLANE + 4 * RW0 * 64 && xstage(3) + RT_SLAB <= ACT + 2 * PLANE), "extra stages stay inside dead rows");
+    static constexpr int Q5 = 42;                               // first conv5 slab
+    static constexpr int QXFREE = 33;                           // every wave has released slab 32 = rt_qg(4, 1, 2): rows 3 / 14 of x are dead
+    static constexpr bool is_extra(int q) { return C5X && q >= Q5 + 2 && (q & 4) != 0; }
+    // physical place of slab q: LDS offset, index of its ready word (ring 0..3 / 0..7, extra 4..7), and the slab that used the place before
+    static constexpr int stage_off(int q) { return is_extra(q) ? xstage(q & 3) : RING + (q % NST) * RT_SLAB; }
+    static constexpr int stage_word(int q) { return is_extra(q) ? 4 + (q & 3) : q % NST; }
+    static constexpr int XB = 49152;                            // second base for DS immediates beyond 64 KB
     // M-tiles (32 pixels) per stage
     static constexpr int ntiles(int K) {
         return TW == 16 ? (K == 1 ? 12 : K == 2 ? 10 : K == 3 ? 8 : K == 4 ? 6 : 4) : (K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2);
@@ -203,9 +230,6 @@ __device__ __forceinline__ int rt_f(int Y, int X) { return ((2 * Y + X) >> 2) & 
 //      needs the slice the previous stage has just produced: a wave that is early has work that does not wait for the others.
 //      The order of conv5's contraction (chunk, half, row, column) is unchanged.  A slab = one kernel row (3 taps) of one
 //      32-channel chunk (conv5: of one 16-channel half chunk); slab numbers run in this order.
-#ifndef RT_INTERLEAVE5
-#define RT_INTERLEAVE5 0   // 1: conv5's chunks spread over the growth stages (r03: measured 1-3 us slower per launch); 0: conv5 after conv4
-#endif
 #if RT_INTERLEAVE5
 constexpr int rt_ebase(int E) { return E == 1 ? 0 : E == 2 ? 12 : E == 3 ? 27 : E == 4 ? 45 : 66; }
 constexpr int rt_qg(int K, int j, int ky) { return K == 1 ? 3 * j + ky : rt_ebase(K) + (j < K ? 3 * j + ky : 3 * K + 6 + ky); }
@@ -322,6 +346,7 @@ struct RtCtx {            // what every stage needs
     int prank;            // rank of this wave among the waves that take part in the current stage
     int wb0, wb1;         // this lane's weight-fragment offsets inside a conv1..4 slab (k-substep 0 / 1), relative to the ring
     int wb5;              // ... inside a conv5 slab (N-tile 0)
+    int wb5x;             // wb5 + RtGeo::XB (the extra stage beyond the reach of a 16-bit DS immediate)
     int hint;             // ready counter of the next slab's ring stage, sampled two k-steps ahead
     unsigned ctlv;        // LDS address of the control words (pinned register: flag accesses are base + immediate)
     unsigned donev;       // LDS address of this wave's done word
@@ -330,10 +355,10 @@ struct RtCtx {            // what every stage needs
 #endif
 };
 template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
-    // slab q is the (q / NST + 1)-th user of stage q % NST; the stage's word counts the slabs its producer has published
-    // (the producer cannot publish slab q + NST before every consumer has released slab q, so the count is exact)
+    // the ready word of a slab's place (RtGeo::stage_word) holds 1 + the number of the newest slab published there; a later slab
+    // cannot be published in the place before every consumer has released slab q, so "word >= q + 1" means "slab q is there"
     using G = RtGeo<TW>;
-    const int target = q / G::NST + 1;
+    const int target = q + 1;
 #ifdef RT_X_NOSYNC   // probe: no hand-over (wrong results)
     return;
 #endif
@@ -342,7 +367,7 @@ template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
 #ifdef SSR_PROBE   // slots 14 / 15 of thread 0's probe row: ticks spent polling for slabs, number of slabs that had to wait
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        while (rt_ld(c.ctl + ctl_ready(q % G::NST)) < target) __builtin_amdgcn_s_sleep(1);   // leave the issue slots to the producer wave of this SIMD
+        while (rt_ld(c.ctl + ctl_ready(G::stage_word(q))) < target) __builtin_amdgcn_s_sleep(1);   // leave the issue slots to the producer wave of this SIMD
 #ifdef SSR_PROBE
         c.wait_ticks += __builtin_amdgcn_s_memtime() - t0;
         c.wait_n += 1;
@@ -351,7 +376,7 @@ template <int TW> __device__ __forceinline__ void rt_acquire(RtCtx& c, int q) {
     }
 }
 template <int TW> __device__ __forceinline__ void rt_sample(RtCtx& c, int q) {
-    c.hint = __hip_atomic_load((const RT_LDS int*)(uintptr_t)(c.ctlv + 4 * ctl_ready(q % RtGeo<TW>::NST)), __ATOMIC_RELAXED,
+    c.hint = __hip_atomic_load((const RT_LDS int*)(uintptr_t)(c.ctlv + 4 * ctl_ready(RtGeo<TW>::stage_word(q))), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void rt_release(RtCtx& c, int upto) {   // this wave is finished with every slab < upto
@@ -531,7 +556,7 @@ __device__ __forceinline__ void rt_grow_run(RtCtx& c, RtGrow<NMT>& st) {
         constexpr int S = j < 2 ? 0 : j - 1, plane = j < 2 ? j : 0;
         constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
         if constexpr (part == 0) {
-            bq[n % NB] = rt_lds_read<u32x4>((kk ? c.wb1 : c.wb0) + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048));
+            bq[n % NB] = rt_lds_read<u32x4>((kk ? c.wb1 : c.wb0) + (G::stage_off(q) + kx * 2048));
         } else {
             constexpr int m = part - 1;
             aq[n % NB][m] = rt_lds_read<u32x4>((kk ? A1[m][t] : A0[m][t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
@@ -621,7 +646,8 @@ __device__ __forceinline__ void rt_c5_run(RtCtx& c, f32x16& acc, int e5) {
         }
         if constexpr (kx == 0) rt_acquire<TW>(c, q);
         constexpr int t = 2 * (ky - 1) + (kx - 1) + 3;
-        bq[n % NB] = rt_lds_read<u32x4>(c.wb5 + (G::RING + (q % G::NST) * RT_SLAB + kx * 2048));
+        if constexpr (G::stage_off(q) + kx * 2048 + 6144 > 65535) bq[n % NB] = rt_lds_read<u32x4>(c.wb5x + (G::stage_off(q) - G::XB + kx * 2048));   // DS immediates are 16 bits
+        else bq[n % NB] = rt_lds_read<u32x4>(c.wb5 + (G::stage_off(q) + kx * 2048));
         aq[n % NB] = rt_lds_read<u32x4>((h ? A1[t] : A0[t]) + (plane * G::PLANE + 64 * (ky * G::pitch(S) + kx)));
         if constexpr (kx == 1 && n + 2 < N1) rt_sample<TW>(c, rt_q5((n + 2) / 18, ((n + 2) % 18) / 9, (((n + 2) % 18) % 9) / 3));
         if constexpr (kx == 2) rt_release(c, q + 1);
@@ -747,8 +773,13 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             int lo;
             asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=&v"(lo) : "v"(lo14), "v"(lo5), "v"((int)(src64 & 1ull)) : "vcc");
 #endif
+#ifdef RT_X_NOWLOAD   // probe: the whole hand-over protocol without the weight loads (wrong results): what is left is the ring, not the L2
+#pragma unroll
+            for (int e = 0; e < 6; ++e) r[e] = u32x4{(unsigned)lo, 0u, 0u, (unsigned)(uintptr_t)src};
+#else
 #pragma unroll
             for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(src + lo + e * 1024);
+#endif
         };
         // a slab's source comes from the LDS table (beyond the end: the last slab again, never stored)
         auto load_slab = [&](int q, u32x4 (&r)[6]) {
@@ -796,6 +827,10 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             RT_PT(tp0);
             TRACE(4, q);
 #ifndef RT_X_NOSYNC
+            // the place of slab q is free once every MFMA wave has released the slab that was there before: q - NST in the ring;
+            // conv5 (C5X): q - 4 for its first two slabs (ring), "x rows dead" for the first four of the extra stages, then q - 8
+            int need = q - (G::NST - 1);
+            if (G::C5X && q >= G::Q5 + 2) need = q < G::Q5 + 6 ? G::QXFREE : q - 7;
             if (q >= G::NST) {
                 for (;;) {
                     // inline asm: a compiler-visible LDS read here would make hipcc drain the refill loads first
@@ -808,7 +843,7 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn), "=&v"(dm) : "v"((int)lds0 + (int)(G::CTL + 4 * RT_CTL_DONE)) : "memory");
 #endif
                     const int dmin = (int)min(min(min(dn[0], dn[1]), min(dn[2], dn[3])), min(min(dm[0], dm[1]), min(dm[2], dm[3])));
-                    if (__builtin_amdgcn_readfirstlane(dmin) >= q - (G::NST - 1)) break;
+                    if (__builtin_amdgcn_readfirstlane(dmin) >= need) break;
                     __builtin_amdgcn_s_sleep(RT_POLL_SLEEP);   // the ring is normally full: a poll per ~200 cycles is plenty and costs the MFMA wave of this SIMD nothing
                 }
             }
@@ -816,9 +851,16 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             RT_PT(tp1);
             TRACE(5, q);
             const int st = q % G::NST;
+            const bool extra = G::C5X && q >= G::Q5 + 2 && (q & 4) != 0;
+            int off = st * RT_SLAB, word = st;
+            if (extra) {
+                off = (q & 3) == 0 ? G::xstage(0) : (q & 3) == 1 ? G::xstage(1) : (q & 3) == 2 ? G::xstage(2) : G::xstage(3);
+                off -= G::RING;
+                word = 4 + (q & 3);
+            }
 #pragma unroll
-            for (int e = 0; e < 6; ++e) rt_lds_write<u32x4>(stv + st * RT_SLAB + e * 1024, r[e]);
-            rt_lds_write<int>(flagv + (lane == 0 ? 4 * ctl_ready(0) + 4 * st : 0), q / G::NST + 1);
+            for (int e = 0; e < 6; ++e) rt_lds_write<u32x4>(stv + off + e * 1024, r[e]);
+            rt_lds_write<int>(flagv + (lane == 0 ? 4 * ctl_ready(0) + 4 * word : 0), q + 1);
             asm volatile("" ::: "memory");
             TRACE(6, q);
             RT_PT(tp2);
@@ -880,13 +922,14 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
     const int bsw = (i >> 2) & 3;
     RtCtx c{d, lds0, ctl, bias_lds, n, ty0, tx0, tid, lane, wave, i, g, 0,
             (int)lds0 + i * 64 + ((g ^ bsw) << 4), (int)lds0 + i * 64 + (((g ^ bsw) ^ 2) << 4),
-            (int)lds0 + nt5 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4), 0, lds0 + G::CTL,
+            (int)lds0 + nt5 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4), (int)lds0 + nt5 * 1024 + i * 32 + ((g ^ ((i >> 3) & 1)) << 4) + G::XB, 0, lds0 + G::CTL,
             lane == 0 ? lds0 + G::CTL + 4 * (RT_CTL_DONE + wave) : lds0 + G::SCR + 4 * lane};
     rt_pin(c.ctlv);
     rt_pin(c.donev);
     rt_pin(c.wb0);
     rt_pin(c.wb1);
     rt_pin(c.wb5);
+    if constexpr (G::C5X) rt_pin(c.wb5x);
     // forward : out = alpha5*(conv5 + b5) + beta1*x + beta2*x_rrdb               (rrdbnet_arch.py:44, :68)
     // backward: d x = gathered dgrad (alpha5 = 1, conv5's scale is folded into the packed weights)
     //                 + beta1*d_out + beta2*d_out_rrdb

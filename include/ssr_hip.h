@@ -144,15 +144,15 @@ typedef struct ssr_rdb_desc {
      * stream (479 KB, re-read by all 256 blocks) hits L2 instead of the Infinity Cache / HBM. */
     const void* w_next[5];
     int32_t w_next_bytes[5];
+    /* which kernel runs THIS launch: 0 = automatic (SSR_RDB_TILE from the environment, else the 8 x 16 tiles of csrc/rdb_tile.hip
+     * when the launch gives (nearly) every CU a workgroup, else the 8 x 8 tiles of csrc/rdb_fwd.hip), 8 = 8 x 8 tiles, 16 = 8 x 16
+     * tiles.  Both kernels add the same products in the same order: their results are bit-identical (tests/test_gpu_rdb_tile.py,
+     * tests/test_gpu_rdb_stress.py).  A per-descriptor field, not library state: two plans may share the library. */
+    int32_t tile;
 } ssr_rdb_desc;
 int ssr_rdb_forward(const ssr_rdb_desc* d, void* stream);
 int ssr_rdb_backward(const ssr_rdb_desc* d, void* stream);
-/* Which kernel the two entry points above run: -1 = automatic (the default: SSR_RDB_TILE from the environment, else 8 x 16
- * tiles of csrc/rdb_tile.hip when the launch gives (nearly) every CU a workgroup, else the 8 x 8 tiles of csrc/rdb_fwd.hip),
- * 0 = 8 x 8 tiles, 16 = 8 x 16 tiles.  Both kernels add the same products in the same order: their results are bit-identical
- * (tests/test_gpu_rdb_tile.py).  Returns the previous setting. */
-int ssr_rdb_set_tile(int32_t tile);
-/* the kernel ssr_rdb_forward / ssr_rdb_backward would run for this descriptor now: 0 = 8 x 8 tiles, 16 = 8 x 16 tiles */
+/* the kernel ssr_rdb_forward / ssr_rdb_backward run for this descriptor: 8 = 8 x 8 tiles, 16 = 8 x 16 tiles */
 int ssr_rdb_tile_of(const ssr_rdb_desc* d);
 
 /*
@@ -252,9 +252,10 @@ int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_
 /* s1 = bilinear2x^T(dy) (+ r if r.p) -> y1 (optional); y = s1 * lrelu'(m) (m optional) */
 int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,
                        int32_t H, int32_t W, int32_t C, void* stream);
-/* 1: per-pixel kernels for every shape; 0 (default): layers whose channels are whole groups of eight 16-byte vectors (64 in
- * bf16, 32 in fp32 storage) use the LDS-tile kernels (same arithmetic, same order: identical bytes in bf16).  Returns the previous setting.  Environment: SSR_BILINEAR_FLAT=1. */
-int32_t ssr_bilinear_set_flat(int32_t on);
+/* OR-ed into `dtype` of the two calls above: the per-pixel kernels for this call whatever the shape.  Default: layers whose
+ * channels are whole groups of eight 16-byte vectors (64 in bf16, 32 in fp32 storage) use the LDS-tile kernels (same arithmetic,
+ * same order: identical bytes in bf16).  A per-call flag, not library state.  Environment (read once): SSR_BILINEAR_FLAT=1. */
+#define SSR_BILINEAR_FLAT 0x100
 /* nearest x2 backward (2x2 sum) with the same epilogue: rrdbnet_arch.py:127-128 backward */
 int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N,
                       int32_t H, int32_t W, int32_t C, void* stream);

@@ -806,16 +806,14 @@ extern "C" int ssr_fill(void* p, int64_t n, int32_t dtype, float value, void* st
     return SSR_OK;
 }
 
-// SSR_BILINEAR_FLAT=1: the per-pixel kernels for every shape (A/B of the LDS-tile kernels; read once)
-static bool g_bilinear_flat = [] { const char* e = getenv("SSR_BILINEAR_FLAT"); return e && e[0] == '1'; }();
-extern "C" int32_t ssr_bilinear_set_flat(int32_t on) {   // returns the previous setting (tests: tile kernels against per-pixel kernels)
-    const int32_t prev = g_bilinear_flat ? 1 : 0;
-    g_bilinear_flat = on != 0;
-    return prev;
-}
+// SSR_BILINEAR_FLAT=1 in the environment (read once) or SSR_BILINEAR_FLAT OR-ed into a call's dtype: the per-pixel kernels for
+// every shape (A/B of the LDS-tile kernels)
+static const bool g_bilinear_flat_env = [] { const char* e = getenv("SSR_BILINEAR_FLAT"); return e && e[0] == '1'; }();
 
 extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dtype, int32_t N, int32_t H, int32_t W,
                                   int32_t C, void* stream) {
+    const bool g_bilinear_flat = g_bilinear_flat_env || (dtype & SSR_BILINEAR_FLAT) != 0;
+    dtype &= ~SSR_BILINEAR_FLAT;
     if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!a.p || !y.p || (C % 8) != 0 || (a.cs % 8) || (a.coff % 8) || (y.cs % 8) || (y.coff % 8) ||
         (b.p && ((b.cs % 8) || (b.coff % 8))))
@@ -841,6 +839,8 @@ extern "C" int ssr_bilinear2x_fwd(ssr_view a, ssr_view b, ssr_view y, int32_t dt
 template <int MODE>
 static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype, int32_t N, int32_t H,
                     int32_t W, int32_t C, void* stream) {
+    const bool g_bilinear_flat = g_bilinear_flat_env || (dtype & SSR_BILINEAR_FLAT) != 0;
+    dtype &= ~SSR_BILINEAR_FLAT;
     if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!dy.p || (!y.p && !y1.p) || (C % 8) != 0 || (dy.cs % 8) || (dy.coff % 8)) return SSR_EINVAL;
     const long total = (long)N * H * W * C / 4;
@@ -862,7 +862,6 @@ static int up2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m
 }
 extern "C" int ssr_bilinear2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,
                                   int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
-    if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     return up2x_bwd<0>(dy, r, y1, y, m, dtype, N, H, W, C, stream);
 }
 extern "C" int ssr_nearest2x_bwd(ssr_view dy, ssr_view r, ssr_view y1, ssr_view y, ssr_view m, int32_t dtype,

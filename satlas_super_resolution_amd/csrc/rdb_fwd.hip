@@ -740,20 +740,20 @@ __global__ __launch_bounds__(RB_NTHREADS) void rdb_kernel(const ssr_rdb_desc d) 
 
 // second-generation kernel (csrc/rdb_tile.hip): 8 x 16 or 8 x 8 tiles, swizzled rows, 6-KB slab ring
 int rdbt_launch(const ssr_rdb_desc& d, void* stream, bool bwd, int tw);
-// Tile choice.  SSR_RDB_TILE = 0: this file's kernel (8x8 tiles, 80-byte rows); 16: csrc/rdb_tile.hip (8x16 tiles);
-// unset / "auto": 8x16 tiles when they still give (nearly) every CU a workgroup (one workgroup owns a CU: 160 KB of LDS).
-int g_rdb_tile_override = -1;   // tools / tests: >= 0 overrides the environment
+// Tile choice: ssr_rdb_desc.tile = 8: this file's kernel (8x8 tiles, 80-byte rows); 16: csrc/rdb_tile.hip (8x16 tiles); 0: automatic =
+// SSR_RDB_TILE from the environment (8 / 16; read once), else 8x16 tiles when they still give (nearly) every CU a workgroup (one
+// workgroup owns a CU: 160 KB of LDS).  The choice travels in the descriptor: no library-global switch.
 static int rdb_pick_tile(const ssr_rdb_desc& d) {
-    static int env = -2;
-    if (env == -2) {
+    static const int env = [] {
         const char* e = getenv("SSR_RDB_TILE");
-        env = (e && *e && *e != 'a') ? atoi(e) : -1;
-    }
-    const int choice = g_rdb_tile_override >= 0 ? g_rdb_tile_override : env;
-    if (choice == 0 || choice == 16) return choice;
+        const int v = (e && *e && *e != 'a') ? atoi(e) : -1;
+        return v == 0 ? 8 : v;                       // "0" (rounds 2-3) = the 8 x 8 kernel
+    }();
+    const int choice = (d.tile == 8 || d.tile == 16) ? d.tile : env;
+    if (choice == 8 || choice == 16) return choice;
     // 8 x 16 tiles want a workgroup for (nearly) every CU; below that the 8 x 8 tiles of this file fill the chip better
     const int t16 = d.N * ((d.H + 7) / 8) * ((d.W + 15) / 16);
-    return t16 >= 192 ? 16 : 0;
+    return t16 >= 192 ? 16 : 8;
 }
 
 static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
@@ -767,7 +767,7 @@ static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     if (d.r2.p && ((d.r2.cs % 4) || (d.r2.coff % 4))) return SSR_EINVAL;
     for (int k = 0; k < 5; ++k)
         if (!d.w[k]) return SSR_EINVAL;
-    if (const int tw = rdb_pick_tile(d)) return rdbt_launch(d, stream, bwd, tw);
+    if (rdb_pick_tile(d) == 16) return rdbt_launch(d, stream, bwd, 16);
     static bool attr_done[2] = {false, false};
     const void* kern = bwd ? reinterpret_cast<const void*>(rdb_kernel<true>) : reinterpret_cast<const void*>(rdb_kernel<false>);
     if (!attr_done[bwd]) {
@@ -782,11 +782,6 @@ static int rdb_launch(const ssr_rdb_desc* dp, void* stream, bool bwd) {
     return SSR_OK;
 }
 
-extern "C" int ssr_rdb_set_tile(int32_t tile) {
-    const int prev = g_rdb_tile_override;
-    g_rdb_tile_override = (tile == 0 || tile == 16) ? tile : -1;
-    return prev;
-}
 extern "C" int ssr_rdb_tile_of(const ssr_rdb_desc* d) { return d ? rdb_pick_tile(*d) : SSR_EINVAL; }
 extern "C" int ssr_rdb_forward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, false); }
 extern "C" int ssr_rdb_backward(const ssr_rdb_desc* dp, void* stream) { return rdb_launch(dp, stream, true); }

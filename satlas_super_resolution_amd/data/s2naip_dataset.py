@@ -146,23 +146,26 @@ class S2NAIPDataset(data.Dataset):
         return self.data_len
 
 
-def build_train_loader(dataset: S2NAIPDataset, opt: Dict, tile_weights_path: str = None, rank: int = 0, world: int = 1):
+def build_train_loader(dataset: S2NAIPDataset, opt: Dict, tile_weights_path: str = None, rank: int = 0, world: int = 1,
+                       seed: int = None):
     """The loader ssr/train.py builds (create_train_val_dataloader): batch_size_per_gpu samples per rank, num_worker_per_gpu worker
     processes, the tile-weight sampler when `tile_weights` is given; pinned uint8 batches so that feed_data's upload is one
-    asynchronous copy."""
+    asynchronous copy.  `seed` is the option file's top-level `manual_seed` (`opt` here is the dataset sub-dict, which does not
+    carry it): None = unseeded, as in the reference (options.py:79-82 seeds rank r with manual_seed + r only when a seed is set)."""
     sampler = None
     if tile_weights_path or opt.get("tile_weights"):
         with open(tile_weights_path or opt["tile_weights"]) as f:
             sampler = dataset.get_tile_weight_sampler(json.load(f))
-        if world > 1:
+        if seed is not None:
             # the weighted sampler draws from numpy's global generator: every rank its own stream (options.py:79-82 seeds
-            # rank r with manual_seed + r), so that the ranks do not draw the same tiles
-            np.random.seed((int(opt.get("manual_seed", 0) or 0) + rank) % (2 ** 32))
+            # rank r with manual_seed + r), so that the ranks do not draw the same tiles; without a configured seed numpy stays
+            # unseeded at every world size (each process then has its own entropy)
+            np.random.seed((int(seed) + rank) % (2 ** 32))
     elif world > 1:
         # data parallel: every rank iterates its own share of the dataset (BasicSR builds an EnlargedSampler(train_set, world,
         # rank, ratio); DistributedSampler is the same partition at ratio 1), reshuffled per epoch through set_epoch()
         sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=bool(opt.get("use_shuffle", False)),
-                                                      seed=int(opt.get("manual_seed", 0) or 0), drop_last=True)
+                                                      seed=int(seed) if seed is not None else 0, drop_last=True)
     return data.DataLoader(dataset, batch_size=int(opt["batch_size_per_gpu"]), shuffle=bool(opt.get("use_shuffle", False)) and sampler is None,
                            sampler=sampler, num_workers=int(opt.get("num_worker_per_gpu", 0)), drop_last=True,
                            pin_memory=torch.cuda.is_available(), persistent_workers=int(opt.get("num_worker_per_gpu", 0)) > 0)

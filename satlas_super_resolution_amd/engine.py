@@ -424,6 +424,19 @@ def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View,
     L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad-gather {prefix}.slice{k}")
 
 
+_CUS = None
+
+
+def _device_cus():
+    """(compute units, XCDs) of the current device.  The XCD count is not in the device properties: 8 for the 256-CU MI300/MI355
+    family (32 CUs per XCD), else one L2 domain is assumed (the XCD-aware item order is a speed hint only)."""
+    global _CUS
+    if _CUS is None:
+        n = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+        _CUS = (int(n), 8 if n % 32 == 0 and n >= 64 else 1)
+    return _CUS
+
+
 class WgradBatch:
     """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride).
 
@@ -466,7 +479,15 @@ class WgradBatch:
     # fetch rate (~12.5 B/clk per CU) bounds both kinds of item, so a single costs 3/4 of a pair for at most half of its products
     COST_TILE = {2: 5900, 1: 4300}
     COST_WRITEOUT = 25000
-    N_CU = 256
+
+    @property
+    def N_CU(self):
+        """compute units of the device the launch will run on (MI355X: 256) - from the device properties, not a constant"""
+        return _device_cus()[0]
+
+    @property
+    def N_XCD(self):
+        return _device_cus()[1]
 
     def _cost(self, it):
         nco = max(1, it.nco)
@@ -523,7 +544,6 @@ class WgradBatch:
                 out.append(g[-1])
         return out
 
-    N_XCD = 8
 
     def _xcd_order(self, items):
         """Workgroup b runs on XCD b % 8 and every XCD has its own L2.  Items that read the same input buffer over the same
@@ -768,7 +788,18 @@ class GeneratorPlan:
             if n_seg > 1:
                 wgb.launch(Bk)                      # in line: the segment ends when its weight gradients are final
                 lo = st.offsets[next_first_key][0] if next_first_key else 0
-                self.bwd_segments.append((Bk, lo, seg_state["hi"] - lo))
+                hi = seg_state["hi"]
+                # the slice [lo, hi) of the gradient arena is what the caller exchanges behind this segment: it must be non-empty
+                # and hold EVERY gradient this segment's batch writes (arena order = backward walk from the end; a spec order
+                # that stopped matching it would all-reduce the wrong slice silently)
+                assert 0 <= lo < hi <= st.numel, (next_first_key, lo, hi)
+                g0, esz = st.grad.data_ptr(), st.grad.element_size()
+                for Lw in wgb.layers:
+                    for ptr in (Lw.dw, Lw.db):
+                        if ptr:
+                            off = (int(ptr) - g0) // esz
+                            assert lo <= off < hi, f"weight gradient at arena offset {off} outside its segment [{lo}, {hi})"
+                self.bwd_segments.append((Bk, lo, hi - lo))
                 seg_state["hi"] = lo
                 Bk = Launcher()
             else:

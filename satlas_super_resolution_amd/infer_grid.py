@@ -97,6 +97,7 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
         read_group = lambda idxs: [pool.submit("read_many", [pngs[i] for i in part]) for part in chunked(idxs)]
         reads = read_group(groups[0]) if groups else []
         saves, stitches = [], []
+        stitched_now = set()                      # tiles stitched in THIS run (a stitched_sr.png on disk may be a stale one)
         for g, idxs in enumerate(groups):
             raw = [a for f in reads for a in f.result()]
             reads = read_group(groups[g + 1]) if g + 1 < len(groups) else []
@@ -110,6 +111,7 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
                     keep[tile][idx], raw_keep[tile][idx] = out[k], raw[k]
                     if len(keep[tile]) == 256 and all(c in keep[tile] for c in cells):
                         stitches += submit_stitch(pool, tile)
+                        stitched_now.add(tile)
                         stitched += 1
         for f in saves + stitches:
             f.result()
@@ -120,7 +122,7 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
                 if tile not in complete:
                     print("Tile ", tile, " contains less than 256 chunks, cannot stitch. Skipping.")
                     continue
-                if os.path.exists(os.path.join(save_path, tile, "stitched_sr.png")) and world == 1:
+                if tile in stitched_now:
                     continue
                 rest += submit_stitch(pool, tile)      # several ranks wrote the chunks: read them back, tiles in parallel
                 stitched += 1

@@ -32,7 +32,7 @@ def train(opt: Dict, max_iters: Optional[int] = None, resume_state: Optional[Dic
     dsets = opt["datasets"]
     train_opt = dict(dsets["train"], phase="train", scale=opt.get("scale", 4))
     train_set = build_dataset(train_opt)
-    loader = build_train_loader(train_set, train_opt, rank=rank, world=world)
+    loader = build_train_loader(train_set, train_opt, rank=rank, world=world, seed=seed)
     val_loaders = []
     for phase, dopt in dsets.items():
         if phase.split("_")[0] == "val":
@@ -78,6 +78,39 @@ def train(opt: Dict, max_iters: Optional[int] = None, resume_state: Optional[Dic
     return {"iters": current_iter, "epochs": epoch, "log": model.get_current_log(), "metrics": dict(model.metric_results)}
 
 
+def resolve_resume(opt: Dict, auto_resume: bool = False, log=print) -> Optional[Dict]:
+    """BasicSR's load_resume_state + check_resume (train.py:64-65 of the reference calls them): `--auto_resume` takes the newest
+    `training_states/<iter>.state` and OVERRIDES `path.resume_state`; a resume ALWAYS redirects `pretrain_network_{g,d}` to
+    `models/net_{g,d}_<iter>.pth` (unless the net is listed in `path.ignore_resume_networks`), and a missing file is an error, not a
+    silent fall-back to the pretrain weights: optimizer moments, EMA and iteration counters of the state file belong to those
+    weights and to no others."""
+    path = opt["path"]
+    state_file = None
+    if auto_resume and os.path.isdir(path["training_states"]):
+        states = [f for f in os.listdir(path["training_states"]) if f.endswith(".state") and f[:-6].isdigit()]
+        if states:
+            state_file = os.path.join(path["training_states"], f"{max(int(f[:-6]) for f in states)}.state")
+    if state_file is None and path.get("resume_state"):
+        state_file = path["resume_state"]
+    if state_file is None:
+        return None
+    resume = torch.load(state_file, map_location="cpu", weights_only=False)
+    it = resume["iter"]
+    ignore = path.get("ignore_resume_networks") or []
+    for net in ("g", "d"):
+        if f"network_{net}" in ignore or net in ignore:
+            log(f"resume: keeping pretrain_network_{net} (ignore_resume_networks)")
+            continue
+        cand = os.path.join(path["models"], f"net_{net}_{it}.pth")
+        if not os.path.exists(cand):
+            raise FileNotFoundError(f"resume state {state_file} is at iteration {it} but {cand} does not exist "
+                                    f"(list 'network_{net}' in path.ignore_resume_networks to keep pretrain_network_{net})")
+        if path.get(f"pretrain_network_{net}") not in (None, cand):
+            log(f"resume: pretrain_network_{net} is redirected to {cand}")
+        path[f"pretrain_network_{net}"] = cand
+    return resume
+
+
 def main():
     import yaml
     ap = argparse.ArgumentParser()
@@ -97,23 +130,7 @@ def main():
     opt["path"].setdefault("models", os.path.join(root, "models"))
     opt["path"].setdefault("training_states", os.path.join(root, "training_states"))
     opt["path"].setdefault("visualization", os.path.join(root, "visualization"))
-    resume = None
-    if opt["path"].get("resume_state"):
-        # BasicSR's load_resume_state + check_resume: an explicit state file also redirects the network checkpoints to the
-        # state's iteration (the reference's option files resume this way)
-        resume = torch.load(opt["path"]["resume_state"], map_location="cpu", weights_only=False)
-        it = resume["iter"]
-        for net in ("g", "d"):
-            cand = os.path.join(opt["path"]["models"], f"net_{net}_{it}.pth")
-            if os.path.exists(cand) or not opt["path"].get(f"pretrain_network_{net}"):
-                opt["path"][f"pretrain_network_{net}"] = cand
-    elif args.auto_resume and os.path.isdir(opt["path"]["training_states"]):
-        states = [f for f in os.listdir(opt["path"]["training_states"]) if f.endswith(".state") and f[:-6].isdigit()]
-        if states:
-            it = max(int(f[:-6]) for f in states)
-            resume = torch.load(os.path.join(opt["path"]["training_states"], f"{it}.state"), map_location="cpu", weights_only=False)
-            opt["path"]["pretrain_network_g"] = os.path.join(opt["path"]["models"], f"net_g_{it}.pth")
-            opt["path"]["pretrain_network_d"] = os.path.join(opt["path"]["models"], f"net_d_{it}.pth")
+    resume = resolve_resume(opt, args.auto_resume)
     train(opt, max_iters=args.max_iters, resume_state=resume)
 
 

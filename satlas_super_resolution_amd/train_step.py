@@ -122,7 +122,9 @@ class ESRGANTrainStep:
         # B = 32, 32 x 32 tiles) and brings its own second wave per SIMD; measured 12.49 ms (one chain, new kernel) vs 12.68 (two
         # chains, new kernel) vs 13.32 (two chains, 8 x 8 kernel).  "auto" = split only where the 8 x 8 kernel will run.
         env_split = os.environ.get("SSR_G_SPLIT", "auto")
-        wide = B * ((h + 7) // 8) * ((w + 15) // 16) >= 192 and os.environ.get("SSR_RDB_TILE", "auto") not in ("0",)
+        probe = hip.RdbDesc()       # ask the library which dense-block kernel this launch shape gets instead of restating its rule
+        probe.dtype, probe.N, probe.H, probe.W = hip.BF16, B, h, w
+        wide = hip.lib().ssr_rdb_tile_of(C.byref(probe)) == 16
         n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
         split = n_split > 1 and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
             and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
@@ -297,15 +299,16 @@ class ESRGANTrainStep:
 
     def step(self, current_iter: Optional[int] = None):
         """One optimize_parameters().  Order of device work (single rank): identical to the reference.
-        With DP the G-grad all-reduce overlaps the D phases and both Adam updates come last (the D
-        phases do not read G's parameters, so the result is unchanged)."""
+        With DP, G's gradient exchange is issued slice by slice behind the segments of G's backward (and so overlaps it and
+        the D phases on the side stream), D's single exchange is issued after G's slices, and each Adam update waits for its
+        own exchange only (the D phases do not read G's parameters, so the result is unchanged)."""
         self.iter = self.iter + 1 if current_iter is None else current_iter
         cfg = self.cfg
         g_on = (self.iter % cfg.net_d_iters == 0) and (self.iter > cfg.net_d_init_iters)
         if self.dp.active and g_on and self.overlap_d and self.dp_fork:
             # data parallel, forked: as in the single-process step the discriminator phases run on a side stream beside G's
             # backward; each network's gradient exchange follows its own backward and each Adam its own exchange.  Collectives are
-            # ISSUED in the same program order on every rank (D's, then G's; they execute in that order on the one comm stream).
+            # ISSUED in the same program order on every rank (G's slices, then D's; they execute in that order on the one comm stream).
             self._run("g_pre", lambda: self._phase_g(run_bwd=False))
             cur = torch.cuda.current_stream()
             if self._side is None:

@@ -361,13 +361,29 @@ def test_training_loop_on_the_miniature_dataset(tmp_path, monkeypatch):
 
 
 def test_test_pipeline_generator_only(tmp_path):
-    """satlas_super_resolution_amd.test.test_pipeline (ssr/test.py:14-46): model built with is_train=False — generator only, the
-    EMA weights of a checkpoint (`param_key_g: params_ema`) — over the `test_datasets` of the option file, `test.metrics` psnr /
-    ssim / cpsnr computed on the device and images written; metrics outside this path raise by name."""
+    """The model plugin built with is_train=False as ssr/test.py:14-46 builds it — generator only, the EMA weights of a
+    checkpoint (`param_key_g: params_ema`) — driven over the `test_datasets` of an option file: `model.validation` computes the
+    `test.metrics` psnr / cpsnr on the device and writes the images; metrics outside this path raise by name.  (The reference's
+    test.py itself is BasicSR glue and out of scope: the few lines of it are restated here, not shipped.)"""
     import os
     from conftest import GOLDEN
     from oracle import esrgan_oracle as O
-    from satlas_super_resolution_amd.test import test_pipeline
+
+    def test_pipeline(opt, log):
+        from satlas_super_resolution_amd import data as _data, models as _models  # noqa: F401  (register the plugins)
+        from satlas_super_resolution_amd.registry import build_dataset, build_model
+        opt = dict(opt, is_train=False, dist=False)
+        loaders = []
+        for _, dopt in sorted(opt["test_datasets"].items()):
+            dset = build_dataset(dict(dopt, phase=dopt.get("phase", "test"), scale=dopt.get("scale", opt.get("scale", 4))))
+            loaders.append(torch.utils.data.DataLoader(dset, batch_size=1, shuffle=False, num_workers=0))
+        model = build_model(opt)
+        results = {}
+        for loader in loaders:
+            model.validation(loader, current_iter=opt.get("name", "test"), tb_logger=None,
+                             save_img=opt.get("test", {}).get("save_img", False))
+            results[loader.dataset.opt["name"]] = dict(model.metric_results)
+        return results
     mini = os.path.join(GOLDEN, "s2naip_mini")
     g_kw = dict(num_in_ch=24, num_out_ch=3, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
     sd = O.generator_init(seed=5, **g_kw)

@@ -159,18 +159,15 @@ def test_bilinear_tile_kernels_match_the_per_pixel_kernels(B, H, W, Cc, fp32):
     dy, r, m = rnd(B, 2 * H, 2 * W, Cc), rnd(B, H, W, Cc), rnd(B, H, W, Cc)
 
     def run(flat, with_b, with_rm):
-        prev = lib.ssr_bilinear_set_flat(1 if flat else 0)
-        try:
-            y = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=tdt, device=dev)
-            hip.check(lib.ssr_bilinear2x_fwd(hip.view(a), hip.view(b2) if with_b else hip.NULL_VIEW, hip.view(y), DT, B, H, W, Cc,
-                                             hip.stream_ptr()), "bil fwd")
-            gx, g1 = torch.zeros_like(a), torch.zeros_like(a)
-            hip.check(lib.ssr_bilinear2x_bwd(hip.view(dy), hip.view(r) if with_rm else hip.NULL_VIEW, hip.view(g1) if with_rm else hip.NULL_VIEW,
-                                             hip.view(gx), hip.view(m) if with_rm else hip.NULL_VIEW, DT, B, H, W, Cc,
-                                             hip.stream_ptr()), "bil bwd")
-            torch.cuda.synchronize()
-        finally:
-            lib.ssr_bilinear_set_flat(prev)
+        dtf = DT | (hip.BILINEAR_FLAT if flat else 0)        # per-call flag (include/ssr_hip.h), no library state
+        y = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=tdt, device=dev)
+        hip.check(lib.ssr_bilinear2x_fwd(hip.view(a), hip.view(b2) if with_b else hip.NULL_VIEW, hip.view(y), dtf, B, H, W, Cc,
+                                         hip.stream_ptr()), "bil fwd")
+        gx, g1 = torch.zeros_like(a), torch.zeros_like(a)
+        hip.check(lib.ssr_bilinear2x_bwd(hip.view(dy), hip.view(r) if with_rm else hip.NULL_VIEW, hip.view(g1) if with_rm else hip.NULL_VIEW,
+                                         hip.view(gx), hip.view(m) if with_rm else hip.NULL_VIEW, dtf, B, H, W, Cc,
+                                         hip.stream_ptr()), "bil bwd")
+        torch.cuda.synchronize()
         return y, gx, g1
 
     for with_b, with_rm in ((True, True), (False, False)):

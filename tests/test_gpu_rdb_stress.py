@@ -22,7 +22,7 @@ N, H, W = 32, 32, 32
 LAUNCHES = int(os.environ.get("SSR_STRESS_LAUNCHES", "2500"))      # per direction and per load condition: 4 x 2500 = 10 000
 
 
-def _desc(hip, b, bwd, r2, cur, out, dcur):
+def _desc(hip, b, bwd, r2, cur, out, dcur, tile):
     from satlas_super_resolution_amd.hip import RdbDesc, View
     d = RdbDesc()
     d.dtype, d.N, d.H, d.W = hip.BF16, N, H, W
@@ -40,6 +40,7 @@ def _desc(hip, b, bwd, r2, cur, out, dcur):
             d.bias[k] = None
         d.alpha5, d.beta1 = 1.0, (0.2 if r2 else 1.0)
     d.r2, d.beta2 = (v(b["r2"]), 1.0) if r2 else (hip.NULL_VIEW, 0.0)
+    d.tile = tile              # per-descriptor kernel choice: 8 = 8 x 8 tiles (csrc/rdb_fwd.hip), 16 = 8 x 16 tiles (csrc/rdb_tile.hip)
     return d
 
 
@@ -55,7 +56,7 @@ def _bufs(seed):
                 bias=[((torch.rand(64, generator=g) * 2 - 1) * 0.1).to(dev) for _ in range(5)])
 
 
-def _side_load(side, ev_stop_after):
+def _side_load(side):
     """Work for the second stream: alternating MFMA-heavy (a torch matmul: any other kernel would do, it is only a disturbance)
     and HBM-heavy (a 256 MB copy) launches; returns a callable that enqueues one more round."""
     a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
@@ -82,47 +83,42 @@ def test_thousands_of_wide_tile_launches_match_the_8x8_kernel(loaded):
     r2 = True
     cur0 = b["cur"]
     zeros = torch.zeros_like(cur0)
-    prev = lib.ssr_rdb_set_tile(0)
-    try:
-        # reference: the 8 x 8 kernel, once per direction
-        cur_ref, out_ref, dcur_ref = cur0.clone(), zeros.clone(), zeros.clone()
-        assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None)), None) == 0
-        torch.cuda.synchronize()
-        assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcur_ref)), None) == 0
-        torch.cuda.synchronize()
-        assert float(out_ref.float().abs().max()) > 0.1 and float(dcur_ref.float().abs().max()) > 0.1
-        lib.ssr_rdb_set_tile(16)
-        assert lib.ssr_rdb_tile_of(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None))) == 16
-        main = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        more = _side_load(side, None) if loaded else None
-        # three rotating target sets so that a launch never waits for the previous comparison
-        NSET = 3
-        curs = [cur0.clone() for _ in range(NSET)]
-        outs = [zeros.clone() for _ in range(NSET)]
-        dcurs = [zeros.clone() for _ in range(NSET)]
-        bad = torch.zeros(4, device="cuda", dtype=torch.int64)     # fwd slices, fwd out, bwd, launches counted
-        ref_s, ref_o, ref_g = cur_ref.view(torch.int16), out_ref.view(torch.int16), dcur_ref.view(torch.int16)
-        sp = main.cuda_stream
-        for it in range(LAUNCHES):
-            k = it % NSET
-            if loaded and it % 8 == 0:
-                more()
-            curs[k].copy_(cur0)
-            outs[k].zero_()
-            dcurs[k].zero_()
-            assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, curs[k], outs[k], None)), sp) == 0
-            # the backward takes the REFERENCE forward activations as masks (its own correctness is what is under test)
-            assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcurs[k])), sp) == 0
-            bad[0] += (curs[k].view(torch.int16) != ref_s).sum()
-            bad[1] += (outs[k].view(torch.int16) != ref_o).sum()
-            bad[2] += (dcurs[k].view(torch.int16) != ref_g).sum()
-            bad[3] += 1
-        torch.cuda.synchronize()
-        nb = bad.cpu().tolist()
-        assert nb[3] == LAUNCHES
-        assert nb[:3] == [0, 0, 0], (f"{LAUNCHES} forward + {LAUNCHES} backward launches of the 8x16 kernel "
-                                      f"({'with' if loaded else 'without'} a busy second stream): differing bf16 values "
-                                      f"x1..x4 {nb[0]}, block output {nb[1]}, dpre/dx {nb[2]}")
-    finally:
-        lib.ssr_rdb_set_tile(prev)
+    # reference: the 8 x 8 kernel, once per direction
+    cur_ref, out_ref, dcur_ref = cur0.clone(), zeros.clone(), zeros.clone()
+    assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None, 8)), None) == 0
+    torch.cuda.synchronize()
+    assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcur_ref, 8)), None) == 0
+    torch.cuda.synchronize()
+    assert float(out_ref.float().abs().max()) > 0.1 and float(dcur_ref.float().abs().max()) > 0.1
+    assert lib.ssr_rdb_tile_of(C.byref(_desc(hip, b, False, r2, cur_ref, out_ref, None, 16))) == 16
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    more = _side_load(side) if loaded else None
+    # three rotating target sets so that a launch never waits for the previous comparison
+    NSET = 3
+    curs = [cur0.clone() for _ in range(NSET)]
+    outs = [zeros.clone() for _ in range(NSET)]
+    dcurs = [zeros.clone() for _ in range(NSET)]
+    bad = torch.zeros(4, device="cuda", dtype=torch.int64)     # fwd slices, fwd out, bwd, launches counted
+    ref_s, ref_o, ref_g = cur_ref.view(torch.int16), out_ref.view(torch.int16), dcur_ref.view(torch.int16)
+    sp = main.cuda_stream
+    for it in range(LAUNCHES):
+        k = it % NSET
+        if loaded and it % 8 == 0:
+            more()
+        curs[k].copy_(cur0)
+        outs[k].zero_()
+        dcurs[k].zero_()
+        assert lib.ssr_rdb_forward(C.byref(_desc(hip, b, False, r2, curs[k], outs[k], None, 16)), sp) == 0
+        # the backward takes the REFERENCE forward activations as masks (its own correctness is what is under test)
+        assert lib.ssr_rdb_backward(C.byref(_desc(hip, b, True, r2, cur_ref, None, dcurs[k], 16)), sp) == 0
+        bad[0] += (curs[k].view(torch.int16) != ref_s).sum()
+        bad[1] += (outs[k].view(torch.int16) != ref_o).sum()
+        bad[2] += (dcurs[k].view(torch.int16) != ref_g).sum()
+        bad[3] += 1
+    torch.cuda.synchronize()
+    nb = bad.cpu().tolist()
+    assert nb[3] == LAUNCHES
+    assert nb[:3] == [0, 0, 0], (f"{LAUNCHES} forward + {LAUNCHES} backward launches of the 8x16 kernel "
+                                  f"({'with' if loaded else 'without'} a busy second stream): differing bf16 values "
+                                  f"x1..x4 {nb[0]}, block output {nb[1]}, dpre/dx {nb[2]}")

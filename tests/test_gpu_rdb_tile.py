@@ -47,12 +47,10 @@ def _run(hip, b, N, H, W, bwd, r2, tile, cur_in):
             d.bias[k] = None
         d.alpha5, d.beta1 = 1.0, (0.2 if r2 else 1.0)
     d.r2, d.beta2 = (v(b["r2"]), 1.0) if r2 else (hip.NULL_VIEW, 0.0)
-    prev = lib.ssr_rdb_set_tile(tile)
-    try:
-        rc = (lib.ssr_rdb_backward if bwd else lib.ssr_rdb_forward)(C.byref(d), None)
-        torch.cuda.synchronize()
-    finally:
-        lib.ssr_rdb_set_tile(prev)
+    d.tile = tile                                   # per-descriptor kernel choice (include/ssr_hip.h): 8 / 16, 0 = automatic
+    assert lib.ssr_rdb_tile_of(C.byref(d)) == tile
+    rc = (lib.ssr_rdb_backward if bwd else lib.ssr_rdb_forward)(C.byref(d), None)
+    torch.cuda.synchronize()
     assert rc == 0
     return (dcur, dcur) if bwd else (cur, out)
 
@@ -62,22 +60,31 @@ def _run(hip, b, N, H, W, bwd, r2, tile, cur_in):
 def test_wide_tile_kernel_is_bit_identical_to_the_8x8_kernel(N, H, W, r2):
     from satlas_super_resolution_amd import hip
     b = _bufs(N, H, W, seed=N * 1000 + H)
-    s0, o0 = _run(hip, b, N, H, W, False, r2, 0, b["cur"])
+    s0, o0 = _run(hip, b, N, H, W, False, r2, 8, b["cur"])
     s1, o1 = _run(hip, b, N, H, W, False, r2, 16, b["cur"])
     assert torch.equal(s0.view(torch.int16), s1.view(torch.int16)), "forward: x1..x4 differ"
     assert torch.equal(o0.view(torch.int16), o1.view(torch.int16)), "forward: block output differs"
     assert float(o0.float().abs().max()) > 0.1            # not a trivially empty comparison
     # backward with the forward activations as LeakyReLU masks
-    g0, _ = _run(hip, b, N, H, W, True, r2, 0, s0)
+    g0, _ = _run(hip, b, N, H, W, True, r2, 8, s0)
     g1, _ = _run(hip, b, N, H, W, True, r2, 16, s0)
     assert torch.equal(g0.view(torch.int16), g1.view(torch.int16)), "backward: dpre4..1 / d x differ"
     assert float(g0.float().abs().max()) > 0.1
 
 
-def test_automatic_choice_and_env_override(monkeypatch):
+def test_automatic_choice_follows_the_grid_size():
+    """tile = 0: 8 x 16 tiles where they give (nearly) every CU a workgroup (>= 192), the 8 x 8 kernel below that."""
     from satlas_super_resolution_amd import hip
+    from satlas_super_resolution_amd.hip import RdbDesc
     lib = hip.lib()
-    prev = lib.ssr_rdb_set_tile(16)
-    assert lib.ssr_rdb_set_tile(0) == 16
-    assert lib.ssr_rdb_set_tile(7) == 0          # anything else = automatic
-    assert lib.ssr_rdb_set_tile(prev) == -1
+    import os
+    if os.environ.get("SSR_RDB_TILE", "auto") not in ("auto", ""):
+        pytest.skip("SSR_RDB_TILE overrides the automatic choice")
+    for n, want in ((32, 16), (24, 16), (16, 8), (4, 8)):
+        d = RdbDesc()
+        d.dtype, d.N, d.H, d.W = hip.BF16, n, 32, 32
+        assert lib.ssr_rdb_tile_of(C.byref(d)) == want, (n, want)
+        d.tile = 8
+        assert lib.ssr_rdb_tile_of(C.byref(d)) == 8
+        d.tile = 16
+        assert lib.ssr_rdb_tile_of(C.byref(d)) == 16

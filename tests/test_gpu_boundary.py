@@ -417,7 +417,7 @@ def test_test_pipeline_generator_only(tmp_path):
         test_pipeline(bad, log=lambda *_: None)
 
 
-@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated"])
+@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated", "stepref_usm"])
 def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
     """The MODEL_REGISTRY plugin driven like ssr/train.py drives the reference model (feed_data(uint8 batch) ->
     optimize_parameters(it) -> get_current_log(); test()) against fixtures produced by EXECUTING the unmodified
@@ -426,7 +426,8 @@ def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
     from satlas_super_resolution_amd import models  # noqa: F401
     from satlas_super_resolution_amd.registry import build_model
     fx = load_golden(name)
-    opt = _opt(tmp_path, fx, feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)))
+    opt = _opt(tmp_path, fx, feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)), l1_gt_usm=bool(fx["opt"].get("l1_gt_usm", False)),
+               gan_gt_usm=bool(fx["opt"].get("gan_gt_usm", False)))
     opt["train"].update({"ema_decay": fx["ema_decay"], "net_d_iters": fx["net_d_iters"], "net_d_init_iters": fx["net_d_init_iters"],
                          "optim_d": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])},
                          "optim_g": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])}})
@@ -456,5 +457,9 @@ def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
     ema = m.ts.ema_state_dict()
     for k, v in fx["g_ema_final"].items():
         _close_update(ema[k].cpu(), v, fx["g0"][k], ("EMA", k), 5e-2)
+    if name == "stepref_usm":                     # the device's sharpened L1 target (ssr_usm_sharp) against what the reference run fed its L1 loss
+        tgt = m.ts.l1_tgt[..., :3].permute(0, 3, 1, 2).float().cpu()
+        assert m.ts.l1_tgt is not m.ts.real_in
+        assert rel_err(tgt, fx["gt_usm_last"]) < 1e-5, rel_err(tgt, fx["gt_usm_last"])
     m.test()                                      # :235-244: net_g_ema under no_grad on the last batch
     assert parity_close(m.output.cpu(), fx["test_output"]), rel_err(m.output.cpu(), fx["test_output"])

@@ -82,7 +82,7 @@ def test_train_step(name):
     assert rel_err(m.output, fx["output_last"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated"])
+@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr", "stepref_gated", "stepref_usm"])
 def test_train_step_against_the_unmodified_reference_method(name):
     """The oracle's step against fixtures produced by EXECUTING the reference's own SSRESRGANModel.feed_data /
     optimize_parameters / test (ssr_esrgan_model.py:104-244; oracle/make_golden_refstep.py) — not a re-typed loop: freeze /
@@ -91,7 +91,14 @@ def test_train_step_against_the_unmodified_reference_method(name):
     fx = load_golden(name)
     cfg = O.StepConfig(l1_weight=fx["l1_weight"], gan_weight=fx["gan_weight"], lr_g=fx["lr"], lr_d=fx["lr"],
                        betas=tuple(fx["betas"]), ema_decay=fx["ema_decay"], feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)),
-                       net_d_iters=fx["net_d_iters"], net_d_init_iters=fx["net_d_init_iters"])
+                       net_d_iters=fx["net_d_iters"], net_d_init_iters=fx["net_d_init_iters"],
+                       l1_gt_usm=bool(fx["opt"].get("l1_gt_usm", False)), gan_gt_usm=bool(fx["opt"].get("gan_gt_usm", False)))
+    if name == "stepref_usm":
+        # stepref_usm: the shipped setting l1_gt_usm = True (esrgan_s2naip_urban.yml:9) through the unmodified feed_data /
+        # optimize_parameters with BasicSR's USMSharp text: the sharpened target itself, then the step that uses it
+        gt_last = fx["data"][-1]["hr"].float() / 255
+        assert float((fx["gt_usm_last"] - gt_last).abs().mean()) > 1e-3            # the sharpener does something on this image
+        assert rel_err(O.usm_sharp(gt_last), fx["gt_usm_last"]) < 1e-6
     m = O.ESRGANOracle(fx["g0"], fx["d0"], cfg)
     for it, batch in enumerate(fx["data"], start=1):
         lr, gt = batch["lr"].float() / 255, batch["hr"].float() / 255            # feed_data :107-109

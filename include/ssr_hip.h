@@ -274,6 +274,9 @@ typedef struct ssr_sn_item {
 int ssr_spectral_norm(const ssr_sn_item* items_dev, int32_t n_items, int32_t max_rows, int32_t max_cols,
                       int32_t power_iter, void* stream);
 /* backward through W_sn = W/sigma: dW_orig += (dW_sn - <dW_sn, W_sn> u v^T) / sigma */
+/* tmp: SSR_SN_BWD_SLOTS floats of scratch per item (per-block partial sums of <dW_sn, W>, added in index order: the result
+ * does not depend on the order in which the blocks finish; nothing to zero) */
+#define SSR_SN_BWD_SLOTS 64
 typedef struct ssr_sn_bwd_item {
     const float* dw_sn; const float* w; const float* u; const float* v; const float* sigma;
     float* dw; float* tmp; int32_t rows, cols;
@@ -288,6 +291,12 @@ int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n_items, int
 int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, float in_scale, float weight,
                   float threshold, void* stream);
 
+/* Deterministic reductions (run-to-run bit-identical results; the reference's fp32 CPU path is).
+ * SSR_DETERMINISTIC OR-ed into the dtype of the two loss calls: loss_out / mean_out are arrays of SSR_LOSS_SLOTS floats, block b
+ * adds its partial sum to slot b (single writer per slot and launch) and the reader adds the slots in index order; without the
+ * flag: one fp32 atomicAdd per block into loss_out[0] (arrival order). */
+#define SSR_DETERMINISTIC 0x200
+#define SSR_LOSS_SLOTS 256
 /* loss_out[0] += weight * mean|a-b| over (N,H,W,C valid); grad (optional) = weight*sign(a-b)/numel */
 int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
                 float* loss_out, void* stream);
@@ -295,6 +304,12 @@ int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t np
  * mean_out[0] += mean(x) (optional); grad = weight*(sigmoid(x)-t)/numel (optional) */
 int ssr_bce_logits_loss(ssr_view x, ssr_view grad, int32_t dtype, int64_t npix, float target, float weight,
                         float* loss_out, float* mean_out, void* stream);
+
+/* dst[e] += sum over p = 0 .. parts-1 (in that order) of src[p * stride + e], e < n: the fixed-order sum of per-split partial
+ * weight gradients (deterministic mode: each pixel-range split of a layer is given its own partial dW / db as `dw` / `db` of a
+ * layer-table entry of its own, so that every gradient element has ONE writer per launch) */
+typedef struct ssr_reduce_item { float* dst; const float* src; int64_t n, stride; int32_t parts, pad_; } ssr_reduce_item;
+int ssr_wgrad_reduce(const ssr_reduce_item* items_dev, int32_t n_items, int64_t max_elems, void* stream);
 
 /* ---- optimizer: torch.optim.Adam (weight_decay 0, eps 1e-8) over a flat fp32 arena, with the
  *      BasicSR model_ema update fused (ssr_esrgan_model.py:193,228,230-231) ---- */

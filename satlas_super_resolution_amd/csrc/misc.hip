@@ -600,14 +600,18 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const ssr_sn_bwd_item* 
             s += it.dw_sn[e] * it.w[e];
     }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) atomicAdd(it.tmp, s);
+    if (threadIdx.x == 0) it.tmp[blockIdx.x] = s;     // one slot per block (no atomics: sn_bwd_apply_kernel adds the slots in index order)
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const ssr_sn_bwd_item* __restrict__ items) {
     const ssr_sn_bwd_item it = items[blockIdx.y];
     const long n = (long)it.rows * it.cols;
     const float sigma = it.sigma[0];
-    const float coef = it.tmp[0] / (sigma * sigma);  // <dW_sn, W> / sigma^2 = <dW_sn, W_sn> / sigma
+    // <dW_sn, W>: the dot kernel's per-block partial sums (one per blockIdx.x of the SAME grid), added in index order by every
+    // thread - a fixed-order sum (round 4: was one fp32 atomicAdd per block, i.e. arrival order)
+    float dot = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) dot += it.tmp[b];
+    const float coef = dot / (sigma * sigma);  // <dW_sn, W> / sigma^2 = <dW_sn, W_sn> / sigma
     const float inv = 1.f / sigma;
     if ((it.cols & 3) == 0 && n < (1L << 31) && (((uintptr_t)it.dw_sn | (uintptr_t)it.dw | (uintptr_t)it.v) & 15) == 0) {
         // four columns per thread: one 32-bit division per 16 bytes (the per-element 64-bit division made this VALU bound)
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const ssr_sn_bwd_item
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void l1_loss_kernel(ssr_view a, ssr_view b, ssr_view grad, long npix, int C,
-                                                      float weight, float* __restrict__ loss_out) {
+                                                      float weight, float* __restrict__ loss_out, bool det) {
     __shared__ float sh[16];
     const long total = npix * C;
     const float invn = 1.f / (float)total;
@@ -652,13 +656,15 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(ssr_view a, ssr_view b, ss
         if (gp) gp[p * grad.cs + grad.coff + c] = from_f32<T>(d > 0.f ? weight * invn : (d < 0.f ? -weight * invn : 0.f));
     }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, s * weight * invn);
+    // det: one slot per block, `+=` by the slot's single writer (launches on a stream are ordered) - the reader adds the slots in
+    // index order; default: one fp32 atomic per block (arrival order: last-bit differences from run to run)
+    if (threadIdx.x == 0 && loss_out) { if (det) loss_out[blockIdx.x] += s * weight * invn; else atomicAdd(loss_out, s * weight * invn); }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bce_loss_kernel(ssr_view x, ssr_view grad, long npix, float target,
                                                        float weight, float* __restrict__ loss_out,
-                                                       float* __restrict__ mean_out) {
+                                                       float* __restrict__ mean_out, bool det) {
     __shared__ float sh[16];
     const float invn = 1.f / (float)npix;
     const T* __restrict__ xp = reinterpret_cast<const T*>(x.p);
@@ -675,10 +681,10 @@ __global__ __launch_bounds__(256) void bce_loss_kernel(ssr_view x, ssr_view grad
         }
     }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, s * weight * invn);
+    if (threadIdx.x == 0 && loss_out) { if (det) loss_out[blockIdx.x] += s * weight * invn; else atomicAdd(loss_out, s * weight * invn); }
     if (mean_out) {
         sm = block_sum(sm, sh);
-        if (threadIdx.x == 0) atomicAdd(mean_out, sm * invn);
+        if (threadIdx.x == 0) { if (det) mean_out[blockIdx.x] += sm * invn; else atomicAdd(mean_out, sm * invn); }
     }
 }
 
@@ -887,8 +893,8 @@ extern "C" int ssr_spectral_norm(const ssr_sn_item* items_dev, int32_t n_items, 
 extern "C" int ssr_spectral_norm_bwd(const ssr_sn_bwd_item* items_dev, int32_t n_items, int32_t max_elems,
                                      void* stream) {
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
-    const int gx = grid_for(max_elems, 256 * 8, 256);
-    // NOTE: every item's tmp[0] must be zero on entry (host memsets the scratch arena in-stream)
+    const int gx = grid_for(max_elems, 256 * 8, SSR_SN_BWD_SLOTS);
+    // every item's tmp holds SSR_SN_BWD_SLOTS floats: block b of the dot kernel stores its partial sum in tmp[b] (nothing to zero)
     hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(gx, n_items), dim3(256), 0, ST(stream), items_dev);
     SSR_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(gx, n_items), dim3(256), 0, ST(stream), items_dev);
@@ -976,15 +982,17 @@ extern "C" int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32
 
 extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype, int64_t npix, int32_t C, float weight,
                            float* loss_out, void* stream) {
+    const bool det = (dtype & SSR_DETERMINISTIC) != 0;      // loss_out = SSR_LOSS_SLOTS floats, one per block
+    dtype &= ~SSR_DETERMINISTIC;
     if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!a.p || !b.p || npix <= 0 || C <= 0) return SSR_EINVAL;
-    const int g = grid_for(npix * C, 256 * 4, 1024);
+    const int g = grid_for(npix * C, 256 * 4, det ? SSR_LOSS_SLOTS : 1024);
     if (dtype == SSR_F32)
         hipLaunchKernelGGL(l1_loss_kernel<float>, dim3(g), dim3(256), 0, ST(stream), a, b, grad, (long)npix, C, weight,
-                           loss_out);
+                           loss_out, det);
     else if (dtype == SSR_BF16)
         hipLaunchKernelGGL(l1_loss_kernel<__bf16>, dim3(g), dim3(256), 0, ST(stream), a, b, grad, (long)npix, C, weight,
-                           loss_out);
+                           loss_out, det);
     else return SSR_EUNSUP;
     SSR_LAUNCH_CHECK();
     return SSR_OK;
@@ -992,16 +1000,35 @@ extern "C" int ssr_l1_loss(ssr_view a, ssr_view b, ssr_view grad, int32_t dtype,
 
 extern "C" int ssr_bce_logits_loss(ssr_view x, ssr_view grad, int32_t dtype, int64_t npix, float target, float weight,
                                    float* loss_out, float* mean_out, void* stream) {
+    const bool det = (dtype & SSR_DETERMINISTIC) != 0;      // loss_out / mean_out = SSR_LOSS_SLOTS floats each, one per block
+    dtype &= ~SSR_DETERMINISTIC;
     if (dtype == SSR_F32X3) dtype = SSR_F32;   // fp32 storage: only the matrix-core kernels differ
     if (!x.p || npix <= 0) return SSR_EINVAL;
-    const int g = grid_for(npix, 256 * 4, 1024);
+    const int g = grid_for(npix, 256 * 4, det ? SSR_LOSS_SLOTS : 1024);
     if (dtype == SSR_F32)
         hipLaunchKernelGGL(bce_loss_kernel<float>, dim3(g), dim3(256), 0, ST(stream), x, grad, (long)npix, target,
-                           weight, loss_out, mean_out);
+                           weight, loss_out, mean_out, det);
     else if (dtype == SSR_BF16)
         hipLaunchKernelGGL(bce_loss_kernel<__bf16>, dim3(g), dim3(256), 0, ST(stream), x, grad, (long)npix, target,
-                           weight, loss_out, mean_out);
+                           weight, loss_out, mean_out, det);
     else return SSR_EUNSUP;
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+// dst[e] += sum_p src[p * stride + e], p = 0 .. parts-1 in that order: the fixed-order sum behind the deterministic weight-gradient
+// mode (engine.WgradBatch: every pixel-range split of a layer writes its own partial gradient, one writer per element)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ssr_reduce_item* __restrict__ items) {
+    const ssr_reduce_item it = items[blockIdx.y];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < it.n; e += (long)gridDim.x * blockDim.x) {
+        float s = it.dst[e];
+        for (int p = 0; p < it.parts; ++p) s += it.src[(long)p * it.stride + e];
+        it.dst[e] = s;
+    }
+}
+extern "C" int ssr_wgrad_reduce(const ssr_reduce_item* items_dev, int32_t n_items, int64_t max_elems, void* stream) {
+    if (!items_dev || n_items <= 0 || max_elems <= 0) return SSR_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(max_elems, 256 * 4, 64), n_items), dim3(256), 0, ST(stream), items_dev);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }

@@ -224,12 +224,27 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const ssr_wgrad_layer* 
                 hold(ra); hold(rb);
             }
         }
-        if (do_bias) {   // 64 threads share each channel octet: LDS float atomics, then one global atomic per channel
-            float* bl = reinterpret_cast<float*>(ctl + WGC_BIAS);
+        if (do_bias) {
+            // 64 threads share each channel octet (lane & 3).  A FIXED-ORDER sum (round 4; LDS float atomics before: arrival order):
+            // xor-shuffle tree over the 16 lanes of a wave that hold the octet, then the four loader waves add their sums one after
+            // the other (LSYNC is the turn counter), then one global add per channel (one item per db element and launch unless
+            // the layer is split over pixel ranges - the deterministic mode gives every split its own db)
+            volatile float* bl = reinterpret_cast<volatile float*>(ctl + WGC_BIAS);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(bl + (lt & 3) * 8 + e, bacc[e]);
+            for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bacc[e] += __shfl_xor(bacc[e], m);
+            const int lw = lt >> 6;
+            while (wg_ld(ctl + WGC_LSYNC) < lw) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bl[lane * 8 + e] = lw == 0 ? bacc[e] : bl[lane * 8 + e] + bacc[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __atomic_fetch_add(ctl + WGC_LSYNC, 1, __ATOMIC_RELAXED);
             while (wg_ld(ctl + WGC_LSYNC) < 4) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (lt < 32 && it.co0 + lt < L.Cout) atomicAdd(L.db + it.co0 + lt, L.alpha * bl[lt]);
         }
         return;
@@ -588,14 +603,28 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
         hold(ra); hold(rb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         hold(ra); hold(rb);
-        if (bias_a || bias_b) {   // 32 threads share each channel octet of a plane: LDS float atomics, then one global atomic per channel
-            float* bl = reinterpret_cast<float*>(ctl + W3C_BIAS);
-            if (do_bias) {
+        if (bias_a || bias_b) {
+            // 32 threads share each channel octet of a plane ((hb, oct) = lane & 7).  Fixed-order sum as in wgrad_bf16_kernel: xor-
+            // shuffle tree over the 8 lanes of a wave with the same (hb, oct), then the four loader waves in turn, then one global
+            // add per channel
+            volatile float* bl = reinterpret_cast<volatile float*>(ctl + W3C_BIAS);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(bl + hb * 32 + oct * 8 + e, bacc[e]);
+            for (int e = 0; e < 8; ++e) bacc[e] = do_bias ? bacc[e] : 0.f;
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bacc[e] += __shfl_xor(bacc[e], m);
+            const int lw = lt >> 6;
+            while (wg_ld(ctl + WGC_LSYNC) < lw) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 8) {          // lane = hb * 4 + oct
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bl[hb * 32 + oct * 8 + e] = lw == 0 ? bacc[e] : bl[hb * 32 + oct * 8 + e] + bacc[e];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __atomic_fetch_add(ctl + WGC_LSYNC, 1, __ATOMIC_RELAXED);
             while (wg_ld(ctl + WGC_LSYNC) < 4) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (lt < 64) {
                 const int h = lt >> 5, c = lt & 31;
                 const ssr_wgrad_layer& LC = h ? LB : L;

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import hip
-from .hip import ConvDesc, View, WgradItem, WgradLayer, PackItem, SNItem, SNBwdItem, view
+from .hip import ConvDesc, View, WgradItem, WgradLayer, PackItem, SNItem, SNBwdItem, ReduceItem, view
 
 
 def rup(a: int, b: int) -> int:
@@ -84,7 +84,7 @@ class ParamStore:
             self.sn_tmp = torch.zeros(len(self.sn_names), rup(mx + 4, 4), device=self.device)
             # dW w.r.t. the normalised weight (wgrad target for SN layers), same offsets as `grad`
             self.grad_sn = torch.zeros(off, dtype=torch.float32, device=self.device)
-            self.sn_dot = torch.zeros(len(self.sn_names), 4, device=self.device)
+            self.sn_dot = torch.zeros(len(self.sn_names), hip.SN_BWD_SLOTS, device=self.device)   # per-block partial sums of <dW_sn, W> (fixed-order sum in the kernel)
         # packed weights
         tdt = hip.torch_dtype(dtype)
         L = hip.lib()
@@ -253,7 +253,6 @@ class ParamStore:
     def spectral_norm_backward(self):
         """grad += d(W/sigma)^T grad_sn ; consumes (and re-zeroes) grad_sn."""
         if self.sn_names:
-            self.sn_dot.zero_()
             hip.check(hip.lib().ssr_spectral_norm_bwd(self.sn_bwd_table.data_ptr(), len(self.sn_names),
                                                       self.sn_max_elems, hip.stream_ptr()), "ssr_spectral_norm_bwd")
             self.grad_sn.zero_()
@@ -424,6 +423,27 @@ def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View,
     L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad-gather {prefix}.slice{k}")
 
 
+_DET = [os.environ.get("SSR_DETERMINISTIC", "0") == "1"]
+
+
+def deterministic() -> bool:
+    """Plans built while this is on use fixed-order reductions only (weight gradients of pixel-range splits through per-split
+    partial buffers + ssr_wgrad_reduce instead of fp32 atomics into one buffer): two runs give bit-identical parameters.  Switched
+    by SSR_DETERMINISTIC=1 or StepConfig.deterministic (train_step.py; option file key `deterministic: true`)."""
+    return _DET[0]
+
+
+class deterministic_mode:
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _DET[0] = _DET[0], (self.on or _DET[0])
+
+    def __exit__(self, *a):
+        _DET[0] = self.prev
+
+
 _CUS = None
 
 
@@ -447,7 +467,7 @@ class WgradBatch:
     # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits (SSR_WGRAD_T3 / _T4: tuning hooks)
     MAX_TILES_PER_ITEM = {3: int(os.environ.get("SSR_WGRAD_T3", "128")), 4: int(os.environ.get("SSR_WGRAD_T4", "64"))}
 
-    def __init__(self, dtype: int, k: int, stride: int, force_atomic: bool = False):
+    def __init__(self, dtype: int, k: int, stride: int, force_atomic: bool = False, det: Optional[bool] = None):
         self.dtype, self.k, self.stride = dtype, k, stride
         self.force_atomic = force_atomic       # another launch accumulates into the same gradients concurrently
         self.kdt = hip.BF16 if dtype == hip.F32X3 else dtype      # element type the wgrad kernel reads
@@ -456,6 +476,15 @@ class WgradBatch:
         self.layer_tab = self.item_tab = None
         self.split_tabs: List[torch.Tensor] = []
         self.splits: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
+        # deterministic mode: a layer that is split over pixel ranges gets one layer-table entry PER SPLIT whose dw / db point
+        # at a partial buffer of that split alone (one writer per gradient element and launch); ssr_wgrad_reduce then adds the
+        # partials to the real gradient in split order.  Without it the splits add into one buffer with fp32 atomics (arrival order).
+        self.det = deterministic() if det is None else bool(det)      # plans capture the mode when THEY are built (backward plans are built lazily)
+        assert not (self.det and force_atomic), "deterministic mode: no second launch may accumulate into the same gradients concurrently"
+        self.virtual = set()                  # indices of the per-split entries of self.layers
+        self._partials = []                   # (dw_ptr, db_ptr, wsize, bsize, [virtual layer indices])
+        self.partial = self.reduce_tab = None
+        self.n_reduce = self.max_reduce = 0
 
     def add(self, x: View, dy: View, N, hi, wi, up, cin, cout, gh, gw, alpha, dw_ptr, cin_w, db_ptr):
         li = len(self.layers)
@@ -463,12 +492,21 @@ class WgradBatch:
         tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.kdt, self.k)
         splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
         per = -(-tiles // splits)
+        lsp = [li] * splits                   # layer-table entry of split sp
+        if self.det and splits > 1:
+            lsp = []
+            for sp in range(splits):          # dw / db are patched in finalize(), when the partial buffer exists
+                lsp.append(len(self.layers))
+                self.virtual.add(len(self.layers))
+                self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, None, cin_w, None))
+            self._partials.append((dw_ptr, db_ptr, cout * cin_w * self.k * self.k, cout if db_ptr else 0, lsp))
         for co0 in range(0, cout, 32):
             for ci0 in range(0, cin_w, hip.lib().ssr_wgrad_ci_tile(self.kdt, self.k)):
                 for sp in range(splits):
                     b, e = sp * per, min(tiles, (sp + 1) * per)
                     if b < e:
-                        self.items.append(WgradItem(li, co0, ci0, b, e, 1 if (splits > 1 or self.force_atomic) else 0, 1, li, co0))
+                        atomic = 1 if ((splits > 1 and not self.det) or self.force_atomic) else 0
+                        self.items.append(WgradItem(lsp[sp], co0, ci0, b, e, atomic, 1, lsp[sp], co0))
 
     def _weight(self, it):
         """MFMA work of an item in (tile, 32-ci half, 32-co plane) units"""
@@ -579,9 +617,33 @@ class WgradBatch:
             self.splits.append((parent, tw[0], tw[1]))
         return View(tw[which].data_ptr(), v.cs, v.coff)
 
+    def _alloc_partials(self):
+        """one fp32 buffer [layer][split][dW | db] for the per-split partial gradients + the table of fixed-order sums"""
+        if not self._partials:
+            return
+        dev = torch.device("cuda", torch.cuda.current_device())
+        total, plan = 0, []
+        for dw_ptr, db_ptr, wsize, bsize, lsp in self._partials:
+            stride = rup(wsize + bsize, 4)
+            plan.append((total, stride))
+            total += stride * len(lsp)
+        self.partial = torch.zeros(total, dtype=torch.float32, device=dev)
+        base = self.partial.data_ptr()
+        red = []
+        for (dw_ptr, db_ptr, wsize, bsize, lsp), (off, stride) in zip(self._partials, plan):
+            for sp, li in enumerate(lsp):
+                self.layers[li].dw = base + 4 * (off + sp * stride)
+                self.layers[li].db = (base + 4 * (off + sp * stride + wsize)) if bsize else None
+            red.append(ReduceItem(dw_ptr, base + 4 * off, wsize, stride, len(lsp), 0))
+            if bsize:
+                red.append(ReduceItem(db_ptr, base + 4 * (off + wsize), bsize, stride, len(lsp), 0))
+        self.reduce_tab, self.n_reduce = hip.device_table(red), len(red)
+        self.max_reduce = max(r.n for r in red)
+
     def finalize(self):
         if not self.layers:
             return
+        self._alloc_partials()
         if hip.lib().ssr_wgrad_co_tile(self.kdt, self.k) == 64 and os.environ.get("SSR_WGRAD_PAIR", "1") == "1":
             self.items = self._pair(self.items)
             if os.environ.get("SSR_WGRAD_BALANCE", "0") == "1":
@@ -605,6 +667,13 @@ class WgradBatch:
         if not self.layers:
             return
         lib = hip.lib()
+        if self.partial is not None:          # deterministic mode: zeroed partials -> wgrad -> fixed-order sum into the gradient
+            L.add(lib.ssr_fill, self.partial.data_ptr(), self.partial.numel(), hip.F32, 0.0, what="zero wgrad partials")
+        self._launch_wgrad(L, lib)
+        if self.partial is not None:
+            L.add(lib.ssr_wgrad_reduce, self.reduce_tab.data_ptr(), self.n_reduce, self.max_reduce, what="wgrad partials -> grad (fixed order)")
+
+    def _launch_wgrad(self, L: Launcher, lib):
         if self.dtype == hip.F32X3:
             for parent, hi_t, lo_t in self.splits:
                 L.add(lib.ssr_split_bf16, parent.data_ptr(), hi_t.data_ptr(), lo_t.data_ptr(), parent.numel(), what="split bf16")
@@ -665,6 +734,7 @@ class GeneratorPlan:
                  d_out_buf: Optional[torch.Tensor] = None, need_input_grad=False, wgrad_atomic: bool = False,
                  bwd_segments: int = 1):
         self.store, self.B, self.dt = store, B, store.dtype
+        self.det = deterministic()          # captured now: the weight-gradient batches below follow the mode the plan was built in
         self.scale, self.nf, self.nb, self.gc = scale, num_feat, num_block, num_grow_ch
         self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
         self.unshuffle = 2 if scale == 2 else 4 if scale == 1 else 1
@@ -772,7 +842,7 @@ class GeneratorPlan:
         if n_seg > 1:
             n_chunks = n_seg
         cuts = {round(n_rdb * q / n_chunks) for q in range(1, n_chunks)}     # close a batch before RDB index r in `cuts`
-        batches = [WgradBatch(self.dt, 3, 1, wgrad_atomic)]
+        batches = [WgradBatch(self.dt, 3, 1, wgrad_atomic, det=self.det)]
         self.bwd_segments = []        # [(Launcher, arena offset, arena elements)]
         seg_state = {"launcher": Bk, "hi": st.numel}
 
@@ -794,7 +864,9 @@ class GeneratorPlan:
                 # that stopped matching it would all-reduce the wrong slice silently)
                 assert 0 <= lo < hi <= st.numel, (next_first_key, lo, hi)
                 g0, esz = st.grad.data_ptr(), st.grad.element_size()
-                for Lw in wgb.layers:
+                for iw, Lw in enumerate(wgb.layers):
+                    if iw in wgb.virtual:          # per-split partial buffers of the deterministic mode (reduced into the arena in line)
+                        continue
                     for ptr in (Lw.dw, Lw.db):
                         if ptr:
                             off = (int(ptr) - g0) // esz
@@ -806,7 +878,7 @@ class GeneratorPlan:
                 sub = Launcher()
                 wgb.launch(sub)
                 Bk.fork(sub, what="wgrad chunk")
-            batches.append(WgradBatch(self.dt, 3, 1, wgrad_atomic))
+            batches.append(WgradBatch(self.dt, 3, 1, wgrad_atomic, det=self.det))
 
         Ho, Wo = self.Ho, self.Wo
         last_up = self.ups[-1]
@@ -1011,6 +1083,7 @@ class DiscriminatorPlan:
         assert H % 8 == 0 and W % 8 == 0, "U-Net discriminator needs H, W divisible by 8"
         assert num_feat % 8 == 0
         self.store, self.B, self.H, self.W, self.dt = store, B, H, W, store.dtype
+        self.det = deterministic()          # captured now: the backward plans (and their weight-gradient batches) are built lazily
         self.nf, self.skip, self.cd = num_feat, skip_connection, num_in_ch
         self.cdp = rup(num_in_ch, 8)
         tdt, dev = hip.torch_dtype(self.dt), store.device
@@ -1085,7 +1158,7 @@ class DiscriminatorPlan:
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         lib = hip.lib()
         L = Launcher()
-        wg3, wg4 = WgradBatch(dt, 3, 1), WgradBatch(dt, 4, 2)
+        wg3, wg4 = WgradBatch(dt, 3, 1, det=self.det), WgradBatch(dt, 4, 2, det=self.det)
 
         def add_wg(name, x, dy, hi, wi, gh, gw, cin=None):
             if not param_grads:

@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libssr_hip.so")
 
 F32, BF16, F32X3 = 0, 1, 2    # F32X3: fp32 storage, split-bf16 matrix math (include/ssr_hip.h)
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+DETERMINISTIC = 0x200          # OR-ed into the dtype of ssr_l1_loss / ssr_bce_logits_loss: per-block loss slots (include/ssr_hip.h)
+LOSS_SLOTS = 256
+SN_BWD_SLOTS = 64
 BILINEAR_FLAT = 0x100         # OR-ed into the dtype of ssr_bilinear2x_fwd / _bwd: per-pixel kernels for this call (include/ssr_hip.h)
 
 
@@ -96,6 +99,11 @@ class SNBwdItem(C.Structure):
                 ("dw", C.c_void_p), ("tmp", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("n", C.c_int64), ("stride", C.c_int64), ("parts", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("ema", C.c_void_p), ("n", C.c_int64), ("lr", C.c_void_p), ("step", C.c_void_p),
@@ -105,7 +113,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
@@ -140,6 +148,7 @@ def lib() -> C.CDLL:
     l.ssr_rdb_backward.argtypes = [C.POINTER(RdbDesc), vp]
     l.ssr_rdb_tile_of.argtypes = [C.POINTER(RdbDesc)]
     l.ssr_conv2d_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    l.ssr_wgrad_reduce.argtypes = [vp, i32, i64, vp]
     l.ssr_wgrad_ci_tile.argtypes = [i32, i32]
     l.ssr_wgrad_co_tile.argtypes = [i32, i32]
     l.ssr_wgrad_tiles.argtypes = [i32, i32, i32, i32, i32]

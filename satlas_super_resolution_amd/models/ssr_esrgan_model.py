@@ -71,7 +71,8 @@ def step_config_from_opt(opt: dict) -> StepConfig:
         l1_gt_usm=opt.get("l1_gt_usm", False) is not False, gan_gt_usm=opt.get("gan_gt_usm", False) is not False,
         percep_gt_usm=opt.get("percep_gt_usm", False) is not False,
         real_label=float(gan.get("real_label_val", 1.0)), fake_label=float(gan.get("fake_label_val", 0.0)),
-        perceptual=dict(perc) if perc else None)
+        perceptual=dict(perc) if perc else None,
+        deterministic=bool(opt.get("deterministic", False)))   # ours: fixed-order reductions only (bit-identical runs; train_step.StepConfig)
 
 
 @MODEL_REGISTRY.register()

@@ -73,7 +73,8 @@ class PerceptualPlan:
     the generator output, activations kept), `bwd` (loss, feature gradients, dgrads down to the image)."""
 
     def __init__(self, opt: Dict, B: int, H: int, W: int, dtype: int, x_buf: torch.Tensor, tgt_buf: torch.Tensor,
-                 grad_buf: torch.Tensor, loss_ptr: int, num_ch: int = 3, state: Optional[Dict[str, torch.Tensor]] = None):
+                 grad_buf: torch.Tensor, loss_ptr: int, num_ch: int = 3, state: Optional[Dict[str, torch.Tensor]] = None,
+                 loss_flags: int = 0):
         if opt.get("type", "PerceptualLoss") != "PerceptualLoss":
             raise NotImplementedError(f"train.perceptual_opt.type={opt.get('type')!r}")
         if opt.get("vgg_type", "vgg19") != "vgg19":
@@ -172,7 +173,7 @@ class PerceptualPlan:
             hh, ww = dims[name]
             cout = acts[name].shape[-1]
             # loss += w_k * pw * mean|Fx - Ft| ; g_F = w_k * pw * sign(Fx - Ft) / numel
-            Bk.add(lib.ssr_l1_loss, view(acts[name]), view(feats_t[name]), view(g_acts[name]), dtype, B * hh * ww, cout, wgt * self.pw,
+            Bk.add(lib.ssr_l1_loss, view(acts[name]), view(feats_t[name]), view(g_acts[name]), dtype | loss_flags, B * hh * ww, cout, wgt * self.pw,
                    loss_ptr, what=f"feature L1 {name}")
         for li in reversed(range(len(layers))):
             name, idx, cin, cout, pooled_before = layers[li]

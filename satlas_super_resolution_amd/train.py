@@ -51,9 +51,9 @@ def train(opt: Dict, max_iters: Optional[int] = None, resume_state: Optional[Dic
         if hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(epoch)
         for batch in loader:
+            if current_iter >= total_iters:      # (the reference's loop counts one past the end before it breaks: train.py:104-108;
+                break                            #  the returned iteration count is the number of optimizer steps taken)
             current_iter += 1
-            if current_iter > total_iters:
-                break
             model.update_learning_rate(current_iter, warmup_iter=opt["train"].get("warmup_iter", -1))
             model.feed_data(batch)
             model.optimize_parameters(current_iter)

@@ -39,6 +39,7 @@ class StepConfig:
     perceptual: Optional[Dict] = None   # train.perceptual_opt (VGG19 feature L1, :153-160; yml :123-137)
     real_label: float = 1.0
     fake_label: float = 0.0
+    deterministic: bool = False    # fixed-order reductions only: two runs give bit-identical parameters (engine.deterministic; SSR_DETERMINISTIC=1)
 
 
 LOSS_KEYS = ("l_g_pix", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake")
@@ -109,7 +110,15 @@ class ESRGANTrainStep:
         self.percep_tgt = target_for(bool(cfg.percep_gt_usm)) if cfg.perceptual else None
         self._tgt_by_flag = by_flag
         self._gt_usm = None   # fp32 NCHW scratch for ssr_usm_sharp
-        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        # deterministic mode (cfg.deterministic / SSR_DETERMINISTIC=1): every loss scalar is SSR_LOSS_SLOTS per-block slots that
+        # log() adds in index order; weight gradients of split layers go through per-split partial buffers (engine.WgradBatch);
+        # the generator runs as ONE chain (two half-batch chains would add into the same gradients concurrently)
+        self.det = bool(cfg.deterministic) or engine.deterministic()
+        self._det_ctx = engine.deterministic_mode(self.det)
+        self._det_ctx.__enter__()
+        self.loss_dt = self.dt | (hip.DETERMINISTIC if self.det else 0)
+        self.loss_stride = hip.LOSS_SLOTS if self.det else 1
+        self.losses = torch.zeros(8 * self.loss_stride, dtype=torch.float32, device=dev)
         self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
                                                num_feat=d_kwargs.get("num_feat", 64),
                                                skip_connection=d_kwargs.get("skip_connection", True))
@@ -126,7 +135,7 @@ class ESRGANTrainStep:
         probe.dtype, probe.N, probe.H, probe.W = hip.BF16, B, h, w
         wide = hip.lib().ssr_rdb_tile_of(C.byref(probe)) == 16
         n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
-        split = n_split > 1 and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
+        split = n_split > 1 and not self.det and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
             and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
         if split:
             self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
@@ -141,10 +150,12 @@ class ESRGANTrainStep:
         if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
             from .perceptual import PerceptualPlan
             self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.dt, self.fake_in, self.percep_tgt, self.grad_l1,
-                                         self.losses.data_ptr() + 4 * 6, num_ch=cout, state=vgg_state)
+                                         self.losses.data_ptr() + 4 * 6 * self.loss_stride, num_ch=cout, state=vgg_state,
+                                         loss_flags=self.loss_dt & hip.DETERMINISTIC)
             self.p_plan.pack()
         self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
         self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas_d or cfg.betas, cfg.eps, 0.0)
+        self._det_ctx.__exit__()
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
         self._warm = set()
         self._side = None
@@ -213,10 +224,10 @@ class ESRGANTrainStep:
     # ------------------------------------------------------------------ phases
     def _bce(self, target, weight, loss_idx, mean_idx, with_grad=True, plan=None):
         d = plan or self.d_plan
-        lp = self.losses.data_ptr()
+        lp, ls = self.losses.data_ptr(), 4 * self.loss_stride
         hip.check(hip.lib().ssr_bce_logits_loss(view(d.logits), view(d.d_logits) if with_grad else hip.NULL_VIEW,
-                                                self.dt, self.B * self.H * self.W, target, weight, lp + 4 * loss_idx,
-                                                (lp + 4 * mean_idx) if mean_idx is not None else None,
+                                                self.loss_dt, self.B * self.H * self.W, target, weight, lp + ls * loss_idx,
+                                                (lp + ls * mean_idx) if mean_idx is not None else None,
                                                 hip.stream_ptr()), "ssr_bce_logits_loss")
 
     def _d_forward(self, x_buf):
@@ -230,7 +241,7 @@ class ESRGANTrainStep:
         self.losses.zero_()
         self.g_store.pack()
         self.g_plan.fwd.run()                                              # :140
-        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.dt,
+        hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.loss_dt,
                                         self.B * self.H * self.W, self.cout, cfg.l1_weight, self.losses.data_ptr(),
                                         hip.stream_ptr()), "ssr_l1_loss")   # :147-150
         if self.p_plan is not None:                                        # :153-160
@@ -384,7 +395,8 @@ class ESRGANTrainStep:
     # ------------------------------------------------------------------ results
     def log(self) -> "OrderedDict[str, float]":
         """get_current_log(): one host sync, only when the caller logs (train.py:116-121)."""
-        vals = self.dp.reduce_scalars(self.losses).tolist()
+        scal = self.losses if not self.det else self.losses.view(8, self.loss_stride).double().cpu().sum(1).float().to(self.losses.device)
+        vals = self.dp.reduce_scalars(scal).tolist()      # det: the per-block slots added in index order on the host
         out = OrderedDict((k, vals[i]) for i, k in enumerate(LOSS_KEYS))
         if self.p_plan is not None:
             out["l_g_percep"] = vals[6]

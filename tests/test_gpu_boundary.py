@@ -19,9 +19,19 @@ def _tiny(c_in=6, c_d=3, nb=1):
     return g_kw, d_kw, O.generator_init(seed=31, **g_kw), O.discriminator_init(c_d, 8, seed=32)
 
 
-def _close_update(got, ref, p0, what, frac=2e-2):
+def _close_update(got, ref, p0, what, frac=2e-2, lr_steps=None):
+    """Post-step parameters compared on the UPDATE.  With `lr_steps` (= lr x number of Adam steps): Adam normalises the gradient,
+    so an element whose gradient is at rounding level gets a +-lr step whose size is noise in any fp32 implementation - at most
+    0.1 % of a tensor's elements may leave the tight bound, and none by more than the maximal Adam step (as
+    tests/test_gpu_parity.py::_update_close)."""
     upd_ref, upd = ref - p0, got - p0
-    assert (upd - upd_ref).abs().max() <= frac * upd_ref.abs().max() + 3e-7 * ref.abs().max() + 1e-9, what
+    err = (upd - upd_ref).abs()
+    tight = frac * upd_ref.abs().max() + 3e-7 * ref.abs().max() + 1e-9
+    if lr_steps is None:
+        assert err.max() <= tight, what
+        return
+    assert (err > tight).float().mean().item() <= 1e-3, (what, "fraction of elements off", (err > tight).float().mean().item())
+    assert err.max() <= 2.1 * lr_steps + tight, (what, float(err.max()))
 
 
 def test_gated_iterations_follow_the_reference_incl_ema():
@@ -446,17 +456,18 @@ def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
         if "l_g_pix" not in ref:                  # a gated iteration: the reference's log has no generator terms
             assert log.get("l_g_pix", 0.0) == 0.0
     n = len(fx["data"])
+    steps = fx["lr"] * n if name == "stepref_usm" else None      # the smooth targets of this fixture leave a few gradients at rounding level
     for k, v in fx["g_final"].items():
-        _close_update(m.ts.g_store.tensor(k).cpu(), v, fx["g0"][k], ("G", k), 5e-2)
+        _close_update(m.ts.g_store.tensor(k).cpu(), v, fx["g0"][k], ("G", k), 5e-2, steps)
     sd_d = m.ts.d_store.state_dict()
     for k, v in fx["d_final"].items():
         if k.endswith("_u") or k.endswith("_v"):
             assert rel_err(sd_d[k].cpu(), v) < 1e-3, ("D buffer", k)
         else:
-            _close_update(sd_d[k].cpu(), v, fx["d0"][k], ("D", k), 5e-2)
+            _close_update(sd_d[k].cpu(), v, fx["d0"][k], ("D", k), 5e-2, steps)
     ema = m.ts.ema_state_dict()
     for k, v in fx["g_ema_final"].items():
-        _close_update(ema[k].cpu(), v, fx["g0"][k], ("EMA", k), 5e-2)
+        _close_update(ema[k].cpu(), v, fx["g0"][k], ("EMA", k), 5e-2, None if steps is None else steps * (1 - fx["ema_decay"]) * n)
     if name == "stepref_usm":                     # the device's sharpened L1 target (ssr_usm_sharp) against what the reference run fed its L1 loss
         tgt = m.ts.l1_tgt[..., :3].permute(0, 3, 1, 2).float().cpu()
         assert m.ts.l1_tgt is not m.ts.real_in

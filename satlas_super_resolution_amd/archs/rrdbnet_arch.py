@@ -14,18 +14,23 @@ from ..registry import ARCH_REGISTRY
 from .hipnet import HipNet
 
 
+def _generator_forward(net, need, x):
+    net.store()
+    B, _, H, W = x.shape
+    plan = net.plan(B, H, W, training=need)
+    net.pack_if_stale()
+    plan.load_input(x.detach().contiguous().float())
+    net.run_forward(plan)
+    plan.generation = getattr(plan, "generation", 0) + 1
+    return plan, plan.read_output()
+
+
 class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, need, x, *params):
-        st = net.store()
-        B, _, H, W = x.shape
-        plan = net.plan(B, H, W, training=need)
-        net.pack_if_stale()
-        plan.load_input(x.detach().contiguous().float())
-        plan.fwd.run()
-        plan.generation = getattr(plan, "generation", 0) + 1
+        plan, y = _generator_forward(net, need, x)
         ctx.net, ctx.plan, ctx.gen = net, plan, plan.generation
-        return plan.read_output()
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -62,6 +67,8 @@ class SSR_RRDBNet(HipNet):
         return self._plans[key]
 
     def forward(self, x):
+        if not torch.is_grad_enabled():      # inference: no autograd node (and no marshalling of 702 parameters through Function.apply)
+            return _generator_forward(self, False, x)[1]
         params = list(self.parameters())
         # grad mode is off inside Function.forward: decide here whether activations must be retained
         need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))

@@ -19,6 +19,19 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 
+def host_cores() -> int:
+    """cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    machine's CPUs even inside a container limited to a few)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def read_png(path: str) -> np.ndarray:
     from PIL import Image
     with Image.open(path) as im:
@@ -29,10 +42,30 @@ def read_many(paths: Sequence[str]) -> List[np.ndarray]:
     return [read_png(p) for p in paths]
 
 
+def encode_png(arr: np.ndarray, level: int = 1) -> bytes:
+    """A [H, W, 3] uint8 image as an 8-bit RGB PNG: filter type 0 ("None") on every scanline, one IDAT chunk, zlib level `level`.
+    Same pixels as any other encoder's file; 4-6x cheaper than Pillow's writer, which tries the five row filters on every
+    scanline before zlib's default level 6 (2.7 ms per 128 x 128 chunk against 0.45 ms here; the 2048 x 2048 mosaic 160 ms
+    against 70 ms) - the PNG encode was what kept whole-tile inference host-bound (profiles/r03io_*.json)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 3, a.shape
+    h, w = a.shape[:2]
+    rows = np.empty((h, 1 + 3 * w), np.uint8)
+    rows[:, 0] = 0                                    # filter type of the scanline: None
+    rows[:, 1:] = a.reshape(h, 3 * w)
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(rows.tobytes(), level)) + chunk(b"IEND", b""))
+
+
 def save_png(arr: np.ndarray, path: str) -> None:
-    from PIL import Image
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    Image.fromarray(np.ascontiguousarray(arr)).save(path)
+    with open(path, "wb") as f:
+        f.write(encode_png(arr))
 
 
 def save_many(items: Sequence[Tuple[np.ndarray, str]]) -> int:
@@ -66,7 +99,92 @@ def stitch_from_dir(chunks_dir: str, img_size: int, path: str, sentinel2: bool =
     return stitch_and_save(cells, img_size, path, sentinel2)
 
 
-_TASKS = {"read_many": read_many, "save_many": save_many, "stitch_and_save": stitch_and_save, "stitch_from_dir": stitch_from_dir}
+# ---- shared-memory transport (round 4).  Pixels do not travel through the pipes: the driver and the workers map the same files
+# (np.memmap of files under /dev/shm, or under the temporary directory when /dev/shm is small), a task names a block, offsets and
+# shapes.  With pickled arrays the driver thread moved ~37 MB per tile through 64-KB pipe buffers under the GIL and whole-tile
+# inference stayed at 4.4 tiles/s whatever the codecs cost (profiles/r04j_*.json).
+class ShmBlock:
+    """a file-backed shared byte block; the creating side owns (and finally unlinks) the file"""
+
+    _serial = [0]
+
+    def __init__(self, nbytes: int, directory: str, tag: str):
+        self.nbytes = int(nbytes)
+        ShmBlock._serial[0] += 1           # never the same path twice: the (long-lived) workers cache their mappings by path
+        self.path = os.path.join(directory, f"ssr_png_{os.getpid()}_{ShmBlock._serial[0]}_{tag}")
+        import mmap
+        with open(self.path, "wb") as f:
+            f.truncate(self.nbytes)
+        self._f = open(self.path, "r+b")
+        self._mm = mmap.mmap(self._f.fileno(), self.nbytes)
+        self.buf = np.frombuffer(self._mm, dtype=np.uint8)       # a plain ndarray: slicing a np.memmap costs ~10 us per view
+
+    def close(self):
+        self.buf = None                                        # (the mapping itself goes when the last view of it does)
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
+
+
+def shm_dir(need_bytes: int) -> str:
+    import shutil
+    import tempfile
+    try:
+        if shutil.disk_usage("/dev/shm").free >= 2 * need_bytes:
+            return "/dev/shm"
+    except OSError:
+        pass
+    return tempfile.gettempdir()
+
+
+_MAPS = {}
+
+
+def _map(path: str, nbytes: int) -> np.ndarray:
+    m = _MAPS.get(path)
+    if m is None or m.shape[0] != nbytes:
+        import mmap
+        if len(_MAPS) > 64:
+            _MAPS.clear()
+        with open(path, "r+b") as f:
+            m = _MAPS[path] = np.frombuffer(mmap.mmap(f.fileno(), nbytes), dtype=np.uint8)
+    return m
+
+
+def read_into(paths: Sequence[str], shm_path: str, nbytes: int, offsets: Sequence[int], slot_bytes: int):
+    """decode every file into its slot of the block; returns the shapes (an image that does not fit its slot comes back as an array)"""
+    m = _map(shm_path, nbytes)
+    out = []
+    for pth, off in zip(paths, offsets):
+        a = read_png(pth)
+        if a.nbytes > slot_bytes:
+            out.append(a)
+            continue
+        m[off:off + a.nbytes] = a.reshape(-1)
+        out.append(tuple(a.shape))
+    return out
+
+
+def save_from(shm_path: str, nbytes: int, items: Sequence[Tuple[int, Tuple[int, ...], str]]) -> int:
+    """encode and write the images that lie at (offset, shape) in the block"""
+    m = _map(shm_path, nbytes)
+    for off, shape, path in items:
+        n = int(np.prod(shape))
+        save_png(m[off:off + n].reshape(shape), path)
+    return len(items)
+
+
+def timed(name: str, *args):
+    """a task with its start / end times on the worker's clock (SSR_INFER_TRACE)"""
+    import time
+    t0 = time.time()
+    res = _TASKS[name](*args)
+    return (t0, time.time(), os.getpid(), res)
+
+
+_TASKS = {"read_many": read_many, "save_many": save_many, "stitch_and_save": stitch_and_save, "stitch_from_dir": stitch_from_dir,
+          "read_into": read_into, "save_from": save_from, "timed": timed}
 
 
 class PngWorkerPool:
@@ -121,11 +239,12 @@ class PngWorkerPool:
             self.q.put(None)
         for t in self.threads:
             t.join()
-        for p in self.procs:
+        for p in self.procs:               # every worker sees EOF first, then they exit side by side (one by one: 13 ms each)
             try:
                 p.stdin.close()
             except OSError:
                 pass
+        for p in self.procs:
             p.wait()
         self.procs, self.threads = [], []
 
@@ -134,6 +253,36 @@ class PngWorkerPool:
 
     def __exit__(self, *exc):
         self.close()
+
+
+_SHARED = {}
+
+
+class shared_pool:
+    """`with shared_pool(n) as pool`: a PngWorkerPool that outlives the block - the next call with the same n gets the same
+    workers (interpreter start + numpy / Pillow import of 15 processes is ~0.4 s, more than a whole tile takes); closed at exit.
+    Workers end by themselves when this process goes away (EOF on their stdin)."""
+
+    def __init__(self, n: int, threads: int = 8):
+        self.key = (n, threads)
+
+    def __enter__(self) -> "PngWorkerPool":
+        pool = _SHARED.get(self.key)
+        if pool is None or (pool.procs and any(p.poll() is not None for p in pool.procs)):
+            if not _SHARED:
+                import atexit
+                atexit.register(close_shared_pools)
+            pool = _SHARED[self.key] = PngWorkerPool(*self.key)
+        return pool
+
+    def __exit__(self, *exc):
+        return False
+
+
+def close_shared_pools():
+    for pool in list(_SHARED.values()):
+        pool.close()
+    _SHARED.clear()
 
 
 def _worker_main():

@@ -21,6 +21,15 @@ def format_s2naip_data(s2_data, n_s2_images: int, device):
     The reference's validity test `[0, 0, 0] in frame` on an ndarray is `(frame == [0, 0, 0]).any()`: a frame is set aside
     as soon as ANY of its values is 0 (:17).  The `random` module is consumed exactly as the reference does (one
     `random.sample` over the index list of the same length), so the same seed picks the same frames."""
+    chosen, first = select_frames(s2_data, n_s2_images)
+    stack = torch.from_numpy(chosen)                                                # [n, 32, 32, 3] uint8
+    s2_tensor = stack.permute(0, 3, 1, 2).reshape(1, n_s2_images * 3, 32, 32)      # frame-major, RGB inside a frame
+    return s2_tensor.to(device).float() / 255, first
+
+
+def select_frames(s2_data, n_s2_images: int):
+    """The host half of format_s2naip_data (infer_utils.py:6-32): which frames of the stack go to the network - the `random`
+    module consumed exactly as the reference consumes it.  Returns (uint8 [n_s2_images, 32, 32, 3], the first frame)."""
     frames = np.reshape(s2_data, (-1, 32, 32, 3))
     has_zero = (frames == 0).any(axis=(1, 2, 3))
     clean, dirty = np.flatnonzero(~has_zero).tolist(), np.flatnonzero(has_zero).tolist()
@@ -28,9 +37,14 @@ def format_s2naip_data(s2_data, n_s2_images: int, device):
         chosen = random.sample(clean, n_s2_images)
     else:
         chosen = clean + random.sample(dirty, n_s2_images - len(clean))
-    stack = torch.from_numpy(np.ascontiguousarray(frames[chosen]))                  # [n, 32, 32, 3] uint8
-    s2_tensor = stack.permute(0, 3, 1, 2).reshape(1, n_s2_images * 3, 32, 32)      # frame-major, RGB inside a frame
-    return s2_tensor.to(device).float() / 255, frames[0]
+    return np.ascontiguousarray(frames[chosen]), frames[0]
+
+
+def frames_to_input(sel_u8: torch.Tensor) -> torch.Tensor:
+    """The device half, for a whole batch at once: uint8 [B, n, 32, 32, 3] -> float [B, n*3, 32, 32] in [0, 1]; per chunk the
+    same permute / reshape / `.float() / 255` as format_s2naip_data (:33-38), so the values are bit-identical."""
+    b, n = sel_u8.shape[:2]
+    return sel_u8.permute(0, 1, 4, 2, 3).reshape(b, n * 3, 32, 32).float() / 255
 
 
 def quantize_output(output: torch.Tensor) -> np.ndarray:

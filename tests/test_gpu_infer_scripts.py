@@ -67,3 +67,45 @@ def test_infer_driver_matches_the_unmodified_reference_script(tmp_path):
         ref = fx["single_pairs"][M.digest(lr)].numpy()           # the reference's {i} follows glob's order: match by the low-res image
         mx, fr = _levels(sr, ref)
         assert sr.shape == (128, 128, 3) and mx <= 1 and fr <= 2e-3, (k, mx, fr)
+
+
+def test_infer_grid_two_ranks_write_their_shares_and_rank0_stitches_from_disk(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m satlas_super_resolution_amd.infer_grid -opt ...` as two processes on
+    this GPU (gloo standing in for RCCL; the data path has no collective, only the barrier in front of the stitch): rank r runs and
+    writes chunks r, r + 2, ..., rank 0 then builds both mosaics of every complete tile by RE-READING the chunk files of both
+    ranks (the reference's stitch(), /root/reference/ssr/utils/infer_utils.py:41-60).  Frame selection draws from `random` per
+    processed chunk (infer_utils.py:22-30), so a sharded run picks other frame orders than a serial one: layout, names, shapes and the
+    input mosaic are compared with the reference script's run, the super-resolved mosaic with this run's own chunk files."""
+    import socket
+    import subprocess
+    import sys
+    fx = load_golden("infer_scripts")
+    M, opt = _setup(tmp_path, "grid")
+    opt["compute_dtype"] = "fp32x3"
+    opt["io_workers"] = 2
+    with open(tmp_path / "opt.yml", "w") as f:
+        yaml.safe_dump(opt, f)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   SSR_DIST_BACKEND="gloo", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, "-m", "satlas_super_resolution_amd.infer_grid", "-opt", str(tmp_path / "opt.yml")],
+                                      cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "'chunks': 130" in outs[0] and "'chunks': 129" in outs[1], outs          # 259 chunks dealt round-robin
+    assert "'tiles_stitched': 1" in outs[0] and "'tiles_stitched': 0" in outs[1]
+    tree = M.read_tree(str(tmp_path / "out_grid"))
+    assert sorted(tree) == fx["grid_files"]
+    assert {k: tuple(v.shape) for k, v in tree.items()} == fx["grid_shapes"]
+    assert M.digest(tree["t0/stitched_s2.png"]) == fx["grid_stitched_s2_sha256"]
+    sr = tree["t0/stitched_sr.png"]
+    for i in range(16):
+        for j in range(16):               # every cell of the mosaic is the chunk file some rank wrote
+            assert np.array_equal(sr[128 * i:128 * (i + 1), 128 * j:128 * (j + 1)], tree[f"t0/{i}_{j}.png"]), (i, j)
+    assert float(sr.std()) > 5

@@ -98,9 +98,30 @@ typedef struct ssr_conv_desc {
     int32_t s2d;
     /* 0: the mask `m` is LeakyReLU' (1 | 0.2 by the sign of m); 1: ReLU' (1 | 0) — backward through the VGG19 layers */
     int32_t m_relu;
+    /* ---- LeakyReLU decision fix-up of the split-bf16 mode (SSR_F32X3; round 4).  The three-product split rounds a product at
+     * 2^-16 instead of 2^-24: ~10x more pre-activations land on the other side of zero than in an fp32 evaluation, and every such
+     * decision moves all upstream gradients by 0.8 x its gradient (measured: conv_first.weight 25 % of elements outside the 1e-3
+     * gate with 48 of 22.8 M decisions flipped).  With fix_list set on a LeakyReLU layer the epilogue appends every output whose
+     * pre-activation satisfies |v| < fix_thr to the list and ssr_conv2d_fixup recomputes exactly those from the fp32 inputs and
+     * the UNPACKED fp32 weights in double precision and rewrites y: the decisions are then those of an exact evaluation (the
+     * backward reads them from the sign of the stored output), all other outputs keep their 1e-5 accuracy.
+     *   fix_list: int32 [4 + 2 * fix_cap]: [0] entries appended (may exceed fix_cap: the surplus is dropped), [1] internal ticket,
+     *             [2] high-water mark of [0] (diagnostics), [3] unused; then (stored output pixel index, channel) pairs.  Zeroed
+     *             once by the host; ssr_conv2d_fixup resets [0] and [1].
+     *   w_ref: the layer's weights as the reference stores them, fp32 [Cout][w_ref_cin][KH][KW]; w_ref_sigma: NULL or the
+     *          spectral-norm sigma (the effective weight is w_ref / sigma[0]).
+     * Supported: stride 1, one input view (x2 = NULL), up 1 | 2, y only (no y0 / y1 / r1 / r2 / m / accumulate), alpha 1. */
+    int32_t* fix_list;
+    int32_t fix_cap;
+    float fix_thr;
+    const float* w_ref;
+    const float* w_ref_sigma;
+    int32_t w_ref_cin;
 } ssr_conv_desc;
 
 int ssr_conv2d(const ssr_conv_desc* d, void* stream);
+/* recompute the outputs the launch of `d` listed in d->fix_list (see the fix_* fields); a no-op launch when the list is empty */
+int ssr_conv2d_fixup(const ssr_conv_desc* d, void* stream);
 /* n <= 4 descriptors (host array) of identical geometry in ONE launch where the kernel family supports it (the four
  * output-parity classes of a 4x4 stride-2 dgrad, built by the host as 2x2 stride-1 convolutions); otherwise n launches. */
 int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream);

@@ -628,6 +628,67 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
 
 extern "C" int ssr_conv2d(const ssr_conv_desc* dp, void* stream) { return conv2d_impl(dp, stream, 0); }
 
+// ---- LeakyReLU decision fix-up of the split-bf16 mode (include/ssr_hip.h, ssr_conv_desc.fix_*) ----
+// One wave per listed output: the K = Cin * KH * KW products of the reference's convolution (ssr/archs/rrdbnet_arch.py:39-42,
+// discriminator_arch.py:45-69: F.conv2d of fp32 tensors) from the fp32 inputs and the unpacked fp32 weights, summed in double
+// (lane k takes products k, k + 64, ...; xor-shuffle tree), + bias, LeakyReLU, stored over the split-bf16 value.  The list is
+// short (|v| < fix_thr: a few 1e-4 of the outputs), the launch is a handful of microseconds.
+namespace {
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const ssr_conv_desc d) {
+    int* hdr = d.fix_list;
+    const int count = min(hdr[0], d.fix_cap);          // every block reads it before the last one to finish resets it
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const int KK = d.KH * d.KW, K = d.w_ref_cin * KK;
+    const float* __restrict__ xp = reinterpret_cast<const float*>(d.x.p);
+    float* __restrict__ yp = reinterpret_cast<float*>(d.y.p);
+    const double inv_sigma = d.w_ref_sigma ? 1.0 / (double)d.w_ref_sigma[0] : 1.0;
+    const int sh = d.up == 2 ? 1 : 0, LH = d.Hi << sh, LW = d.Wi << sh;
+    for (int e = blockIdx.x * 4 + wave; e < count; e += nw) {
+        const int p = hdr[4 + 2 * e], co = hdr[5 + 2 * e];
+        const int ox = p % d.Wo, t = p / d.Wo, oy = t % d.Ho, n = t / d.Ho;
+        const float* __restrict__ wrow = d.w_ref + (size_t)co * K;
+        double s = 0.0;
+        for (int k = lane; k < K; k += 64) {
+            const int ci = k / KK, tap = k - ci * KK, ky = tap / d.KW, kx = tap - ky * d.KW;
+            const int iy = oy * d.stride + ky - d.pad_y, ix = ox * d.stride + kx - d.pad_x;
+            if (iy >= 0 && iy < LH && ix >= 0 && ix < LW) {
+                const size_t px = (size_t)(n * d.Hi + (iy >> sh)) * d.Wi + (ix >> sh);
+                s += (double)wrow[k] * (double)xp[px * d.x.cs + d.x.coff + ci];
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) {
+            const float v = (float)(s * inv_sigma + (d.bias ? (double)d.bias[co] : 0.0));
+            yp[(size_t)p * d.y.cs + d.y.coff + co] = lrelu(v);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(hdr + 1, 1) == (int)gridDim.x - 1) {     // the last block: the list is consumed
+            atomicMax(hdr + 2, hdr[0]);
+            hdr[0] = 0;
+            hdr[1] = 0;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ssr_conv2d_fixup(const ssr_conv_desc* dp, void* stream) {
+    if (!dp) return SSR_EINVAL;
+    const ssr_conv_desc& d = *dp;
+    if (!d.fix_list || d.fix_cap <= 0 || !d.w_ref || d.w_ref_cin <= 0 || !d.x.p || !d.y.p) return SSR_EINVAL;
+    if ((d.dtype != SSR_F32X3 && d.dtype != SSR_F32) || d.act != SSR_ACT_LRELU || d.x2.p || d.y0.p || d.y1.p || d.r1.p || d.r2.p || d.m.p ||
+        d.accumulate || d.alpha != 1.f || d.stride != 1 || d.s2d || d.oys != 1 || d.oxs != 1 || d.oyo != 0 || d.oxo != 0 ||
+        d.w_ref_cin > d.Cin)
+        return SSR_EUNSUP;
+    hipLaunchKernelGGL(conv_fixup_kernel, dim3(32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
 // n (<= 4) descriptors that differ only in pointers / padding / output offsets: one launch when they are 2x2 stride-1
 // bf16 layers of identical geometry (the parity classes of a 4x4 stride-2 dgrad), otherwise n launches.
 extern "C" int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream) {

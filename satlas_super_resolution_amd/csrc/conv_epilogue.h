@@ -66,6 +66,15 @@ __device__ __forceinline__ void conv_epilogue(const ssr_conv_desc& d, const f32x
     }
     // ---- phase 2: arithmetic ----
     float s0[16], s1[16], s2[16];
+    if (d.fix_list && d.act == SSR_ACT_LRELU && co_ok) {
+        // split-bf16 mode: pre-activations at rounding level go on the list ssr_conv2d_fixup recomputes exactly (include/ssr_hip.h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (po[r] >= 0 && fabsf(acc[r] + bv) < d.fix_thr) {
+                const int k = atomicAdd(d.fix_list, 1);
+                if (k < d.fix_cap) { d.fix_list[4 + 2 * k] = po[r]; d.fix_list[5 + 2 * k] = co; }
+            }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = acc[r] + bv;

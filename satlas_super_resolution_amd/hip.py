@@ -51,6 +51,8 @@ class ConvDesc(C.Structure):
         ("accumulate", C.c_int32),
         ("m", View), ("m_c0", C.c_int32), ("m_c1", C.c_int32),
         ("s2d", C.c_int32), ("m_relu", C.c_int32),
+        ("fix_list", C.c_void_p), ("fix_cap", C.c_int32), ("fix_thr", C.c_float), ("w_ref", C.c_void_p), ("w_ref_sigma", C.c_void_p),
+        ("w_ref_cin", C.c_int32),
     ]
 
 
@@ -113,7 +115,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_fixup", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
@@ -139,6 +141,7 @@ def lib() -> C.CDLL:
         raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     l.ssr_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
+    l.ssr_conv2d_fixup.argtypes = [C.POINTER(ConvDesc), vp]
     l.ssr_conv2d_impl.argtypes = [C.POINTER(ConvDesc), vp, i32]
     l.ssr_conv2d_batch.argtypes = [C.POINTER(ConvDesc), i32, vp]
     l.ssr_conv2d_variant.argtypes = [C.POINTER(ConvDesc)]

@@ -402,7 +402,10 @@ def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
     upstream of it, so the deviation grows towards the first layers: r02u measured conv_first.weight / D conv0.weight 5 - 25 % of
     elements outside the gate (max-norm 2.7e-3 .. 7e-3, mean <= 8e-4) and the input gradients 0.6 - 5.7 % (max-norm <= 2e-2), while
     every single layer is within 1e-5 layer-locally and the forward output within 2e-5.  The mode's contract is therefore:
-    OUTPUT parity at the 1e-3 gate, gradients of training quality; the gradient-exact mode is `fp32`."""
+    OUTPUT parity at the 1e-3 gate, gradients of training quality; the gradient-exact mode is `fp32`.
+    "fp32x3-fix" (round 4, engine.X3_FIXUP): pre-activations below 1e-4 recomputed in double from the layer's fp32 inputs.  It
+    removes a fifth of the differing decisions (r04m: 48 -> 38 in G, 9 -> 4 in D, the same with a threshold of 1e-3): the rest
+    come from the 1e-5 perturbation the layer's INPUTS carry, which no local repair reaches.  Reported, not asserted."""
     got, ref32, ref64 = got.detach().double().cpu(), ref32.detach().double().cpu(), ref64.detach().double().cpu()
     scale = float(ref64.abs().max())
     lim = 1e-3 * (scale + ref64.abs())
@@ -417,8 +420,8 @@ def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
         assert e_dev <= 0.1 and m_dev <= 1e-2, (what, f_dev, e_dev, m_dev)      # sanity bound only: see the docstring
 
 
-@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24)])   # full_g96 pins the oracle (CPU test)
-def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
+@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24), ("fp32x3-fix", "full_g24", 24)])   # full_g96 pins the oracle (CPU test)
+def test_generator_vs_reference_class_at_full_size(mode, name, c_in, monkeypatch):
     """SSR_RRDBNet(nf=64, gc=32, nb=23) forward + backward on the device against what the UNMODIFIED reference class produced for
     the same parameters and inputs (oracle/make_golden_fullsize.py; the reference, not the oracle, is the comparison target)."""
     from conftest import load_golden
@@ -430,7 +433,8 @@ def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
     sd = biased(O.generator_init(seed=fx["seed"], **kw), fx["seed"] + 1)
     x, g = _seeded(fx, (2, c_in, 32, 32))
     r = torch.randn(2, 3, 128, 128, generator=g)
-    st = engine.ParamStore(engine.generator_specs(**kw), _set_mode(mode))
+    monkeypatch.setattr(engine, "X3_FIXUP", [mode.endswith("-fix")])     # "-fix": with the LeakyReLU decision fix-up (engine.X3_FIXUP: reported, see there)
+    st = engine.ParamStore(engine.generator_specs(**kw), _set_mode(mode.split("-")[0]))
     st.load_state_dict(sd)
     plan = engine.GeneratorPlan(st, 2, 32, 32, training=True, need_input_grad=True, **kw)
     st.pack()
@@ -438,6 +442,11 @@ def test_generator_vs_reference_class_at_full_size(mode, name, c_in):
     plan.fwd.run()
     y = plan.read_output().cpu()
     assert parity_close(y, fx["y"]), rel_err(y, fx["y"])
+    if mode == "fp32x3-fix":      # the decision fix-up ran: some outputs were listed, and no list overflowed
+        torch.cuda.synchronize()
+        hw = plan._cb.fix_high_water()
+        print(f"[fp32x3-fix] largest LeakyReLU fix-up list of the forward: {hw} outputs (capacity {engine.X3_FIX_CAP})")
+        assert 0 < hw < engine.X3_FIX_CAP
     plan.load_output_grad(r.cuda())
     st.grad.zero_()
     plan.bwd.run()
@@ -471,7 +480,7 @@ def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
     worst = max(range(len(prec.flips)), key=lambda i: prec.flips[i] / prec.sizes[i])
     print(f"[{mode} masked] LeakyReLU decisions that differ from the float64 oracle's own: {flips} of {total} ({flips / total:.2e}); "
           f"worst activation #{worst}: {prec.flips[worst]} of {prec.sizes[worst]}")
-    tol = 2e-4 if mode == "fp32x3" else 1e-4          # of max|ref| per tensor; measured: see the printed lines
+    tol = 2e-4 if mode.startswith("fp32x3") else 1e-4          # of max|ref| per tensor; measured: see the printed lines
     worst_err = 0.0
     for k, g in got.items():
         ref = xm.grad if k.startswith("dx") else sdm[k].grad
@@ -486,8 +495,8 @@ def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
     print(f"[{mode} masked] worst parameter / input gradient deviation from the mask-conditioned float64 oracle: {worst_err:.2e} of max|ref| (asserted <= {tol:.0e})")
 
 
-@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3")])                    # full_d27 pins the oracle (CPU test)
-def test_discriminator_vs_reference_class_at_full_size(mode, name):
+@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), ("fp32x3-fix", "full_d3")])                    # full_d27 pins the oracle (CPU test)
+def test_discriminator_vs_reference_class_at_full_size(mode, name, monkeypatch):
     """SSR_UNetDiscriminatorSN(nf=64) on 128x128 (3- and 27-channel input) against the unmodified reference class: logits, input
     gradient, parameter gradients through the spectral norm, u / v after the power iteration."""
     from conftest import load_golden
@@ -498,7 +507,8 @@ def test_discriminator_vs_reference_class_at_full_size(mode, name):
     sd = O.discriminator_init(c_d, 64, seed=fx["seed"])
     x, g = _seeded(fx, (1, c_d, 128, 128))
     r = torch.randn(1, 1, 128, 128, generator=g)
-    dt = _set_mode(mode)
+    monkeypatch.setattr(engine, "X3_FIXUP", [mode.endswith("-fix")])     # "-fix": with the LeakyReLU decision fix-up (reported)
+    dt = _set_mode(mode.split("-")[0])
     st = engine.ParamStore(engine.discriminator_specs(c_d, 64, in_hw=(128, 128)), dt)
     st.load_state_dict(sd)
     plan = engine.DiscriminatorPlan(st, 1, 128, 128, num_in_ch=c_d, num_feat=64, skip_connection=True)

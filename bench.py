@@ -245,6 +245,30 @@ GATE = {
 }
 
 
+def pmc_traffic(dom, dtype, B, frames):
+    """HBM bytes per launch of kernel `dom` from rocprofv3 PMC passes (tools/pmc_traffic.py).  Counters cannot be collected from
+    inside this process, so the number is only reported when the profile file (profiles/traffic.json for bf16,
+    profiles/traffic_<dtype>.json for the other modes) was collected on THIS build of the library (source hash) at THIS
+    configuration; otherwise (None, note naming the dated file)."""
+    tp = os.path.join(ROOT, "profiles", "traffic.json" if dtype == "bf16" else f"traffic_{dtype}.json")
+    if not os.path.exists(tp):
+        return None, f"{os.path.relpath(tp, ROOT)} not collected"
+    try:
+        from satlas_super_resolution_amd import build as bld
+        tj = json.load(open(tp))
+        meta = tj.get("_meta", {})
+        same = (meta.get("source_hash") == bld.source_hash() and meta.get("batch") == B and meta.get("frames") == frames
+                and meta.get("dtype") == dtype)
+        detail = tj.get(dom)
+        if same and isinstance(detail, dict):
+            return detail["bytes_per_launch"], None
+        return None, (f"{os.path.relpath(tp, ROOT)} holds PMC traffic for build {str(meta.get('source_hash'))[:12]} at batch {meta.get('batch')}, "
+                      f"frames {meta.get('frames')}, {meta.get('dtype')} ({meta.get('collected', 'undated')}): not this build/config"
+                      + ("" if isinstance(detail, dict) else f", or no entry for {dom}") + ", so not reported as this run's")
+    except Exception as e:   # noqa: BLE001
+        return None, f"{os.path.relpath(tp, ROOT)} unreadable: {e}"
+
+
 def roofline_of(agg, dtype):
     """dominant MFMA kernel of an instrumented step: algorithmic FLOPs of its launches / their summed duration"""
     conv = {k: v for k, v in agg.items() if v[2] > 0}
@@ -279,7 +303,10 @@ def precision_leg(args, dtype, g_kw, d_kw, c_in, c_d, B, lr, gt, steps):
     finite = all(v == v and abs(v) < 1e30 for v in ts.log().values())
     roof = None
     if not args.no_roofline:
-        _, roof = roofline_of(instrumented_step(ts, args, dtype), dtype)
+        dom, roof = roofline_of(instrumented_step(ts, args, dtype), dtype)
+        roof["traffic"], note = pmc_traffic(dom, dtype, B, args.frames)
+        if note:
+            roof["traffic_note"] = note
     del ts
     gc.collect()
     torch.cuda.empty_cache()
@@ -401,27 +428,7 @@ def main():
     trace("instrumented step done")
     if ctx.rank == 0 and agg is not None:
         dom, roof0 = roofline_of(agg, args.dtype)
-        # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py).  Counters cannot be collected from inside
-        # this process, so the number is only reported when profiles/traffic.json was collected on THIS build of the library
-        # (source hash) at THIS configuration; otherwise null, with a pointer to the dated file.
-        traffic, traffic_note = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                from satlas_super_resolution_amd import build as bld
-                tj = json.load(open(tp))
-                meta = tj.get("_meta", {})
-                same = (meta.get("source_hash") == bld.source_hash() and meta.get("batch") == B and meta.get("frames") == args.frames
-                        and meta.get("dtype") == args.dtype)
-                detail = tj.get(dom)
-                if same and isinstance(detail, dict):
-                    traffic = detail["bytes_per_launch"]
-                else:
-                    traffic_note = (f"profiles/traffic.json holds PMC traffic for build {str(meta.get('source_hash'))[:12]} at "
-                                    f"batch {meta.get('batch')}, frames {meta.get('frames')}, {meta.get('dtype')} "
-                                    f"({meta.get('collected', 'undated')}): not this build/config, so not reported as this run's")
-            except Exception as e:   # noqa: BLE001
-                traffic_note = f"profiles/traffic.json unreadable: {e}"
+        traffic, traffic_note = pmc_traffic(dom, args.dtype, B, args.frames)
         out["roofline"] = dict(roof0, traffic=traffic)
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note

@@ -97,8 +97,23 @@ template <int TW> struct RtGeo {
     static constexpr int base(int s) { return s == 0 ? ACT : s == 1 ? ACT + 2 * PLANE : base(s - 1) + rows(s - 1) * 64; }
     static constexpr int DUMMY = base(4) + rows(4) * 64;
     static constexpr int SCR = DUMMY + 64;                     // 256 B: where lanes 1..63 of a flag write go (never read)
+    // M-tiles (32 pixels) per stage
+    static constexpr int ntiles(int K) {
+        return TW == 16 ? (K == 1 ? 12 : K == 2 ? 10 : K == 3 ? 8 : K == 4 ? 6 : 4) : (K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2);
+    }
     static constexpr int SRC = SCR + 256;                      // [80] 64-bit source address of every weight slab
-    static constexpr int LDS = SRC + 640;
+    // the lane -> pixel map of the five stages ([tile][32 lanes] ushort, the tiles of a stage back to back: 12 + 10 + 8 + 6 + 4 at
+    // TW = 16), copied from global memory with ONE 16-byte load per thread in the prologue.  (Round 4: the MFMA waves used to fetch
+    // their eleven entries with separate global loads into registers that hipcc spilled at once - each spill behind an
+    // s_waitcnt vmcnt(0), four memory latencies in a row in front of the first MFMA.)
+    static constexpr int MAP = SRC + 640;
+    static constexpr int map_tile0(int K) {
+        int t0 = 0;
+        for (int k = 1; k < K; ++k) t0 += ntiles(k);
+        return t0;
+    }
+    static constexpr int MAP_TILES = map_tile0(5) + ntiles(5);
+    static constexpr int LDS = MAP + MAP_TILES * 64;
     static_assert(ACT % 64 == 0, "activation rows are 64-byte aligned");
     static constexpr int TROW = 80;               // output transpose slab: [32 px][32 co] bf16, 80-B rows, one per wave
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -123,10 +138,6 @@ template <int TW> struct RtGeo {
     static constexpr int stage_off(int q) { return is_extra(q) ? xstage(q & 3) : RING + (q % NST) * RT_SLAB; }
     static constexpr int stage_word(int q) { return is_extra(q) ? 4 + (q & 3) : q % NST; }
     static constexpr int XB = 49152;                            // second base for DS immediates beyond 64 KB
-    // M-tiles (32 pixels) per stage
-    static constexpr int ntiles(int K) {
-        return TW == 16 ? (K == 1 ? 12 : K == 2 ? 10 : K == 3 ? 8 : K == 4 ? 6 : 4) : (K == 1 ? 8 : K == 2 ? 7 : K == 3 ? 5 : K == 4 ? 4 : 2);
-    }
     // M-tile m of MFMA wave w (0..7; waves w and w + 4 share a SIMD) in growth stage K; -1: none.  A wave without a tile skips
     // the stage (it releases the stage's slabs at once).  TW = 16: the SIMDs carry 3,3,3,3 | 3,3,2,2 | 2,2,2,2 | 1,1,2,2 tiles.
     static constexpr int tile_of(int K, int w, int m) {
@@ -209,12 +220,26 @@ template <int TW> constexpr bool rt_map_complete() {   // every region pixel is 
 }
 static_assert(rt_map_complete<16>(), "lane -> pixel map must cover every region exactly once");
 static_assert(rt_map_complete<8>(), "lane -> pixel map must cover every region exactly once");
-template <int TW> struct RtMapHolder { static const RtMap<TW> map; };
-__device__ const RtMap<16> rt_map16 = rt_make_map<16>();
-__device__ const RtMap<8> rt_map8 = rt_make_map<8>();
-template <int TW> __device__ __forceinline__ int rt_map_entry(int K, int t, int i) {
-    if constexpr (TW == 16) return rt_map16.e[K - 1][t][i];
-    else return rt_map8.e[K - 1][t][i];
+// compact copy for the kernel: the tiles of the five stages back to back (RtGeo::map_tile0), 64 bytes per tile, padded to 16-byte vectors
+template <int TW> struct RtMapC { unsigned short e[RtGeo<TW>::MAP_TILES][32]; };
+template <int TW> constexpr RtMapC<TW> rt_make_mapc() {
+    constexpr RtMap<TW> m = rt_make_map<TW>();
+    RtMapC<TW> c{};
+    for (int K = 1; K <= 5; ++K)
+        for (int t = 0; t < RtGeo<TW>::ntiles(K); ++t)
+            for (int i = 0; i < 32; ++i) c.e[RtGeo<TW>::map_tile0(K) + t][i] = m.e[K - 1][t][i];
+    return c;
+}
+__device__ const RtMapC<16> rt_mapc16 = rt_make_mapc<16>();
+__device__ const RtMapC<8> rt_mapc8 = rt_make_mapc<8>();
+template <int TW> __device__ __forceinline__ const u32x4* rt_mapc_vec() {
+    if constexpr (TW == 16) return reinterpret_cast<const u32x4*>(&rt_mapc16);
+    else return reinterpret_cast<const u32x4*>(&rt_mapc8);
+}
+// this lane's entry of M-tile t of stage K, from the LDS copy (valid after the prologue's barrier)
+template <int TW, int K> __device__ __forceinline__ int rt_map_entry(unsigned lds0, int t, int i) {
+    constexpr int T0 = RtGeo<TW>::map_tile0(K);
+    return rt_lds_read<unsigned short>(lds0 + RtGeo<TW>::MAP + 2 * ((T0 + t) * 32 + i));
 }
 
 // swizzle of a frame pixel: XOR applied to the 16-B part index of its 64-B row
@@ -294,6 +319,8 @@ __device__ __forceinline__ unsigned long long rt_slab_src(const ssr_rdb_desc& d,
     return (base + (unsigned long long)(tapblk * 2048)) | (k == 4 ? 1ull : 0ull);   // tap block: 32 co x 32 ci (conv5: 64 co x 16 ci) bf16 = 2048 B
 }
 typedef const __attribute__((address_space(1))) char* rt_gptr;   // global memory, explicitly (never a flat access)
+__device__ const float rt_zero_f32 = 0.f;                         // what a missing bias array reads (every prologue load is unconditional)
+__device__ const u32x4 rt_zero16 = {0u, 0u, 0u, 0u};              // what the X0 slots of pixels outside the image read
 
 #ifndef RT_POLL_SLEEP
 #define RT_POLL_SLEEP 3
@@ -685,47 +712,70 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
     TPROBE(0);
     const bool producer = wave >= RT_NCONS;
     const int pw = wave - RT_NCONS;
-    {
-        const int k = tid < 128 ? tid >> 5 : 4, cc = tid < 128 ? tid & 31 : tid - 128;   // 4 x 32 + 64 entries
-        const float* bp = k == 0 ? d.bias[0] : k == 1 ? d.bias[1] : k == 2 ? d.bias[2] : k == 3 ? d.bias[3] : d.bias[4];   // no indexed access: the
-        if (tid < 192) bias_lds[tid] = bp ? bp[cc] : 0.f;                                                                 // descriptor stays in SGPRs
+    // ---- prologue, part 1: every global load the block needs before its first MFMA is ISSUED here, unconditionally, before any of
+    //      them is waited for: the x halo first (below), then the bias entry, the slab-source entry and the lane -> pixel map vector
+    //      of this thread.  (Round 4: the bias load used to be waited for in front of everything else, the map entries were eleven
+    //      separate loads spilled one by one behind s_waitcnt vmcnt(0): six memory latencies in a row, 4.9 k of the block's 58 k
+    //      ticks; tools/rdbt_check probe.)
+    float pro_bias[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned long long pro_src;
+    u32x4 pro_map;
+    auto prologue_loads = [&]() {
+        // bias table [4 x 32 + 64]: thread t reads entry t & 31 of conv1..4 and t & 63 of conv5 through the five SCALAR pointers of the
+        // descriptor (a per-thread pick of one of them becomes an indexed load of the pointer + a dependent flat load: two latencies)
+        if (!BWD) {
+            typedef const __attribute__((address_space(1))) float* gfp;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float* bp = d.bias[k] ? d.bias[k] + (k < 4 ? (tid & 31) : (tid & 63)) : &rt_zero_f32;
+                pro_bias[k] = *(gfp)bp;
+            }
+        }
+        pro_src = rt_slab_src<BWD>(d, min(tid, RT_NSLAB - 1));
+        pro_map = rt_mapc_vec<TW>()[min(tid, G::MAP_TILES * 4 - 1)];
+    };
+    auto prologue_stores = [&]() {
+        if (tid < 64) {
+            if (tid < 32) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bias_lds[k * 32 + tid] = pro_bias[k];
+            }
+            bias_lds[128 + tid] = pro_bias[4];
+        }
         if (tid >= 192 && tid < 224) ctl[tid - 192] = 0;
-        if (tid < 80) rt_lds_write<unsigned long long>(lds0 + G::SRC + 8 * tid, rt_slab_src<BWD>(d, min(tid, RT_NSLAB - 1)));
-    }
+        if (tid < 80) rt_lds_write<unsigned long long>(lds0 + G::SRC + 8 * tid, pro_src);
+        if (tid < G::MAP_TILES * 4) rt_lds_write<u32x4>(lds0 + G::MAP + 16 * tid, pro_map);
+    };
     // ---- the 64-channel input halo region (x / d_out): 18 x (TW+10) pixels -> X0 (2 planes of 32 channels, swizzled rows),
     //      staged through registers by ALL waves (the MFMA waves have nothing else to do before the barrier).  It is what the
     //      first MFMA needs, so the producers issue its loads BEFORE their first weight slabs (a wave's loads return in order).
-    constexpr int NPX0 = 18 * G::RW0, NV0 = 2 * NPX0 * 4, NQ = (NV0 + RT_NTHREADS - 1) / RT_NTHREADS;
-    auto x0_load = [&](u32x4 (&rx)[NQ]) {
+    // Round 4: by LDS-DMA (global_load_lds_dwordx4) instead of through registers.  Staged through registers the five vectors per
+    // thread were spilled by hipcc one by one in the prologue (load, s_waitcnt vmcnt(0), scratch store, next load: a memory latency
+    // each); a DMA needs no data register.  A wave-instruction fills 1 KiB of LDS, lane l the 16-byte slot l of it, from ANY global
+    // address: the lane picks the (pixel, part) whose swizzled place that slot is; pixels outside the image read a zero block.
+    constexpr int X0_SLOTS = 2 * G::PLANE / 16, X0_INST = (X0_SLOTS + 63) / 64, PL_SLOTS = G::PLANE / 16;
+    auto x0_dma = [&]() {
         const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.in.p);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int v = tid + q * RT_NTHREADS;                 // (plane, pixel, part)
-            const int plane = v / (NPX0 * 4), r2 = v - plane * (NPX0 * 4);
-            const int pix = r2 >> 2, part = r2 & 3;
+        typedef const __attribute__((address_space(1))) void* gvp;
+        typedef __attribute__((address_space(3))) void* lvp;
+        for (int u = wave; u < X0_INST; u += RT_NCONS + RT_NPROD) {      // wave-uniform
+            const int sl = u * 64 + lane;                                // 16-byte slot of X0 this lane fills
+            const int plane = sl >= PL_SLOTS ? 1 : 0, r2 = sl - plane * PL_SLOTS;
+            const int pix = r2 >> 2;
             const int py = pix / G::RW0, pxx = pix - py * G::RW0;
+            const int part = (r2 & 3) ^ rt_f(py, pxx);                   // the logical part whose swizzled place is this slot
             const int iy = ty0 - 5 + py, ix = tx0 - 5 + pxx;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (v < NV0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * H + iy) * W + ix) * d.in.cs + d.in.coff +
-                                                      plane * 32 + part * 8);
-            rx[q] = val;
-        }
-    };
-    auto x0_store = [&](const u32x4 (&rx)[NQ]) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int v = tid + q * RT_NTHREADS;
-            const int plane = v / (NPX0 * 4), r2 = v - plane * (NPX0 * 4);
-            const int pix = r2 >> 2, part = r2 & 3;
-            const int py = pix / G::RW0, pxx = pix - py * G::RW0;
-            if (v < NV0) rt_lds_write<u32x4>(lds0 + G::base(0) + plane * G::PLANE + 64 * pix + ((part ^ rt_f(py, pxx)) << 4), rx[q]);
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const __bf16* src = xg + ((size_t)(n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * d.in.cs + d.in.coff + plane * 32 + part * 8;
+            const void* sp = in ? (const void*)src : (const void*)&rt_zero16;
+            if (sl < X0_SLOTS)
+                __builtin_amdgcn_global_load_lds((gvp)sp, (lvp)(smem + G::base(0) + u * 1024), 16, 0, 0);
         }
     };
     // ---- producer waves: the block's data movers ----
     if (producer) {
-        u32x4 rx[NQ];
-        x0_load(rx);
+        // (the first RT_RQ weight slabs of this wave are requested FIRST, below; then its share of the x halo and the small tables:
+        //  everything the block needs before its first MFMA is in flight within one memory latency)
         // wave pw owns the slabs q = pw (mod 4) and with them the ring stages q % NST (NST = 4: exactly one), so a stage's
         // ready word has ONE writer and a slab costs one decode, six loads, six stores and one flag; a queue of RT_RQ whole
         // slabs (6 KiB: six 16-byte vectors per lane) lives in registers.  (r03: dealing 1-KiB pieces round-robin made the
@@ -793,14 +843,29 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         // opaque copy of q, so that the pointer pick stays a v_cndmask chain
         static_for<0, RT_RQ>([&](auto uc) {
             const int q = pw + RT_NPROD * decltype(uc)::value;
-            int qv = q;
-            rt_pin(qv);
-            const unsigned long long a = rt_slab_src<BWD>(d, qv);
-            const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-            load_from(((unsigned long long)ahi << 32) | alo, wq[decltype(uc)::value]);
+            static_assert(RT_NPROD * (RT_RQ - 1) + RT_NPROD - 1 < 15 || RT_INTERLEAVE5, "the first slabs of a producer belong to conv1 / conv2");
+            unsigned long long a;
+            if constexpr (!RT_INTERLEAVE5 && RT_NPROD * (RT_RQ - 1) + RT_NPROD - 1 < 15) {
+                // slabs 0..14 = conv1 (0..5) and conv2 (6..14): a scalar pick between two kernel-argument pointers (s_cselect), no
+                // indexed load of the pointer in front of the six loads (which cost the producers a memory latency per slab here)
+                const bool c2 = q >= 6;
+                const int r = c2 ? q - 6 : q, j = r / 3, ky = r - 3 * j, k = c2 ? 1 : 0;
+                const int c = BWD ? (j < 2 ? k + j : k + 1 - j) : j;
+                const unsigned long long base = c2 ? (unsigned long long)(uintptr_t)d.w[1] : (unsigned long long)(uintptr_t)d.w[0];
+                a = base + (unsigned long long)((c * 9 + 3 * ky) * 2048);
+            } else {
+                int qv = q;
+                rt_pin(qv);
+                const unsigned long long av = rt_slab_src<BWD>(d, qv);
+                a = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(av >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)av);
+            }
+            load_from(a, wq[decltype(uc)::value]);
         });
-        x0_store(rx);
-        __syncthreads();   // the only barrier: X0, bias table, source table, zeroed control words
+        prologue_loads();
+        x0_dma();            // last: hipcc waits for every outstanding load (s_waitcnt vmcnt(0)) behind the DMA loop
+        prologue_stores();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of X0 has landed (DMA writes are not covered by the barrier)
+        __syncthreads();   // the only barrier: X0, bias table, source table, lane -> pixel map, zeroed control words
 #ifndef RT_PRIO_PROD
 #define RT_PRIO_PROD 0
 #endif
@@ -885,35 +950,32 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         return;
     }
     // ---------------- MFMA waves ----------------
-    u32x4 rx0[NQ];
-    x0_load(rx0);
-    // this lane's pixels (rt_map) for every stage, requested now; tile_of is constexpr in (K, w, m), the wave index is a
-    // run-time (scalar) value: select over the eight waves
+    prologue_loads();
+    x0_dma();
+    // tile_of is constexpr in (K, w, m), the wave index is a run-time (scalar) value: select over the eight waves.  This lane's
+    // pixels come out of the LDS copy of the map when a stage begins (rt_map_entry).
     auto pick8 = [&](auto f) {
         const int v0 = f(0), v1 = f(1), v2 = f(2), v3 = f(3), v4 = f(4), v5 = f(5), v6 = f(6), v7 = f(7);
         return wave == 0 ? v0 : wave == 1 ? v1 : wave == 2 ? v2 : wave == 3 ? v3 : wave == 4 ? v4 : wave == 5 ? v5 : wave == 6 ? v6 : v7;
     };
-    int ent[4][2], ntl[4], prk[5];
+    int tl[4][2], ntl[4], prk[5];                   // scalar (wave-uniform) values
 #pragma unroll
     for (int K = 1; K <= 4; ++K) {
         ntl[K - 1] = pick8([&](int w) { return G::ntl(K, w); });
 #pragma unroll
         for (int m = 0; m < G::nmt(K); ++m) {
             const int t = pick8([&](int w) { return G::tile_of(K, w, m); });
-            ent[K - 1][m] = rt_map_entry<TW>(K, t >= 0 ? t : 0, i);
+            tl[K - 1][m] = t >= 0 ? t : 0;
         }
     }
 #pragma unroll
     for (int K = 1; K <= 5; ++K) prk[K - 1] = pick8([&](int w) { return G::prank(K, w); });
     const int mt5 = pick8([&](int w) { return G::m5(w); }), nt5 = pick8([&](int w) { return G::n5(w); });
-    const int e5 = rt_map_entry<TW>(5, mt5, i);
-    // rows of the output transpose slab this lane sends to memory: v = h*64 + lane -> row v >> 2 (32 co = 4 parts)
-    int e5s[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) e5s[hh] = rt_map_entry<TW>(5, mt5, (hh * 64 + lane) >> 2);
-    x0_store(rx0);
+    prologue_stores();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TPROBE(1);
     __syncthreads();   // the only barrier (see the producer branch)
+    const int e5 = rt_map_entry<TW, 5>(lds0, mt5, i);
     TRACE(9, 0);
 #ifndef RT_PRIO_MFMA
 #define RT_PRIO_MFMA 1
@@ -950,9 +1012,10 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
         const int nt = ntl[K - 1];
         RtGrow<G::nmt(K)> sa;       // this wave owns nmt(K) tiles ...
         RtGrow<1> sb;               // ... or one (only one of the two states is ever live)
-        int ea[G::nmt(K)], eb[1] = {ent[K - 1][0]};
+        int ea[G::nmt(K)], eb[1];
 #pragma unroll
-        for (int m = 0; m < G::nmt(K); ++m) ea[m] = ent[K - 1][m];
+        for (int m = 0; m < G::nmt(K); ++m) ea[m] = rt_map_entry<TW, K>(lds0, tl[K - 1][m], i);
+        eb[0] = ea[0];
         constexpr bool TWO = G::nmt(K) == 2;
         constexpr int JA = K == 1 ? 2 : K;      // growth chunks in front of the stage's conv5 chunk (conv1: both, then its epilogue)
 #if !RT_INTERLEAVE5
@@ -1016,7 +1079,7 @@ __global__ __launch_bounds__(RT_NTHREADS) void rdbt_kernel(const ssr_rdb_desc d)
             for (int hh = 0; hh < 2; ++hh) {
                 const int v = hh * 64 + lane;
                 const int row = v >> 2, part = v & 3;
-                const int es = e5s[hh];
+                const int es = rt_map_entry<TW, 5>(lds0, mt5, (hh * 64 + lane) >> 2);   // the pixel whose row of the slab this lane sends
                 const int oy = ty0 - 5 + (es & 31), ox = tx0 - 5 + ((es >> 5) & 31);
                 const u32x4 val = rt_lds_read<u32x4>(slabw + row * G::TROW + part * 16);
                 if (oy < H && ox < W) {

@@ -21,6 +21,13 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
       --kernel-trace --output-format csv -d /tmp/pmc_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmc_$TAG.log 2>&1)
   python tools/pmc_sq.py /tmp/pmc_$TAG $O/${TAG}_pmc_sq.json || tail -20 /tmp/pmc_$TAG.log
 fi
+if [ "${LEG_TRAFFIC:-0}" = "1" ]; then      # HBM traffic of the parity legs' dominant kernels -> profiles/traffic_<dtype>.json (bench.py legs.*.roofline.traffic)
+  for DT in fp32x3 fp32; do
+    (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_${TAG}_$DT -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcf_${TAG}_$DT.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_${TAG}_$DT -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcw_${TAG}_$DT.log 2>&1)
+    SSR_PMC_DTYPE=$DT python tools/pmc_traffic.py /tmp/pmc_fetch_${TAG}_$DT /tmp/pmc_write_${TAG}_$DT $O/${TAG}_traffic_$DT.json > /dev/null && cp $O/${TAG}_traffic_$DT.json profiles/traffic_$DT.json && echo "traffic $DT ok"
+  done
+fi
 if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcf_$TAG.log 2>&1)
   (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/pmcw_$TAG.log 2>&1)

@@ -20,6 +20,11 @@ def symbol(name: str):
     if "rdb_kernel<false>" in name or "rdb_kernelILb0" in name: return "rdb_kernel<false>"
     if "wgrad_bf16_k3_kernel" in name: return "wgrad_kernel<bf16,K3>"
     if "wgrad_bf16_kernel" in name: return "wgrad_kernel<bf16,K4>"
+    import re
+    m = re.search(r"conv_x3_kernel<(\d), \d, (\d), (\d), \d>", name)        # <KH, KW, NT, MW, KS>: bench.py's conv_kernel<fp32x3,K..,S1,NT..,W..>
+    if m: return f"conv_kernel<fp32x3,K{m.group(1)},S1,NT{m.group(2)},W{m.group(3)}>"
+    m = re.search(r"wgrad_kernel<float, (\d),", name)
+    if m: return f"wgrad_kernel<fp32,K{m.group(1)}>"
     if "conv_big_kernel" in name: return "conv_big_kernel"
     if "conv_ws_kernel" in name: return "conv_ws_kernel"
     return None

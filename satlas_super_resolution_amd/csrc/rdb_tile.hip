@@ -16,14 +16,19 @@
 //     The lane -> pixel table (rt_map) deals the pixels of a stage's region to lanes by that residue;
 //     (80-B padded rows of the first kernel: 160 KB for this tile; swizzled: 131 KB)
 //   * weight ring of 6-KB slabs (3 taps = one kernel row of one 32-channel chunk), 4 stages at TW = 16: the hand-over
-//     latency of the old two-stage 18-KB ring (830 cycles per slab, exposed in conv4/conv5) is covered by depth;
-//   * 4 MFMA waves + 4 producer waves = two waves per SIMD and 256 registers each (the old 4 + 6 left 168);
+//     latency of the old two-stage 18-KB ring (830 cycles per slab, exposed in conv4/conv5) is covered by depth; round 4: conv5's
+//     slabs alternate between the ring and four extra stages in rows of x that are dead by then (RtGeo::C5X: eight slabs deep);
+//   * 8 MFMA waves (two per SIMD) + 4 producer waves that each OWN a ring stage = 12 waves, three per SIMD, 168 registers each
+//     (the old 4 + 6 had one MFMA wave per SIMD: 35 cycles per MFMA instead of 25.6);
 //   * block -> tile map keeps the tiles of an image on ONE XCD (block b runs on XCD b % 8): halo re-reads hit that
-//     XCD's L2 instead of fetching every image into all eight.
+//     XCD's L2 instead of fetching every image into all eight;
+//   * round 4: the prologue costs ONE memory latency - the x halo comes in by LDS-DMA (no staging registers), the lane -> pixel map
+//     is an LDS table filled with one load per thread, the bias / slab-source loads are unconditional and issued before any wait.
 //
 // LDS map (TW = 16): ring 4 x 6144 B | bias table | control words | X0 2 planes x 468 rows | X1 414 | X2 308 | X3 262 |
-// X4 180 rows | dummy row = 159.9 KB.  After the prologue there is NO s_barrier: LDS flags as in rdb_fwd.hip
-//   ready[NST]  (producer -> consumers)    per ring stage: slabs its producer has published there
+// X4 180 rows | dummy row | flag scratch | slab-source table | lane -> pixel map = 159.6 KB.  After the prologue there is NO s_barrier:
+// LDS flags as in rdb_fwd.hip
+//   ready[8]    (producer -> consumers)    per slab place (4 ring stages + 4 conv5 extras): 1 + the newest slab published there
 //   done[8]     (consumer w -> producers)  number of slabs wave w is finished with
 //   slice[1..5] (consumers <-> consumers)  waves that have stored their part of slice K / arrived at the final sync
 #include "common.h"

@@ -559,7 +559,10 @@ __device__ __forceinline__ void rt_grow_run(RtCtx& c, RtGrow<NMT>& st) {
 #endif
                 rt_flush_core<TW, K - 1, BWD>(c.d, c.lds0, c.n, c.ty0, c.tx0, c.prank * 64 + c.lane, G::npart(K) * 64);
             }
-            if constexpr (j == K && BWD) {   // the epilogue's masks: requested one chunk ahead
+#ifndef RT_MASK_AHEAD
+#define RT_MASK_AHEAD 1      // chunks between the request of the epilogue's masks and the epilogue (1: at the start of the stage's last chunk)
+#endif
+            if constexpr (j == (K + 1 - RT_MASK_AHEAD > 0 ? K + 1 - RT_MASK_AHEAD : 1) && BWD) {   // the epilogue's masks: requested RT_MASK_AHEAD chunks ahead
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) rt_load_mask<K>(c.d, rt_pix(st.ent[m], true, c.n, c.ty0, c.tx0, c.d.H, c.d.W), c.g, st.mk[m]);
             }

@@ -30,6 +30,7 @@ if [ "${SKIP_LEG_TRAFFIC:-0}" != "1" ]; then  # the parity legs' dominant kernel
     SSR_PMC_DTYPE=$DT python tools/pmc_traffic.py /tmp/pmc_fetch_${TAG}_$DT /tmp/pmc_write_${TAG}_$DT $O/${TAG}_traffic_$DT.json > /dev/null && cp $O/${TAG}_traffic_$DT.json profiles/traffic_$DT.json && echo "traffic $DT collected"
   done
 fi
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py ${BENCH_ARGS:-} > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; tail -1 $O/${TAG}_bench.json | cut -c1-1200
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/prof_$TAG.log 2>&1)

@@ -29,7 +29,11 @@
 #ifdef SSR_PROBE   // tools/wgrad_probe.hip
 #define GPROBE(k) do { if (threadIdx.x == 0) g_probe[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define GPROBE_K(kk) do { if (threadIdx.x == 0 && k == 20) g_probe[blockIdx.x * 16 + (kk)] = __builtin_amdgcn_s_memtime(); } while (0)
+// device-wide 100-MHz clock + where the workgroup ran (s_memtime is per XCD): the launch's timeline across CUs
+#define GPROBE_RT(kk) do { if (threadIdx.x == 0) { g_probe[blockIdx.x * 16 + (kk)] = __builtin_amdgcn_s_memrealtime(); \
+    g_probe[blockIdx.x * 16 + 11] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #else
+#define GPROBE_RT(kk)
 #define GPROBE(k)
 #define GPROBE_K(kk)
 #endif
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
     const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
     const int ntile = it.tile_end - it.tile_begin;
     if (tid < 128) ctl[tid] = 0;
-    GPROBE(0);
+    GPROBE(0); GPROBE_RT(9);
     __syncthreads();   // the only barrier
 
     if (wave >= 4) {
@@ -710,13 +714,19 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
             for (int q = 0; q < NOUT / 256; ++q) {
                 const int e = tid + q * 256;
                 const int co = e / 576, rem = e - co * 576;
-                if (co0 + co < LC.Cout && rem < nci * 9)
-                    atomicAdd(dw + ((size_t)(co0 + co) * LC.Cin_w + it.ci0) * 9 + rem, red[e]);
+                if (co0 + co < LC.Cout && rem < nci * 9) {
+                    float* dst = dw + ((size_t)(co0 + co) * LC.Cin_w + it.ci0) * 9 + rem;
+#ifdef WG_X_PLAINOUT
+                    *dst += red[e];
+#else
+                    atomicAdd(dst, red[e]);
+#endif
+                }
             }
             if (c == 0 && pair) wg_sync4(ctl + WGC_SYNC, phase, lane);   // the tile is read before the second plane overwrites it
         }
     });
-    GPROBE(8);
+    GPROBE(8); GPROBE_RT(10);
 }
 
 int launch_k3(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {

@@ -1,7 +1,8 @@
 // The generator-body weight-gradient launch as the step issues it: NRDB dense blocks x 14 (conv, co, ci) items over DISTINCT
 // 192-channel buffers (N = 32, 32 x 32), item order 0 = layer-major (rounds 1-2), 1 = one dense block per XCD queue.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DSSR_PROBE -Iinclude -Isatlas_super_resolution_amd/csrc tools/wgrad_body_probe.hip -o tools/wgrad_body_probe
-//   tools/wgrad_body_probe [nrdb=69] [order=0|1|2 (2 = heavy first)] [shared=0|1] [pair=0|1]
+//   tools/wgrad_body_probe [nrdb=69] [order=0|1|2 (2 = heavy first)] [shared=0|1] [pair=0|1] [cut: 0 none, N > 0 at most N tiles per item,
+//                          -1 = equal shares: the cost-ordered item sequence cut at multiples of total / 256, longest piece first]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -11,7 +12,7 @@ __device__ unsigned long long* g_probe;
 #include "../satlas_super_resolution_amd/csrc/wgrad_bf16.hip"
 int main(int argc, char** argv) {
     const int N = 32, H = 32, W = 32, CS = 192;
-    const int nrdb = argc > 1 ? atoi(argv[1]) : 69, order = argc > 2 ? atoi(argv[2]) : 0, shared = argc > 3 ? atoi(argv[3]) : 0, pairing = argc > 4 ? atoi(argv[4]) : 0;
+    const int nrdb = argc > 1 ? atoi(argv[1]) : 69, order = argc > 2 ? atoi(argv[2]) : 0, shared = argc > 3 ? atoi(argv[3]) : 0, pairing = argc > 4 ? atoi(argv[4]) : 0, cut = argc > 5 ? atoi(argv[5]) : 0;
     const size_t bufb = (size_t)N * H * W * CS * 2;
     const int nbuf = shared ? 1 : nrdb + 1;
     char *x, *dy; float* dw;
@@ -63,6 +64,40 @@ int main(int argc, char** argv) {
         std::stable_sort(q.begin(), q.end(), [](auto& a, auto& b) { return a.size() > b.size(); });
         for (size_t j = 0; j < q[0].size(); ++j) for (auto& qq : q) if (j < qq.size()) I.push_back(qq[j]);
     }
+    if (cut != 0) {
+        auto cost = [&](const ssr_wgrad_item& it) { return (double)(it.tile_end - it.tile_begin) * (weight(it) == 4 ? 5900.0 : weight(it) == 2 ? 4300.0 : 3000.0); };
+        std::vector<ssr_wgrad_item> out;
+        if (cut <= -2) {   // whole rounds stay whole; the items of the last, partial round are cut into (-cut - 1) * 256 pieces
+            const size_t whole = I.size() / 256 * 256, rest = I.size() - whole;
+            for (size_t i = 0; i < whole; ++i) out.push_back(I[i]);
+            if (rest) {
+                const int per_item = std::max(1, (int)(((-cut - 1) * 256 + rest - 1) / rest));
+                for (size_t i = whole; i < I.size(); ++i) {
+                    const auto it = I[i]; const int n = it.tile_end - it.tile_begin, step = (n + per_item - 1) / per_item;
+                    for (int b = it.tile_begin; b < it.tile_end; b += step) { auto p = it; p.tile_begin = b; p.tile_end = std::min(it.tile_end, b + step); p.atomic = 1; out.push_back(p); }
+                }
+            }
+        } else if (cut > 0) {
+            for (auto it : I) for (int b = it.tile_begin; b < it.tile_end; b += cut) { auto p = it; p.tile_begin = b; p.tile_end = std::min(it.tile_end, b + cut); p.atomic = 1; out.push_back(p); }
+        } else {
+            double total = 0; for (auto& it : I) total += cost(it);
+            const double T = total / 256; double acc = 0; int k = 1;
+            for (auto it : I) {
+                const double per = cost(it) / (it.tile_end - it.tile_begin);
+                int b = it.tile_begin;
+                while (b < it.tile_end) {
+                    const double room = k * T - acc;                       // work left in the current share
+                    int n = std::min(it.tile_end - b, std::max(1, (int)(room / per + 0.5)));
+                    if (it.tile_end - b - n < 4) n = it.tile_end - b;       // no crumbs
+                    auto p = it; p.tile_begin = b; p.tile_end = b + n; p.atomic = 1; out.push_back(p);
+                    acc += n * per; b += n;
+                    if (acc >= k * T - 0.5 * per) ++k;
+                }
+            }
+            std::stable_sort(out.begin(), out.end(), [&](auto& a, auto& b) { return cost(a) > cost(b); });
+        }
+        I = out;
+    }
     ssr_wgrad_layer* Ld; ssr_wgrad_item* Id;
     hipMalloc(&Ld, L.size() * sizeof(L[0])); hipMalloc(&Id, I.size() * sizeof(I[0]));
     hipMemcpy(Ld, L.data(), L.size() * sizeof(L[0]), hipMemcpyHostToDevice);
@@ -90,6 +125,21 @@ int main(int argc, char** argv) {
     }
     printf("  loop %.0f cycles per item (%.0f per tile; heaviest items %.0f, others %.0f per tile), write-out %.0f; launch span %.0f cycles\n",
            loop / nb, loop / nb / tiles, n18 ? loop18 / n18 / tiles : 0., n9 ? loop9 / n9 / tiles : 0., wo / nb, double(t1 - t0));
+    {   // timeline on the device-wide 100-MHz clock: span of the launch, CU time in use, workgroups per CU
+        unsigned long long r0 = ~0ull, r1 = 0; double busy = 0; std::vector<unsigned long long> ids;
+        for (int b = 0; b < nb; ++b) { r0 = std::min(r0, h[b * 16 + 9]); r1 = std::max(r1, h[b * 16 + 10]); busy += double(h[b * 16 + 10] - h[b * 16 + 9]);
+                                       ids.push_back(h[b * 16 + 11] & 0xf0000ff00ull | (h[b * 16 + 11] & 0xe000ull)); }
+        std::sort(ids.begin(), ids.end()); const size_t ncu = std::unique(ids.begin(), ids.end()) - ids.begin();
+        printf("  timeline: span %.1f us, sum of workgroup times %.1f us = %.2f of %zu CUs x span; mean workgroup %.1f us\n", (r1 - r0) / 100.0, busy / 100.0,
+               busy / (double(r1 - r0) * ncu), ncu, busy / 100.0 / nb);
+        // CU time in use per tenth of the span
+        double use[10] = {0};
+        for (int b = 0; b < nb; ++b) for (int i = 0; i < 10; ++i) {
+            const double a = r0 + (r1 - r0) * i / 10.0, e = r0 + (r1 - r0) * (i + 1) / 10.0;
+            use[i] += std::max(0.0, std::min(e, (double)h[b * 16 + 10]) - std::max(a, (double)h[b * 16 + 9]));
+        }
+        printf("  CUs in use per tenth of the span:"); for (int i = 0; i < 10; ++i) printf(" %.0f", use[i] / ((r1 - r0) / 10.0)); printf("\n");
+    }
     // start-time histogram of the blocks (in 10ths of the span): how the rounds fall
     int hist[10] = {0}; for (int b = 0; b < nb; ++b) hist[std::min(9, int(10.0 * double(h[b * 16] - t0) / double(t1 - t0)))]++;
     printf("  starts per tenth of the span:"); for (int i = 0; i < 10; ++i) printf(" %d", hist[i]); printf("\n");

@@ -133,8 +133,17 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     // without s2d), soff(c) = the chunk's uniform offset.
     const bool s2d = KT == 2 && d.s2d != 0;
     const int cpc_shift = s2d ? 31 - __builtin_clz((unsigned)(d.Cin >> 7)) : 0;   // log2(source channels / 32)
+    // Round 4: every staging load is ONE unconditional buffer load.  pgo / wgo are per-lane BYTE offsets from the image / chunk
+    // base; a vector that must read zeros (outside the image, past the last channel, past the end of the table) gets CB_OOB,
+    // which is beyond num_records of every resource: the hardware returns 0.  Written with a branch around each load (and a
+    // zero-initialised destination) the 2x2 kernels issued ~30 VALU / scalar instructions per MFMA - exec-mask save / restore,
+    // four accumulator-file moves per load for the zeros, descriptor fields re-read from the kernel arguments with
+    // s_waitcnt lgkmcnt(0) in the middle of the LDS read stream - and ran at 15 % MFMA-busy with SQ_WAIT_ANY at 27 %: issue-bound.
+    constexpr int CB_OOB = 0x7ffffff0;
+    const int x_cs = d.x.cs, x_Wi = d.Wi, x_Cin = d.Cin;
     int pgo[CB_NPV], plo[CB_NPV], wgo[CB_NWV], wlo[CB_NWV];
     unsigned pmk[KT == 2 ? CB_NPV : 1];
+    const int climit = s2d ? 0x7fffffff : x_Cin - (tid % VPP) * 8;   // chunk start c0 is inside this lane's channels iff c0 < climit (s2d: whole chunks)
 #pragma unroll
     for (int q = 0; q < CB_NPV; ++q) {
         const int v = tid + q * 256;
@@ -147,15 +156,17 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                 const bool y0 = sy >= 0 && sy < d.Hi, y1 = sy + 1 >= 0 && sy + 1 < d.Hi;
                 const bool x0 = sx >= 0 && sx < d.Wi, x1 = sx + 1 >= 0 && sx + 1 < d.Wi;
                 pmk[q] = v < CB_NPIX * VPP ? (unsigned)(y0 && x0) | (unsigned)(y0 && x1) << 1 | (unsigned)(y1 && x0) << 2 | (unsigned)(y1 && x1) << 3 : 0u;
-                pgo[q] = (sy * d.Wi + sx) * d.x.cs + d.x.coff + part * 8;
+                // the q = 0 source pixel may lie one row / column outside the image: the resource's base address is one row and
+                // one pixel BELOW the tensor (xbias), so that this lane offset is never negative (valid classes land inside)
+                pgo[q] = ((sy * d.Wi + sx) * d.x.cs + d.x.coff + part * 8) * 2 + (d.Wi + 1) * d.x.cs * 2;
             } else {
                 const bool ok = v < CB_NPIX * VPP && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-                pmk[q] = ok ? 1u : 0u;
-                pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : 0;
+                pmk[q] = ok ? 1u : 0u;                          // (q = 0 without s2d)
+                pgo[q] = ok ? (int)((((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) * 2) : CB_OOB;
             }
         } else {
             const bool ok = v < CB_NPIX * VPP && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
-            pgo[q] = ok ? (int)(((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) : -1;
+            pgo[q] = ok ? (int)((((size_t)(ly >> upshift) * d.Wi + (lx >> upshift)) * d.x.cs + d.x.coff + part * 8) * 2) : CB_OOB;
         }
         plo[q] = v < CB_NPIX * VPP ? pix * CB_AROW + part * 16 : -1;
     }
@@ -163,49 +174,62 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
     for (int q = 0; q < CB_NWV; ++q) {
         const int v = tid + q * 256;
         const int row = v / VPP, part = v % VPP;               // row = tap*64 + co
-        wgo[q] = ((row >> 6) * d.CoutPad + co0 + (row & 63)) * 32 + part * 8;
         wlo[q] = v < T::WROWS * VPP ? CB_PATCH + row * CB_AROW + part * 16 : -1;
+        wgo[q] = wlo[q] >= 0 ? (((row >> 6) * d.CoutPad + co0 + (row & 63)) * 32 + part * 8) * 2 : CB_OOB;
     }
-    const __amdgpu_buffer_rsrc_t rsx = cb_rsrc(d.x.p, (long)d.N * ximg * 2), rsw = cb_rsrc(d.w, (long)((nchunks + WSUB - 1) / WSUB) * wchunk * 2);
+    auto cap = [](long b) { return b > 0x7fffff00L ? 0x7fffff00L : b; };
+    const long xbias = s2d ? (long)(d.Wi + 1) * d.x.cs * 2 : 0;
+    const __amdgpu_buffer_rsrc_t rsx = cb_rsrc(reinterpret_cast<const char*>(d.x.p) - xbias, cap((long)d.N * ximg * 2 + xbias)), rsw = cb_rsrc(d.w, cap((long)((nchunks + WSUB - 1) / WSUB) * wchunk * 2));
     u32x4 rp[CB_NPV], rw[CB_NWV];
     // one staging load (vector j of the 19 per thread).  A wave that issues its loads back to back sits in the issue
     // of each one until the previous has drained (~170 cycles per 1-KiB instruction: the ~6.4 B/clk per-wave limit of
     // tools/l2_probe.hip) and cannot issue MFMAs meanwhile, so the loads of chunk c+1 are sprinkled over the k-steps
     // of chunk c.
-    auto load_one = [&](int nn, int c, auto jc) {          // vector j of chunk c of image nn
+    // the wave-uniform part of a chunk's loads, computed ONCE per chunk (inside load_one the compiler recomputed these scalar
+    // products for each of the 13 - 19 loads): class bit to test, byte offsets of the chunk in x and in the packed weights
+    struct LoadPos { int q, c0, xs, ws; };
+    auto load_pos = [&](int nn, int c) {
+        LoadPos p;
+        p.c0 = c * CK;
+        if constexpr (KT == 2) {
+            p.q = s2d ? c >> cpc_shift : 0;
+            // s2d: class q reads source pixel (2Y - 1 + (q >> 1), 2X - 1 + (q & 1)); pgo is relative to (2Y - 1, 2X - 1)
+            p.xs = (int)(nn * ximg * 2) + (s2d ? (((p.q >> 1) * x_Wi + (p.q & 1)) * x_cs + ((c - (p.q << cpc_shift)) << 5)) * 2 : p.c0 * 2);
+            p.ws = (int)(c * wchunk * 2);
+        } else {
+            p.q = 0;
+            p.xs = (int)((nn * ximg + p.c0) * 2);
+            p.ws = (int)((c / WSUB) * wchunk * 2) + (c % WSUB) * CK * 2;
+        }
+        return p;
+    };
+    auto load_one = [&](const LoadPos& lp, auto jc) {       // vector j of the chunk at lp
         constexpr int j = decltype(jc)::value;
-        const int c0 = c * CK;
 #ifdef CB_X_NOLOAD
-        if (c > 1 || nn != n0) return;                         // probe: chunks after the first two reuse stale registers
+        if (lp.ws != 0 || lp.xs != (int)(n0 * ximg * 2)) return;   // probe: only the stream's first chunk is loaded
 #endif
         if constexpr (j < CB_NPV) {
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if constexpr (KT == 2) {
-                const int q = s2d ? c >> cpc_shift : 0;        // wave-uniform
-                const int soff = s2d ? ((q >> 1) * d.Wi + (q & 1)) * d.x.cs + ((c - (q << cpc_shift)) << 5) : c0;
-                if (((pmk[j] >> q) & 1u) && (s2d || c0 + (int)(tid % VPP) * 8 < d.Cin))
-                    val = *reinterpret_cast<const u32x4*>(xg + nn * ximg + (ptrdiff_t)pgo[j] + soff);
-            } else {
-                if (pgo[j] >= 0 && c0 + (int)(tid % VPP) * 8 < d.Cin)
-                    val = __builtin_amdgcn_raw_buffer_load_b128(rsx, pgo[j] * 2, (int)((nn * ximg + c0) * 2), 0);
-            }
-            rp[j] = val;
+            bool ok = lp.c0 < climit;                          // (s2d: climit covers every chunk)
+            if constexpr (KT == 2) ok = ok && ((pmk[j] >> lp.q) & 1u);
+            rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? pgo[j] : CB_OOB, lp.xs, 0);
         } else {
-            if (wlo[j - CB_NPV] >= 0) {
-                if constexpr (KT == 3) rw[j - CB_NPV] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (wgo[j - CB_NPV] + (c % WSUB) * CK) * 2, (int)((c / WSUB) * wchunk * 2), 0);
-                else rw[j - CB_NPV] = *reinterpret_cast<const u32x4*>(wg + (size_t)c * wchunk + wgo[j - CB_NPV]);
-            }
+            rw[j - CB_NPV] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wgo[j - CB_NPV], lp.ws, 0);
         }
     };
-    auto load_chunk = [&](int nn, int c) { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(nn, c, jc); }); };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int q = 0; q < CB_NPV; ++q)
-            if (plo[q] >= 0) *reinterpret_cast<u32x4*>(smem + plo[q]) = rp[q];
-#pragma unroll
-        for (int q = 0; q < CB_NWV; ++q)
-            if (wlo[q] >= 0) *reinterpret_cast<u32x4*>(smem + wlo[q]) = rw[q];
+    auto load_chunk = [&](int nn, int c) { const LoadPos lp = load_pos(nn, c); static_for<0, CB_NPV + CB_NWV>([&](auto jc) { load_one(lp, jc); }); };
+    // (only the LAST vector of each table can be short of threads: the others are stored without a test)
+    auto store_vec = [&](int base, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < CB_NPV) {
+            if constexpr ((j + 1) * 256 <= CB_NPIX * VPP) *reinterpret_cast<u32x4*>(smem + base + plo[j]) = rp[j];
+            else if (plo[j] >= 0) *reinterpret_cast<u32x4*>(smem + base + plo[j]) = rp[j];
+        } else {
+            constexpr int jw = j - CB_NPV;
+            if constexpr ((jw + 1) * 256 <= T::WROWS * VPP) *reinterpret_cast<u32x4*>(smem + base + wlo[jw]) = rw[jw];
+            else if (wlo[jw] >= 0) *reinterpret_cast<u32x4*>(smem + base + wlo[jw]) = rw[jw];
+        }
     };
+    auto store_chunk = [&]() { static_for<0, CB_NPV + CB_NWV>([&](auto jc) { store_vec(0, jc); }); };
 
     // ---- this lane's pixels (one per pixel tile) ----
     int a_off[4];
@@ -449,14 +473,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
         //      The barriers are bare s_barrier + lgkmcnt(0): global loads stay in flight across them. ----
         constexpr int NSTEP = T::NSTEP, CB_PF = 2, NV = CB_NPV + CB_NWV;
         static_assert(NSTEP >= 8 && NV <= 16 && (NSTEP - 4) * 4 >= NV, "store / load slots of the step schedule");
-        auto store_one = [&](int base, auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j < CB_NPV) {
-                if (plo[j] >= 0) *reinterpret_cast<u32x4*>(smem + base + plo[j]) = rp[j];
-            } else {
-                if (wlo[j - CB_NPV] >= 0) *reinterpret_cast<u32x4*>(smem + base + wlo[j - CB_NPV]) = rw[j - CB_NPV];
-            }
-        };
+        auto store_one = [&](int base, auto jc) { store_vec(base, jc); };
         u32x4 wq[NSTEP][2], pq[NSTEP][4];
         // memory operation k (0..5) of k-step s_: the two weight fragments, then pixel fragments 0..3
         auto issue1 = [&](int base, auto sc, auto kc) {
@@ -476,6 +493,9 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             BPROBE_C(2);
             const int cur = (c & 1) * T::BUF, nxt = T::BUF - cur;
             const bool has2 = c + 2 < T_;
+            // past the end of the stream the loads are issued all the same (of the current position: valid addresses, never stored):
+            // no branch around a load
+            const LoadPos lp2 = has2 ? load_pos(nn2, c2) : load_pos(nn, c % nchunks);
             if constexpr (!has1) load_epi_ops(nn);
             static_for<0, NSTEP>([&](auto sc) {
                 constexpr int s_ = decltype(sc)::value;
@@ -497,7 +517,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                         constexpr int j = (s_ < 4 ? s_ : s_ - 4) * 4 + e;   // NV vectors, four per step
                         if constexpr (j < NV) {
                             if constexpr (s_ < 4) store_one(nxt, std::integral_constant<int, j>{});
-                            else if (has2) load_one(nn2, c2, std::integral_constant<int, j>{});
+                            else load_one(lp2, std::integral_constant<int, j>{});
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -536,6 +556,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
             CB_BAR();
             BPROBE_C(5);
             if constexpr (!has_next) load_epi_ops(nn);
+            const LoadPos lp1 = load_pos(nn1, c1);
             // k-steps: 9 taps x 2 sixteen-channel halves; per step 2 weight fragments + 4 pixel fragments -> 8 MFMAs.
             // Reads run CB_PF steps ahead, pinned by sched_barrier fences (one wave per SIMD: nothing else hides LDS latency).
             constexpr int NSTEP = T::NSTEP, CB_PF = 2;
@@ -566,7 +587,7 @@ __device__ __forceinline__ void conv_big_body(const ssr_conv_desc& d) {
                         // last one four steps before the end so that the chunk store does not wait for it
                         constexpr int NV = CB_NPV + CB_NWV, SPAN = NSTEP - CB_TAIL, CB_L2 = NV > SPAN ? NV - SPAN : 0;
                         constexpr int j = s_ < CB_L2 ? 2 * s_ + (k - 6) : (k == 6 ? CB_L2 + s_ : NV);
-                        if constexpr (j < NV) load_one(nn1, c1, std::integral_constant<int, j>{});
+                        if constexpr (j < NV) load_one(lp1, std::integral_constant<int, j>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });

@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     // ---- patch staging: everything that does not depend on the tile is computed once ----
     // vector v = tid + 256 q of the patch: consecutive lanes read consecutive 16-B parts of one pixel (all planes)
     // and then the next pixel: a 64-channel NHWC row is one 128-B line -> a wave instruction touches 8 full lines
+    // Round 4: each patch vector is ONE unconditional buffer load.  The lane part of the address (tile-invariant, bytes) is kept
+    // relative to a resource whose base lies one row and one pixel BELOW the tensor, so that the halo's (-1, -1) offsets stay
+    // non-negative; the tile is a scalar offset; a vector outside the image (or past the last channel / the table) gets an
+    // offset beyond num_records and reads zeros.  (A branch around each load, a zeroed destination and 64-bit pointer sums were
+    // ~90 of the ~520 instructions a wave issues per tile for its 36 MFMAs: the loop is issue-bound.)
+    constexpr int WS_OOB = 0x7ffffff0;
+    const long xbias = (long)(d.Wi + 1) * d.x.cs * 2;
+    const long xbytes = (long)d.N * d.Hi * d.Wi * d.x.cs * 2 + xbias;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xg)) - xbias, 0,
+                                                                         (int)(xbytes > 0x7fffff00L ? 0x7fffff00L : xbytes), 0x00020000);
     int p_rel[NPV], p_yx[NPV];
 #pragma unroll
     for (int q = 0; q < NPV; ++q) {
@@ -97,38 +107,56 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
         const int py = pix / WS_PW, px = pix - py * WS_PW;
         const int c = pl * 32 + part * 8;
         const bool ok = v < NV && c < d.Cin;
-        p_rel[q] = ((((py - 1) >> upshift) * d.Wi + ((px - 1) >> upshift)) * d.x.cs + c);
+        p_rel[q] = ((((py - 1) >> upshift) * d.Wi + ((px - 1) >> upshift)) * d.x.cs + d.x.coff + c) * 2 + (int)xbias;
         p_yx[q] = ok ? ((py - 1) & 0xffff) | ((px - 1) << 16) : 0x7fff7fff;   // never inside
     }
     u32x4 rp[NPV];
+    const int x_cs2 = d.x.cs * 2, x_Hi = d.Hi, x_Wi = d.Wi;
     auto load_patch = [&](int n, int gy0, int gx0) {
-        const __bf16* base = xg + ((size_t)(n * d.Hi + (gy0 >> upshift)) * d.Wi + (gx0 >> upshift)) * d.x.cs + d.x.coff;
+        const int soff = ((n * x_Hi + (gy0 >> upshift)) * x_Wi + (gx0 >> upshift)) * x_cs2;
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
             const int ly = gy0 + (int)(short)(p_yx[q] & 0xffff), lx = gx0 + (p_yx[q] >> 16);
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if ((unsigned)ly < (unsigned)LH && (unsigned)lx < (unsigned)LW)
-                val = *reinterpret_cast<const u32x4*>(base + p_rel[q]);
-            rp[q] = val;
+            const bool in = (unsigned)ly < (unsigned)LH && (unsigned)lx < (unsigned)LW;
+            rp[q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, in ? p_rel[q] : WS_OOB, soff, 0);
         }
     };
+    int p_lds[NPV];                                            // (tile-invariant LDS offsets: not recomputed per tile)
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) {
+        const int v = tid + q * 256;
+        const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
+        p_lds[q] = (pp8 >> 2) * PLANE + pix * WS_AROW + (pp8 & 3) * 16;
+    }
     auto store_patch = [&](int buf) {
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int q = 0; q < NPV; ++q) {
-            const int v = tid + q * 256;
-            const int pix = v / (NPL * 4), pp8 = v - pix * (NPL * 4);
-            if (v < NV) *reinterpret_cast<u32x4*>(base + (pp8 >> 2) * PLANE + pix * WS_AROW + (pp8 & 3) * 16) = rp[q];
+            if ((q + 1) * 256 <= NV || tid + q * 256 < NV) *reinterpret_cast<u32x4*>(base + p_lds[q]) = rp[q];
         }
     };
-    auto decode = [&](int tile, int& n, int& gy0, int& gx0) {
+    // tile -> (image, tile row, tile column): decoded once by division, then advanced by the grid stride with carries (two
+    // divisions by run-time values per tile were ~40 scalar / vector instructions in a loop that is issue-bound)
+    struct TilePos { int n, ty, tx; };
+    auto decode = [&](int tile) {
+        TilePos t;
         int b = tile;
-        const int tx_i = b % tiles_x; b /= tiles_x;
-        const int ty_i = b % tiles_y;
-        n = b / tiles_y;
-        gy0 = ty_i * WS_TH; gx0 = tx_i * WS_TW;
+        t.tx = b % tiles_x; b /= tiles_x;
+        t.ty = b % tiles_y;
+        t.n = b / tiles_y;
+        return t;
     };
-
+    const TilePos stride_pos = decode((int)gridDim.x);
+    auto advance = [&](TilePos t) {
+        t.tx += stride_pos.tx;
+        int cy = 0;
+        if (t.tx >= tiles_x) { t.tx -= tiles_x; cy = 1; }
+        t.ty += stride_pos.ty + cy;
+        int cn = 0;
+        if (t.ty >= tiles_y) { t.ty -= tiles_y; cn = 1; }
+        t.n += stride_pos.n + cn;
+        return t;
+    };
     __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(d.y.p);
     __bf16* __restrict__ y0p = reinterpret_cast<__bf16*>(d.y0.p);
     __bf16* __restrict__ y1p = reinterpret_cast<__bf16*>(d.y1.p);
@@ -141,9 +169,10 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     __bf16* slab1 = slab + 4 * (32 * SROW);                // second output (lean Y1 variants)
 
     int tile = blockIdx.x;
-    int n, gy0, gx0;
+    int n = 0, gy0 = 0, gx0 = 0;
+    TilePos tp = decode(tile);
     if (tile < ntiles) {
-        decode(tile, n, gy0, gx0);
+        n = tp.n; gy0 = tp.ty * WS_TH; gx0 = tp.tx * WS_TW;
         load_patch(n, gy0, gx0);
         store_patch(0);
     }
@@ -152,12 +181,12 @@ __global__ __launch_bounds__(256, (NPL * NT > 2 ? 1 : 2)) void conv_ws_kernel(co
     for (; tile < ntiles; tile += gridDim.x) {
         WPROBE(0);
         const int next = tile + gridDim.x;
-        int n_n = 0, gy0_n = 0, gx0_n = 0;
+        tp = advance(tp);
+        // past the last tile the patch of the current tile is requested again (valid addresses, never stored): no branch
+        const bool has_next = next < ntiles;
+        const int n_n = has_next ? tp.n : n, gy0_n = has_next ? tp.ty * WS_TH : gy0, gx0_n = has_next ? tp.tx * WS_TW : gx0;
 #ifndef WS_NO_LOAD
-        if (next < ntiles) {
-            decode(next, n_n, gy0_n, gx0_n);
-            load_patch(n_n, gy0_n, gx0_n);
-        }
+        load_patch(n_n, gy0_n, gx0_n);
 #endif
         WPROBE(1);
         // ---- this lane's output pixel ----

@@ -7,8 +7,8 @@
 __device__ unsigned long long* g_probe;
 #include "../satlas_super_resolution_amd/csrc/conv_big.hip"
 int main(int argc, char** argv) {
-    const int N = 16, H = argc > 1 ? atoi(argv[1]) : 128, W = H, Cin = argc > 2 ? atoi(argv[2]) : 128, Cout = argc > 3 ? atoi(argv[3]) : 64;
-    const int KT = argc > 4 ? atoi(argv[4]) : 3;
+    const int N = argc > 6 ? atoi(argv[6]) : 16, H = argc > 1 ? atoi(argv[1]) : 128, W = H, Cin = argc > 2 ? atoi(argv[2]) : 128, Cout = argc > 3 ? atoi(argv[3]) : 64;
+    const int KT = argc > 4 ? atoi(argv[4]) : 3, ep21 = argc > 5 ? atoi(argv[5]) : 0;   // ep21 = 1: LeakyReLU + residual + second output (the U-Net decoder's forward convs)
     __bf16 *x, *w, *y; const size_t nx = (size_t)N * H * W * Cin * 2, ny = (size_t)N * H * W * Cout * 2, nw = (size_t)Cin * 9 * Cout * 2;
     hipMalloc(&x, nx); hipMalloc(&y, ny); hipMalloc(&w, nw);
     hipMemset(x, 0x3c, nx); hipMemset(w, 0x3c, nw);
@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
     d.dtype = SSR_BF16; d.x = {x, Cin, 0}; d.N = N; d.Hi = H; d.Wi = W; d.up = 1; d.Cin = Cin; d.w = w; d.CoutPad = Cout;
     d.KH = d.KW = KT; d.stride = 1; d.pad_y = d.pad_x = KT == 3 ? 1 : 0; d.Gh = H; d.Gw = W; d.Ho = H; d.Wo = W; d.oys = d.oxs = 1;
     d.Cout = Cout; d.y = {y, Cout, 0}; d.alpha = 1.f; d.act = 1;
+    if (ep21) { __bf16 *r1, *y0; hipMalloc(&r1, ny); hipMalloc(&y0, ny); hipMemset(r1, 0x3c, ny); d.r1 = {r1, Cout, 0}; d.r1_nc = Cout; d.beta1 = 1.f; d.y0 = {y0, Cout, 0}; }
     const int nb = N * ((H + 31) / 32) * ((W + 15) / 16) * (Cout / 64);
     unsigned long long* probe; hipMalloc(&probe, (size_t)nb * 16 * 8); hipMemset(probe, 0, (size_t)nb * 16 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &probe, sizeof(probe));

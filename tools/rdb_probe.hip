@@ -6,13 +6,15 @@
 #include <vector>
 __device__ unsigned long long* g_probe;
 #include "../satlas_super_resolution_amd/csrc/rdb_fwd.hip"
+// the 8x16-tile kernel (round 3) is a separate translation unit in the library; this probe times the 8x8 kernel only (desc.tile = 8 / SSR_RDB_TILE=0)
+int rdbt_launch(const ssr_rdb_desc&, void*, bool, int) { return SSR_EUNSUP; }
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16, H = 32, W = 32, CS = 192;
     __bf16 *cur, *out, *w[5];
     hipMalloc(&cur, (size_t)N * H * W * CS * 2); hipMalloc(&out, (size_t)N * H * W * CS * 2);
     hipMemset(cur, 0x3c, (size_t)N * H * W * CS * 2);
     const int cin[5] = {64, 96, 128, 160, 192}, cp[5] = {32, 32, 32, 32, 64};
-    ssr_rdb_desc d{};
+    ssr_rdb_desc d{}; d.tile = 8;
     for (int k = 0; k < 5; ++k) { size_t b = (size_t)cin[k] * 9 * cp[k] * 2; hipMalloc(&w[k], b); hipMemset(w[k], 0x3c, b); d.w[k] = w[k]; }
     d.dtype = SSR_BF16; d.N = N; d.H = H; d.W = W; d.in = {cur, CS, 0}; d.slices = {cur, CS, 0}; d.mask = {cur, CS, 0}; d.out = {out, CS, 0}; d.alpha5 = 0.2f; d.beta1 = 1.f;
     const int nblk = N * 16;

@@ -708,6 +708,11 @@ bool ssr_conv_big_shape_ok(const ssr_conv_desc& d) {
     if (d.r1.p && d.r1_nc < d.Cout) return false;
     if (d.r2.p && d.r2_nc < d.Cout) return false;
     if (d.m.p && !(d.m_c0 == 0 && d.m_c1 >= d.Cout)) return false;
+    // buffer addressing: every tensor is reached through a 32-bit byte offset from its resource base (the staging loads, the
+    // epilogue operands, the output stores).  Larger tensors go to the generic kernel (64-bit pointers).
+    const long lim = 0x7fffff00L;
+    const long xin = ((long)d.N * d.Hi * d.Wi + d.Wi + 1) * d.x.cs * 2, npo = (long)d.N * d.Ho * d.Wo * 2;
+    if (xin > lim || npo * d.y.cs > lim || (d.y0.p && npo * d.y0.cs > lim) || (d.r1.p && npo * d.r1.cs > lim) || (d.m.p && npo * d.m.cs > lim)) return false;
     auto al = [](const ssr_view& v) { return !v.p || ((v.cs % 4) == 0 && (v.coff % 4) == 0 && ((uintptr_t)v.p % 8) == 0); };
     auto al16 = [](const ssr_view& v) { return (v.cs % 8) == 0 && (v.coff % 8) == 0 && ((uintptr_t)v.p % 16) == 0; };
     return al16(d.y) && al(d.y0) && al(d.y1) && al(d.r1) && al(d.r2) && al(d.m);

@@ -427,6 +427,8 @@ bool ssr_conv_ws_shape_ok(const ssr_conv_desc& d) {
     if (d.r1.p && d.r1_nc < d.Cout) return false;
     if (d.r2.p && d.r2_nc < d.Cout) return false;
     if (d.m.p && !(d.m_c0 == 0 && d.m_c1 >= d.Cout)) return false;
+    // the patch loads address x through a 32-bit byte offset from a buffer resource: larger inputs go to the generic kernel
+    if (((long)d.N * d.Hi * d.Wi + d.Wi + 1) * d.x.cs * 2 > 0x7fffff00L) return false;
     auto al = [](const ssr_view& v) { return !v.p || ((v.cs % 4) == 0 && (v.coff % 4) == 0 && ((uintptr_t)v.p % 8) == 0); };
     return al(d.y) && al(d.y0) && al(d.y1) && al(d.r1) && al(d.r2) && al(d.m);
 }

@@ -120,8 +120,13 @@ class ShmBlock:
         self.buf = np.frombuffer(self._mm, dtype=np.uint8)       # a plain ndarray: slicing a np.memmap costs ~10 us per view
 
     def close(self):
-        self.buf = None                                        # (the mapping itself goes when the last view of it does)
+        self.buf = None
         try:
+            self._mm.close()                                   # refused while a view of the block is still alive somewhere:
+        except (BufferError, ValueError):                      # then the mapping goes with the last view
+            pass
+        try:
+            self._f.close()
             os.unlink(self.path)
         except OSError:
             pass

@@ -108,12 +108,22 @@ def instrumented_step(ts, args, dtype=None):
             elif name == "ssr_conv2d_wgrad":
                 sym = f"wgrad_kernel<{dtype},K{a[4]}>"
                 fl = WGRAD_FLOPS.get(a[0], 0.0)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            # one event pair per RUN of consecutive launches of the same kernel symbol (the 69 dense blocks of the forward chain are
+            # one run): an event record is a barrier packet with a cache release of its own - around every single launch it added
+            # ~4 us to each (dense block 36 us against 32 us in a rocprofv3 trace of the same launches)
+            if not records or records[-1][6] or records[-1][0] != sym:
+                if records and not records[-1][6]:
+                    records[-1][3].record()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                records.append([sym, 0.0, e0, e1, what, 0, False])
             rc = fn(*a, hip.stream_ptr())
-            e1.record()
             assert rc == 0, (name, rc)
-            records.append((sym, fl, e0, e1, what))
+            records[-1][1] += fl
+            records[-1][5] += 1
+        if records and not records[-1][6]:      # a launch list ends: close the run (torch fills / copies between lists stay outside)
+            records[-1][3].record()
+            records[-1][6] = True
 
     class Rec:
         def __init__(self, L):
@@ -133,6 +143,16 @@ def instrumented_step(ts, args, dtype=None):
     # durations in a rocprofv3 trace of the real step are longer while the step is shorter.)
     overlap, ts.overlap_d = getattr(ts, "overlap_d", False), False
     register_wgrad_flops(ts)
+    # The host issues these ~600 launches one by one from Python (an event record, a ctypes call, an event record: ~25 us each),
+    # about as fast as the device executes them; whenever the device got ahead, the time it then waited for the next kernel to
+    # ARRIVE lay between that kernel's two events (dense block: 36 us here against 32 us in a rocprofv3 trace of the same launches).
+    # A spinning plug kernel in front keeps the device busy until the whole step is queued: the events then bracket device time only.
+    plug_ms = float(os.environ.get("SSR_BENCH_PLUG_MS", "40"))
+    if plug_ms > 0 and hasattr(torch.cuda, "_sleep"):
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(); torch.cuda._sleep(2_000_000); c1.record(); c1.synchronize()       # cycles of the spin kernel's clock per ms
+        per_ms = 2_000_000 / max(1e-3, c0.elapsed_time(c1))
+        torch.cuda._sleep(int(plug_ms * per_ms))
     try:
         ts.step()
     finally:
@@ -142,14 +162,14 @@ def instrumented_step(ts, args, dtype=None):
     torch.cuda.synchronize()
     agg, per_layer = {}, {}
 
-    for sym, fl, e0, e1, what in records:
+    for sym, fl, e0, e1, what, cnt, _closed in records:
         secs = e0.elapsed_time(e1) * 1e-3
         a = agg.setdefault(sym, [0, 0.0, 0.0])
-        a[0] += 1
+        a[0] += cnt
         a[1] += secs
         a[2] += fl
-        b = per_layer.setdefault((what, sym), [0, 0.0, 0.0])
-        b[0] += 1
+        b = per_layer.setdefault((what, sym), [0, 0.0, 0.0])      # (a run is filed under its first launch's label)
+        b[0] += cnt
         b[1] += secs
         b[2] += fl
     if os.environ.get("SSR_BENCH_LAYER_DUMP"):
@@ -432,8 +452,8 @@ def main():
         out["roofline"] = dict(roof0, traffic=traffic)
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
-        out["roofline"]["note"] = ("launch durations from an instrumented step in which every launch runs alone (forks inlined, HIP events "
-                                   "around each C-ABI call on the launch stream); compare with a rocprofv3 trace taken with "
+        out["roofline"]["note"] = ("launch durations from an instrumented step in which every launch runs alone (forks inlined, queued behind a spinning plug kernel so that no host latency lies between the events, one HIP event pair "
+                                   "around each run of consecutive launches of the same kernel on the launch stream); compare with a rocprofv3 trace taken with "
                                    "SSR_OVERLAP_D=0 SSR_G_SPLIT=0 (profiles/*_kernel_stats_serial*.csv) — in the overlapped step the "
                                    "kernels share the CUs")
         out["kernel_time_breakdown_ms"] = {k: round(1e3 * v[1], 4) for k, v in

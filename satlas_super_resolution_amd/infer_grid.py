@@ -70,6 +70,8 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
     # box that grants 16), shared by the ranks of the node, one core left to each rank's driver thread
     workers = int(opt.get("io_workers", max(1, min(16, png_io.host_cores() // max(1, world) - 1))))
     done = 0
+    import time as _clock
+    t_start = _clock.perf_counter()
 
     def out_path(i):
         tile, idx = pngs[i].split("/")[-2], pngs[i].split("/")[-1]      # keep tile / index so that the stitch finds them
@@ -105,9 +107,11 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
             fs = []
             for arrs, size, path, s2 in ((keep.pop(tile), 2048, sr_path, False), (raw_keep.pop(tile), 512, s2_path, True)):
                 m = png_io.mosaic([arrs[c] for c in cells], size, 16, s2)
-                blk = new_block(m.nbytes, f"mosaic{len(blocks)}")
+                # a one-shot block per mosaic: not in `blocks` (it is closed and unlinked as soon as its file is written), and the
+                # worker maps it transiently - a cached mapping of an unlinked block keeps its tmpfs pages allocated
+                blk = png_io.ShmBlock(m.nbytes, sdir, f"r{rank}_mosaic")
                 blk.buf[:] = m.reshape(-1)
-                f = pool.submit("save_from", blk.path, blk.nbytes, [(0, tuple(m.shape), path)])
+                f = pool.submit("save_from", blk.path, blk.nbytes, [(0, tuple(m.shape), path)], True)
                 f.add_done_callback(lambda _f, b=blk: b.close())
                 fs.append(f)
             return fs
@@ -244,7 +248,9 @@ def run_infer_grid(opt: Dict, model: Optional[Callable[[torch.Tensor], torch.Ten
                 stitched += 1
             for f in rest:
                 f.result()
-    return {"chunks": done, "tiles_stitched": stitched}
+    secs = _clock.perf_counter() - t_start
+    # (io_workers / seconds: what the run had and took - eight ranks on one host share its cores, README.md:159 of the reference)
+    return {"chunks": done, "tiles_stitched": stitched, "io_workers": workers, "seconds": round(secs, 3)}
 
 
 def main():

@@ -143,23 +143,47 @@ def shm_dir(need_bytes: int) -> str:
     return tempfile.gettempdir()
 
 
-_MAPS = {}
+_MAPS = {}          # path -> (ndarray view, mmap): the FIXED blocks of a run (in / out rings), mapped once per worker
+_MAPS_MAX = 16
+
+
+def _open_map(path: str, nbytes: int):
+    import mmap
+    with open(path, "r+b") as f:
+        mm = mmap.mmap(f.fileno(), nbytes)
+    return np.frombuffer(mm, dtype=np.uint8), mm
+
+
+def _close_map(entry):
+    arr, mm = entry
+    del arr
+    try:
+        mm.close()                                             # gives the pages of an unlinked block back to the tmpfs
+    except (BufferError, ValueError):                          # a view is still alive somewhere: the mapping goes with it
+        pass
 
 
 def _map(path: str, nbytes: int) -> np.ndarray:
-    m = _MAPS.get(path)
-    if m is None or m.shape[0] != nbytes:
-        import mmap
-        if len(_MAPS) > 64:
-            _MAPS.clear()
-        with open(path, "r+b") as f:
-            m = _MAPS[path] = np.frombuffer(mmap.mmap(f.fileno(), nbytes), dtype=np.uint8)
-    return m
+    """cached mapping of a long-lived block.  Least-recently-used entries are CLOSED when the cache is full: a worker that merely
+    dropped its reference kept the tmpfs pages of blocks the driver had long unlinked (a 12.6-MB mosaic block per tile and worker
+    on a multi-hundred-tile run filled /dev/shm; one-shot blocks now go through `transient`)."""
+    e = _MAPS.pop(path, None)
+    if e is not None and e[0].shape[0] != nbytes:
+        _close_map(e)
+        e = None
+    if e is None:
+        while len(_MAPS) >= _MAPS_MAX:
+            _close_map(_MAPS.pop(next(iter(_MAPS))))
+        e = _open_map(path, nbytes)
+    _MAPS[path] = e                                            # (re-)inserted last = most recently used
+    return e[0]
 
 
-def read_into(paths: Sequence[str], shm_path: str, nbytes: int, offsets: Sequence[int], slot_bytes: int):
-    """decode every file into its slot of the block; returns the shapes (an image that does not fit its slot comes back as an array)"""
-    m = _map(shm_path, nbytes)
+def read_into(paths: Sequence[str], shm_path: str, nbytes: int, offsets: Sequence[int], slot_bytes: int, transient: bool = False):
+    """decode every file into its slot of the block; returns the shapes (an image that does not fit its slot comes back as an array).
+    transient: the block is used once (map, fill, unmap; nothing cached)"""
+    e = _open_map(shm_path, nbytes) if transient else None
+    m = e[0] if transient else _map(shm_path, nbytes)
     out = []
     for pth, off in zip(paths, offsets):
         a = read_png(pth)
@@ -168,15 +192,23 @@ def read_into(paths: Sequence[str], shm_path: str, nbytes: int, offsets: Sequenc
             continue
         m[off:off + a.nbytes] = a.reshape(-1)
         out.append(tuple(a.shape))
+    if transient:
+        del m
+        _close_map(e)
     return out
 
 
-def save_from(shm_path: str, nbytes: int, items: Sequence[Tuple[int, Tuple[int, ...], str]]) -> int:
-    """encode and write the images that lie at (offset, shape) in the block"""
-    m = _map(shm_path, nbytes)
+def save_from(shm_path: str, nbytes: int, items: Sequence[Tuple[int, Tuple[int, ...], str]], transient: bool = False) -> int:
+    """encode and write the images that lie at (offset, shape) in the block.  transient: a one-shot block (a tile's mosaic) -
+    mapped, encoded and unmapped here, so that the driver's unlink really frees it"""
+    e = _open_map(shm_path, nbytes) if transient else None
+    m = e[0] if transient else _map(shm_path, nbytes)
     for off, shape, path in items:
         n = int(np.prod(shape))
         save_png(m[off:off + n].reshape(shape), path)
+    if transient:
+        del m
+        _close_map(e)
     return len(items)
 
 

@@ -83,7 +83,7 @@ def resolve_resume(opt: Dict, auto_resume: bool = False, log=print) -> Optional[
     `training_states/<iter>.state` and OVERRIDES `path.resume_state`; a resume ALWAYS redirects `pretrain_network_{g,d}` to
     `models/net_{g,d}_<iter>.pth` (unless the net is listed in `path.ignore_resume_networks`), and a missing file is an error, not a
     silent fall-back to the pretrain weights: optimizer moments, EMA and iteration counters of the state file belong to those
-    weights and to no others."""
+    weights and to no others; every `path.param_key_*` that says 'params_ema' is reset to 'params'."""
     path = opt["path"]
     state_file = None
     if auto_resume and os.path.isdir(path["training_states"]):
@@ -108,6 +108,13 @@ def resolve_resume(opt: Dict, auto_resume: bool = False, log=print) -> Optional[
         if path.get(f"pretrain_network_{net}") not in (None, cand):
             log(f"resume: pretrain_network_{net} is redirected to {cand}")
         path[f"pretrain_network_{net}"] = cand
+    # check_resume's last step: a checkpoint written by save() holds the TRAINED weights under 'params' and the EMA under
+    # 'params_ema'; the option files read `param_key_g: params_ema` for fine-tuning / inference, and on a resume that would load
+    # the EMA into the trainable generator while the restored Adam moments and counters belong to 'params'
+    for k in [k for k in path if k.startswith("param_key")]:
+        if path[k] == "params_ema":
+            path[k] = "params"
+            log(f"resume: {k} is reset from 'params_ema' to 'params' (the optimizer state belongs to the raw weights)")
     return resume
 
 

@@ -114,48 +114,47 @@ class ESRGANTrainStep:
         # log() adds in index order; weight gradients of split layers go through per-split partial buffers (engine.WgradBatch);
         # the generator runs as ONE chain (two half-batch chains would add into the same gradients concurrently)
         self.det = bool(cfg.deterministic) or engine.deterministic()
-        self._det_ctx = engine.deterministic_mode(self.det)
-        self._det_ctx.__enter__()
-        self.loss_dt = self.dt | (hip.DETERMINISTIC if self.det else 0)
-        self.loss_stride = hip.LOSS_SLOTS if self.det else 1
-        self.losses = torch.zeros(8 * self.loss_stride, dtype=torch.float32, device=dev)
-        self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
-                                               num_feat=d_kwargs.get("num_feat", 64),
-                                               skip_connection=d_kwargs.get("skip_connection", True))
-        import os
-        # the generator as two half-batch launch chains (engine.SplitGeneratorPlan) where its launches are latency chains of
-        # single-wave-per-CU kernels: the fused dense blocks (bf16, nf = 64, gc = 32) at batches of two full rounds or more
-        # r02g, two boxes, B = 32 8xS2 bf16: 14.40 -> 13.97 ms and 13.78 -> 13.53 ms per step with two chains; four chains
-        # (half-chip launches): 14.9 ms — slower; B = 16 (one round per launch already): no difference
-        # r03: the 8 x 16-tile dense-block kernel (csrc/rdb_tile.hip) wants the WHOLE batch in one launch (one workgroup per CU at
-        # B = 32, 32 x 32 tiles) and brings its own second wave per SIMD; measured 12.49 ms (one chain, new kernel) vs 12.68 (two
-        # chains, new kernel) vs 13.32 (two chains, 8 x 8 kernel).  "auto" = split only where the 8 x 8 kernel will run.
-        env_split = os.environ.get("SSR_G_SPLIT", "auto")
-        probe = hip.RdbDesc()       # ask the library which dense-block kernel this launch shape gets instead of restating its rule
-        probe.dtype, probe.N, probe.H, probe.W = hip.BF16, B, h, w
-        wide = hip.lib().ssr_rdb_tile_of(C.byref(probe)) == 16
-        n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
-        split = n_split > 1 and not self.det and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
-            and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
-        if split:
-            self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
-                                                    parts=n_split, **g_kwargs)
-        else:
-            # data parallel: G's backward in segments, so that a segment's slice of the gradient arena is on the wire while the next
-            # segment computes (step(): one all-reduce per segment).  SSR_DP_SEGMENTS=1: one exchange behind the whole backward.
-            n_seg = max(1, int(os.environ.get("SSR_DP_SEGMENTS", "3"))) if (dp is not None and dp.active) else 1
-            self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
-                                               bwd_segments=n_seg, **g_kwargs)
-        self.p_plan = None
-        if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
-            from .perceptual import PerceptualPlan
-            self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.dt, self.fake_in, self.percep_tgt, self.grad_l1,
-                                         self.losses.data_ptr() + 4 * 6 * self.loss_stride, num_ch=cout, state=vgg_state,
-                                         loss_flags=self.loss_dt & hip.DETERMINISTIC)
-            self.p_plan.pack()
-        self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
-        self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas_d or cfg.betas, cfg.eps, 0.0)
-        self._det_ctx.__exit__()
+        # plans capture the mode while THEY are built; the process-global switch is restored even when a constructor raises
+        with engine.deterministic_mode(self.det):
+            self.loss_dt = self.dt | (hip.DETERMINISTIC if self.det else 0)
+            self.loss_stride = hip.LOSS_SLOTS if self.det else 1
+            self.losses = torch.zeros(8 * self.loss_stride, dtype=torch.float32, device=dev)
+            self.d_plan = engine.DiscriminatorPlan(self.d_store, B, H, W, num_in_ch=cd,
+                                                   num_feat=d_kwargs.get("num_feat", 64),
+                                                   skip_connection=d_kwargs.get("skip_connection", True))
+            import os
+            # the generator as two half-batch launch chains (engine.SplitGeneratorPlan) where its launches are latency chains of
+            # single-wave-per-CU kernels: the fused dense blocks (bf16, nf = 64, gc = 32) at batches of two full rounds or more
+            # r02g, two boxes, B = 32 8xS2 bf16: 14.40 -> 13.97 ms and 13.78 -> 13.53 ms per step with two chains; four chains
+            # (half-chip launches): 14.9 ms — slower; B = 16 (one round per launch already): no difference
+            # r03: the 8 x 16-tile dense-block kernel (csrc/rdb_tile.hip) wants the WHOLE batch in one launch (one workgroup per CU at
+            # B = 32, 32 x 32 tiles) and brings its own second wave per SIMD; measured 12.49 ms (one chain, new kernel) vs 12.68 (two
+            # chains, new kernel) vs 13.32 (two chains, 8 x 8 kernel).  "auto" = split only where the 8 x 8 kernel will run.
+            env_split = os.environ.get("SSR_G_SPLIT", "auto")
+            probe = hip.RdbDesc()       # ask the library which dense-block kernel this launch shape gets instead of restating its rule
+            probe.dtype, probe.N, probe.H, probe.W = hip.BF16, B, h, w
+            wide = hip.lib().ssr_rdb_tile_of(C.byref(probe)) == 16
+            n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
+            split = n_split > 1 and not self.det and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
+                and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
+            if split:
+                self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
+                                                        parts=n_split, **g_kwargs)
+            else:
+                # data parallel: G's backward in segments, so that a segment's slice of the gradient arena is on the wire while the next
+                # segment computes (step(): one all-reduce per segment).  SSR_DP_SEGMENTS=1: one exchange behind the whole backward.
+                n_seg = max(1, int(os.environ.get("SSR_DP_SEGMENTS", "3"))) if (dp is not None and dp.active) else 1
+                self.g_plan = engine.GeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,
+                                                   bwd_segments=n_seg, **g_kwargs)
+            self.p_plan = None
+            if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
+                from .perceptual import PerceptualPlan
+                self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.dt, self.fake_in, self.percep_tgt, self.grad_l1,
+                                             self.losses.data_ptr() + 4 * 6 * self.loss_stride, num_ch=cout, state=vgg_state,
+                                             loss_flags=self.loss_dt & hip.DETERMINISTIC)
+                self.p_plan.pack()
+            self.opt_g = AdamState(self.g_store, cfg.lr_g, cfg.betas, cfg.eps, cfg.ema_decay)
+            self.opt_d = AdamState(self.d_store, cfg.lr_d, cfg.betas_d or cfg.betas, cfg.eps, 0.0)
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
         self._warm = set()
         self._side = None

@@ -1,4 +1,5 @@
-"""CPU, world_size 2, gloo: the data-parallel exchange (satlas_super_resolution_amd/dp.py).
+"""CPU, world_size 2 / 4 / 8, gloo: the data-parallel exchange (satlas_super_resolution_amd/dp.py; the reference launches 8 ranks,
+/root/reference/README.md:159).
 
 Checks (a) chunked async all-reduce of a flat arena, (b) the DP identity the design relies on:
 per-rank half-batch gradients summed and scaled by 1/world equal the full-batch gradients of the
@@ -29,7 +30,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from satlas_super_resolution_amd.dp import init_distributed
     from oracle import esrgan_oracle as O
-    torch.set_num_threads(2)
+    torch.set_num_threads(1 if world > 4 else 2)
     ctx = init_distributed(backend="gloo")
     assert ctx.world == world and ctx.rank == rank and ctx.active
     # (a) chunked all-reduce over a flat arena
@@ -37,14 +38,26 @@ def _worker(rank, world, port, q):
     flat = torch.arange(4321, dtype=torch.float32) * (rank + 1)
     ctx.all_reduce_async(flat)
     ctx.wait()
-    assert torch.equal(flat, torch.arange(4321, dtype=torch.float32) * 3)
-    assert abs(ctx.grad_scale - 0.5) < 1e-12
+    assert torch.equal(flat, torch.arange(4321, dtype=torch.float32) * (world * (world + 1) // 2))
+    assert abs(ctx.grad_scale - 1.0 / world) < 1e-12
+    # (a2) the segmented generator exchange of train_step.step(): the gradient arena is exchanged slice by slice, LAST slice first
+    # (engine.GeneratorPlan.bwd_segments: contiguous slices in backward order), each slice chunked on its own, each with its own
+    # handle; slice and chunk boundaries do not coincide (chunk_elems = 1000 against slices of 1501 / 1700 / 1120 elements)
+    arena = (torch.arange(4321, dtype=torch.float32) % 97) * (rank + 1)
+    bounds = [(2621, 4321), (1120, 2621), (0, 1120)]
+    assert sum(hi - lo for lo, hi in bounds) == arena.numel()
+    handles = [ctx.all_reduce_async(arena[lo:hi]) for lo, hi in bounds]
+    assert [len(h) for h in handles] == [2, 2, 2]          # ceil(1700 / 1000), ceil(1501 / 1000), ceil(1120 / 1000) collectives
+    for h in handles:
+        ctx.wait(h)
+    assert not ctx._pending
+    assert torch.equal(arena, (torch.arange(4321, dtype=torch.float32) % 97) * (world * (world + 1) // 2))
     # (b) DP identity on a small ESRGAN step
     g_kw = dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
     g0 = O.generator_init(seed=5, **g_kw)
     d0 = O.discriminator_init(3, 8, seed=6)
     torch.manual_seed(7)
-    lr, gt = torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32)
+    lr, gt = torch.rand(world, 6, 8, 8), torch.rand(world, 3, 32, 32)      # global batch = world x 1 (weak scaling: per-rank batch fixed)
     full = O.ESRGANOracle(g0, d0, O.StepConfig())
     full.step(lr, gt, 1)
     part = O.ESRGANOracle(g0, d0, O.StepConfig())
@@ -75,14 +88,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_dp_world2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=480) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -90,4 +104,4 @@ def test_dp_world2_gloo():
         assert eg < 1e-4, ("G grads", rank, eg)
         assert ed < 1e-4, ("D grads", rank, ed)
         assert same_uv
-        assert losses == [1.5, 2.0]
+        assert losses == [(world + 1) / 2, 2.0]

@@ -1,9 +1,9 @@
-"""GPU, world_size 2 on ONE device: the data-parallel branch of ESRGANTrainStep.step() — phase graphs ("g", "d", "opt_g",
+"""GPU, world_size 2 and 8 on ONE device (the reference launches 8 ranks, /root/reference/README.md:159): the data-parallel branch of ESRGANTrainStep.step() — phase graphs ("g", "d", "opt_g",
 "opt_d") with the gradient exchanges between them on the side stream, per-exchange wait events, 1/world folded into
 Adam — exercised end to end on the HIP path.  Two processes share cuda:0, so the collective backend is gloo (RCCL refuses
 two ranks on one device); everything else is the code path `bench.py --gpus N` runs over RCCL.
 
-Checks: both ranks end bit-identical; per-rank batch 1 + exchange == the CPU oracle's full-batch (B = 2) step, two
+Checks: all ranks end bit-identical; per-rank batch 1 + exchange == the CPU oracle's full-batch (B = world) step, two
 iterations (losses through reduce_scalars, parameters on the update, EMA)."""
 import os
 import socket
@@ -26,9 +26,9 @@ def _free_port():
     return p
 
 
-def _data():
+def _data(world=2):
     torch.manual_seed(11)
-    return [(torch.rand(2, 6, 8, 8), torch.rand(2, 3, 32, 32)) for _ in range(2)]
+    return [(torch.rand(world, 6, 8, 8), torch.rand(world, 3, 32, 32)) for _ in range(2)]
 
 
 def _worker(rank, world, port, q, outdir):
@@ -45,7 +45,8 @@ def _worker(rank, world, port, q, outdir):
     ts.load_state(O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6))
     ts.sync_params_from_rank0()
     logs = []
-    for it, (lr, gt) in enumerate(_data(), start=1):
+    assert len(ts.g_plan.bwd_segments) == 3      # G's exchange in three slices, each behind its backward segment
+    for it, (lr, gt) in enumerate(_data(world), start=1):
         ts.feed_data(lr[rank:rank + 1].cuda(), gt[rank:rank + 1].cuda())
         ts.step(it)
         logs.append(dict(ts.log()))
@@ -61,31 +62,33 @@ def _worker(rank, world, port, q, outdir):
 
 
 @pytest.mark.gpu
-def test_dp_world2_shared_gpu_matches_full_batch_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_shared_gpu_matches_full_batch_oracle(tmp_path, world):
     from oracle import esrgan_oracle as O
-    world, port = 2, _free_port()
+    port = _free_port()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     procs = [mpc.Process(target=_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
-    paths = [q.get(timeout=600) for _ in range(world)]
+    paths = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     res = sorted((torch.load(pth, weights_only=False) for pth in paths), key=lambda r: r[0])
-    (_, logs0, g0r, d0r, ema0), (_, logs1, g1r, d1r, _) = res
+    _, logs0, g0r, d0r, ema0 = res[0]
     # identical replicas after two steps (same reduced gradients, same deterministic updates)
-    for k in g0r:
-        assert torch.equal(g0r[k], g1r[k]), ("G replica mismatch", k)
-    for k in d0r:
-        assert torch.equal(d0r[k], d1r[k]), ("D replica mismatch", k)
-    assert logs0 == logs1
+    for _, logs1, g1r, d1r, _ in res[1:]:
+        for k in g0r:
+            assert torch.equal(g0r[k], g1r[k]), ("G replica mismatch", k)
+        for k in d0r:
+            assert torch.equal(d0r[k], d1r[k]), ("D replica mismatch", k)
+        assert logs0 == logs1
     # == the oracle's full-batch step
     g_init, d_init = O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6)
     orc = O.ESRGANOracle(g_init, d_init, O.StepConfig())
     lr_steps = 1e-4 * 2
-    for it, (lr, gt) in enumerate(_data(), start=1):
+    for it, (lr, gt) in enumerate(_data(world), start=1):
         ref_log = orc.step(lr, gt, it)
         for k, v in ref_log.items():
             assert abs(logs0[it - 1][k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, logs0[it - 1][k], v)
@@ -108,8 +111,9 @@ def test_dp_world2_shared_gpu_matches_full_batch_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_n_ranks_on_one_gpu_prints_one_json_line(world):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with all ranks on
     cuda:0 and gloo standing in for RCCL: every rank must take part in every collective — the timed steps, the max-over-
     ranks reduction AND the instrumented roofline step — and rank 0 alone prints the JSON line."""
     import json
@@ -117,15 +121,17 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SSR_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
-           "--batch", "2", "--blocks", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "2",
+           "--batch", "2", "--blocks", "1", "--no-cpu-baseline", "--blocks-timed", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["losses_finite"]
+    assert out["n_gpus"] == world and out["config"]["global_batch"] == 2 * world and out["losses_finite"]
+    assert out["config"]["parallelism"] == f"dp{world}" and out["scaling"] == "weak" and out["dtype"] == "fp32x3"
+    assert out["value"] == pytest.approx(2 * world * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-6)   # whole-job rate
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
 
 

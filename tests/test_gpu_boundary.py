@@ -158,9 +158,19 @@ def test_save_resume_round_trip_before_first_batch(tmp_path):
         a.feed_data(_batch(*data[it - 1]))
         a.optimize_parameters(it)
     # ---- second process: rebuild from the files, resume before the first batch
+    # through train.py's resolve_resume, with the key the shipped option files carry (`param_key_g: params_ema`,
+    # esrgan_s2naip_urban.yml:86-92): the resume must load the TRAINED weights ('params') into the generator - the Adam moments
+    # belong to them - and the EMA from 'params_ema' (BasicSR check_resume resets the key)
+    from satlas_super_resolution_amd.train import resolve_resume
     opt_b = copy.deepcopy(opt)
-    opt_b["path"]["pretrain_network_g"] = str(tmp_path / "models" / "net_g_2.pth")
-    opt_b["path"]["pretrain_network_d"] = str(tmp_path / "models" / "net_d_2.pth")
+    opt_b["path"].update(pretrain_network_g="published/esrgan.pth", param_key_g="params_ema", strict_load_g=True,
+                         resume_state=str(tmp_path / "states" / "2.state"))
+    state_b = resolve_resume(opt_b, log=lambda m: None)
+    assert state_b["iter"] == 2 and opt_b["path"]["param_key_g"] == "params"
+    assert opt_b["path"]["pretrain_network_g"] == str(tmp_path / "models" / "net_g_2.pth")
+    assert opt_b["path"]["pretrain_network_d"] == str(tmp_path / "models" / "net_d_2.pth")
+    ck = torch.load(tmp_path / "models" / "net_g_2.pth", map_location="cpu")
+    assert (ck["params"]["conv_first.weight"] - ck["params_ema"]["conv_first.weight"]).abs().max() > 0
     b = build_model(opt_b)
     b.resume_training(state)
     assert b.ts is None
@@ -373,27 +383,13 @@ def test_training_loop_on_the_miniature_dataset(tmp_path, monkeypatch):
 def test_test_pipeline_generator_only(tmp_path):
     """The model plugin built with is_train=False as ssr/test.py:14-46 builds it — generator only, the EMA weights of a
     checkpoint (`param_key_g: params_ema`) — driven over the `test_datasets` of an option file: `model.validation` computes the
-    `test.metrics` psnr / cpsnr on the device and writes the images; metrics outside this path raise by name.  (The reference's
-    test.py itself is BasicSR glue and out of scope: the few lines of it are restated here, not shipped.)"""
+    `test.metrics` psnr / cpsnr on the device and writes the images; metrics outside this path raise by name.  The driver is
+    satlas_super_resolution_amd/test.py, the BasicSR-free counterpart of the reference's ssr/test.py (as train.py is of ssr/train.py)."""
     import os
     from conftest import GOLDEN
     from oracle import esrgan_oracle as O
 
-    def test_pipeline(opt, log):
-        from satlas_super_resolution_amd import data as _data, models as _models  # noqa: F401  (register the plugins)
-        from satlas_super_resolution_amd.registry import build_dataset, build_model
-        opt = dict(opt, is_train=False, dist=False)
-        loaders = []
-        for _, dopt in sorted(opt["test_datasets"].items()):
-            dset = build_dataset(dict(dopt, phase=dopt.get("phase", "test"), scale=dopt.get("scale", opt.get("scale", 4))))
-            loaders.append(torch.utils.data.DataLoader(dset, batch_size=1, shuffle=False, num_workers=0))
-        model = build_model(opt)
-        results = {}
-        for loader in loaders:
-            model.validation(loader, current_iter=opt.get("name", "test"), tb_logger=None,
-                             save_img=opt.get("test", {}).get("save_img", False))
-            results[loader.dataset.opt["name"]] = dict(model.metric_results)
-        return results
+    from satlas_super_resolution_amd.test import test_pipeline       # `python -m satlas_super_resolution_amd.test -opt <yml>`
     mini = os.path.join(GOLDEN, "s2naip_mini")
     g_kw = dict(num_in_ch=24, num_out_ch=3, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
     sd = O.generator_init(seed=5, **g_kw)

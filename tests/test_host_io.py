@@ -86,6 +86,36 @@ def test_worker_pool_decodes_into_and_encodes_from_a_shared_block(tmp_path, work
         blk.close(); out.close()
 
 
+def test_one_shot_blocks_are_not_retained_and_the_mapping_cache_is_bounded(tmp_path):
+    """A tile's mosaic goes to an encoder through a block of its own that the driver unlinks when the file is written: the worker
+    must not keep a mapping of it (an unlinked tmpfs file stays allocated while mapped - 12.6 MB per tile and worker).  The cache of
+    the fixed blocks is bounded and closes what it evicts."""
+    img = np.random.RandomState(2).randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    n0 = len(png_io._MAPS)
+    for k in range(3):
+        blk = png_io.ShmBlock(img.nbytes, png_io.shm_dir(img.nbytes), "mosaic")
+        blk.buf[:] = img.reshape(-1)
+        dst = str(tmp_path / f"m{k}.png")
+        assert png_io.save_from(blk.path, blk.nbytes, [(0, img.shape, dst)], True) == 1      # transient: mapped, encoded, unmapped
+        assert blk.path not in png_io._MAPS and len(png_io._MAPS) == n0
+        blk.close()
+        assert np.array_equal(png_io.read_png(dst), img)
+    blks = [png_io.ShmBlock(64, png_io.shm_dir(64), "ring") for _ in range(png_io._MAPS_MAX + 3)]
+    try:
+        for b in blks:
+            png_io._map(b.path, b.nbytes)[0] = 7
+        assert len(png_io._MAPS) == png_io._MAPS_MAX and blks[0].path not in png_io._MAPS and blks[-1].path in png_io._MAPS
+        assert all(int(b.buf[0]) == 7 for b in blks)
+        png_io._map(blks[3].path, 64)                       # a hit moves the entry to the young end
+        assert list(png_io._MAPS)[-1] == blks[3].path
+    finally:
+        for b in blks:
+            e = png_io._MAPS.pop(b.path, None)
+            if e is not None:
+                png_io._close_map(e)
+            b.close()
+
+
 def test_a_dead_worker_fails_the_task_instead_of_hanging(tmp_path):
     with png_io.PngWorkerPool(1) as pool:
         pool.procs[0].kill()
@@ -138,6 +168,24 @@ def test_resume_without_the_matching_network_file_is_an_error_unless_the_network
     opt["path"]["ignore_resume_networks"] = ["network_d"]
     st = resolve_resume(opt, log=lambda m: None)
     assert st["iter"] == 300 and opt["path"]["pretrain_network_d"] is None and opt["path"]["pretrain_network_g"].endswith("net_g_300.pth")
+
+
+def test_resume_resets_param_key_params_ema_to_params(tmp_path):
+    """BasicSR's check_resume ends by resetting every path.param_key_* that reads 'params_ema' to 'params': the shipped option
+    files say `param_key_g: params_ema` (esrgan_s2naip_urban.yml:86-92) and a resume must load the TRAINED weights - the restored
+    Adam moments and counters belong to them - while the EMA comes from the checkpoint's 'params_ema' entry."""
+    from satlas_super_resolution_amd.train import resolve_resume
+    opt = _resume_tree(tmp_path, iters=(100,))
+    opt["path"].update(resume_state=os.path.join(opt["path"]["training_states"], "100.state"), param_key_g="params_ema",
+                       param_key_d="params", strict_load_g=True)
+    log = []
+    assert resolve_resume(opt, log=log.append)["iter"] == 100
+    assert opt["path"]["param_key_g"] == "params" and opt["path"]["param_key_d"] == "params"
+    assert any("param_key_g is reset" in m for m in log)
+    # a fresh run (no state) keeps the option file's key: fine-tuning from published EMA weights
+    opt2 = {"path": {"models": str(tmp_path / "m"), "training_states": str(tmp_path / "s"), "pretrain_network_g": "w.pth",
+                     "param_key_g": "params_ema"}}
+    assert resolve_resume(opt2, auto_resume=True) is None and opt2["path"]["param_key_g"] == "params_ema"
 
 
 def test_no_state_anywhere_means_a_fresh_run(tmp_path):

@@ -48,7 +48,7 @@ def main():
         res = run_infer_grid(opt, model=net)
         torch.cuda.synchronize()
         t_e2e = time.perf_counter() - t0
-        assert res == {"chunks": 256 * n_tiles, "tiles_stitched": n_tiles}, res
+        assert (res["chunks"], res["tiles_stitched"]) == (256 * n_tiles, n_tiles), res
         # the same run with the PNG work on threads of this process (io_workers = 0: the first version of the driver)
         shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
         t0 = time.perf_counter()

@@ -527,6 +527,286 @@ int launch_conv_x3(const ssr_conv_desc& d, hipStream_t st) {
     return SSR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the split kernel with a DEEP load pipeline.  rocprofv3 of the fp32x3 step (profiles/r05a_*): a 32-channel-output body
+// convolution at B = 32 took 15.5 us for 1.3 us of MFMA work - 2.2 us per 16-channel chunk, i.e. one memory round trip per chunk:
+// the loads of chunk c+1 were issued when chunk c's 14 MFMAs per wave began and waited for when they ended.  Here
+//   * a pipeline STAGE is CPS 16-channel chunks (NT = 1: two, 75 KB per LDS stage; NT = 2: one), so a layer has half the stages;
+//   * PD stages are in flight in REGISTERS beside the two LDS stages: the loads of stage s + PD are issued when stage s starts;
+//   * every staging load is ONE unconditional buffer load (a lane that must read zeros - outside the image, past the last
+//     channel, past the weight table - uses an offset beyond num_records), so hipcc can count them: the wait in front of a
+//     stage's LDS store is vmcnt(loads of the PD - 1 later stages), not vmcnt(0);
+//   * the two tap halves (KS = 2) take alternate (chunk, tap) pairs of a stage.
+// Same packed weights ([chunk16][tap][co][16 hi | 16 lo]), LDS row format, MFMA order inside a chunk and epilogue as conv_body_x3.
+// ------------------------------------------------------------------------------------------------------------------
+#ifdef SSR_PROBE   // tools/x3_probe.hip: s_memtime stamps of thread 0 of every workgroup, 24 slots per workgroup
+#define XPROBE(k) do { if (threadIdx.x == 0) g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XPROBE(k)
+#endif
+constexpr int X3_OOB = 0x7ffffff0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffff00L ? 0x7fffff00L : bytes), 0x00020000);
+}
+
+template <int KH, int KW, int NT, int MW, int KS, int CPS, int PD>
+__device__ __forceinline__ void conv_body_x3p(const ssr_conv_desc& d) {
+    constexpr int VPR = 4, ROWB = 80, BN = 32 * NT, NTAP = KH * KW;
+    constexpr int TH = 2 * MW, TW = 16;
+    constexpr int PH = TH - 1 + KH, PW = TW - 1 + KW;
+    constexpr int NTHR = 64 * MW * KS;
+    constexpr int PV1 = PH * PW * VPR, WV1 = NTAP * BN * VPR;           // vectors of one 16-channel chunk
+    constexpr int PVEC = CPS * PV1, WVEC = CPS * WV1;
+    constexpr int NPV = (PVEC + NTHR - 1) / NTHR, NWV = (WVEC + NTHR - 1) / NTHR;
+    constexpr int SUB = (PH * PW + NTAP * BN) * ROWB;                    // bytes of one chunk in LDS
+    constexpr int STAGE = CPS * SUB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    XPROBE(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MW, kh = wave / MW;
+    const int tiles_x = (d.Gw + TW - 1) / TW, tiles_y = (d.Gh + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * TH, gx0 = tx_i * TW;
+    const int co0 = blockIdx.y * BN;
+    const int upshift = d.up == 2 ? 1 : 0;
+    const int LH = d.Hi << upshift, LW = d.Wi << upshift;
+    const int Cin = d.Cin, Cin2 = d.Cin2, Ktot = Cin + Cin2;
+    const int nchunks = (Ktot + 15) / 16, nst = (nchunks + CPS - 1) / CPS;
+    const long xbytes = (long)d.N * d.Hi * d.Wi * 4;                     // x view.cs = bytes of an input-side tensor
+    const void* xp = d.x.p;
+    const void* x2p = d.x2.p ? d.x2.p : d.x.p;
+    const __amdgpu_buffer_rsrc_t rsw = x3_rsrc(d.w, (long)nchunks * NTAP * d.CoutPad * 64);
+
+    // ---- per-thread staging descriptors (independent of the stage) ----
+    int pgo[NPV], pgo2[NPV], plo[NPV], pk[NPV];       // byte offset of the pixel in x / x2 (X3_OOB: zeros), LDS offset, channel inside the stage
+    int wgo[NWV], wlo[NWV], wcc[NWV];
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) {
+        const int v = tid + q * NTHR;
+        const int cc = v / PV1, r = v - cc * PV1;
+        const int pix = r / VPR, part = r - pix * VPR;
+        const int py = pix / PW, px = pix - py * PW;
+        const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
+        const bool ok = v < PVEC && ly >= 0 && ly < LH && lx >= 0 && lx < LW;
+        const int po = (n * d.Hi + (ly >> upshift)) * d.Wi + (lx >> upshift);
+        pgo[q] = ok ? (po * d.x.cs + d.x.coff) * 4 : X3_OOB;
+        pgo2[q] = (ok && d.x2.p) ? (po * d.x2.cs + d.x2.coff) * 4 : X3_OOB;
+        pk[q] = cc * 16 + part * 4;
+        plo[q] = v < PVEC ? cc * SUB + pix * ROWB + part * 8 : -1;      // hi half of the row; lo half 32 bytes further
+    }
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) {
+        const int v = tid + q * NTHR;
+        const int cc = v / WV1, r = v - cc * WV1;
+        const int row = r / VPR, part = r - row * VPR;
+        const int tap = row / BN, co = row - tap * BN;
+        wcc[q] = v < WVEC ? cc : 0x10000;                               // (beyond the table: never below nchunks)
+        wgo[q] = ((cc * NTAP + tap) * d.CoutPad + co0 + co) * 64 + part * 16;
+        wlo[q] = v < WVEC ? cc * SUB + (PH * PW + row) * ROWB + part * 16 : -1;   // packed rows arrive pre-split [16 hi | 16 lo]
+    }
+    u32x4 rp[PD][NPV], rw[PD][NWV];
+    auto load_stage = [&](int s, auto jc) {            // stage s -> register set j; a stage past the end reads zeros (no memory access)
+        constexpr int j = decltype(jc)::value;
+        const int c0 = s * CPS * 16;
+        const bool live = s < nst;
+        const bool in_x = c0 < Cin;                    // a stage lies in ONE of the two views (the dispatcher checks Cin % (16 CPS) == 0 with x2)
+        const int cb = in_x ? c0 : c0 - Cin, clim = live ? (in_x ? Cin : Cin2) : 0, cs_bytes = (in_x ? d.x.cs : d.x2.cs);
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(in_x ? xp : x2p, xbytes * cs_bytes);
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            const int k = cb + pk[q];
+            const int po = in_x ? pgo[q] : pgo2[q];
+            rp[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (k < clim && po != X3_OOB) ? po + k * 4 : X3_OOB, 0, 0);
+        }
+        const int wbase = s * CPS * NTAP * d.CoutPad * 64, cleft = nchunks - s * CPS;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            rw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wcc[q] < cleft ? wgo[q] + wbase : X3_OOB, 0, 0);
+    };
+    auto store_stage = [&](int buf, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        char* base = smem + buf * STAGE;
+        uint2 hi, lo;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            split4(rp[j][q], hi, lo);
+            if ((q + 1) * NTHR <= PVEC || plo[q] >= 0) {
+                *reinterpret_cast<uint2*>(base + plo[q]) = hi;
+                *reinterpret_cast<uint2*>(base + plo[q] + 32) = lo;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NWV; ++q)
+            if ((q + 1) * NTHR <= WVEC || wlo[q] >= 0) *reinterpret_cast<u32x4*>(base + wlo[q]) = rw[j][q];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int i = lane & 31, g = lane >> 5;
+    const int ty = 2 * wm + (i >> 4), tx = i & 15;
+    const int a_off = (ty * PW + tx) * ROWB + g * 16;               // lane (i, g): channels g*8 .. g*8+7 of pixel i
+    const int b_off = (PH * PW + i) * ROWB + g * 16;
+    // A wave's share of a stage: the (chunk, tap) pairs of its parity (KS = 2) as STRAIGHT-LINE code (one instantiation per
+    // k-half, picked by a scalar branch): the operand reads of pair k + 1 are issued before the MFMAs of pair k and pinned there
+    // (left alone hipcc sinks every ds_read next to its MFMA: read, wait, MFMA chains).
+    auto contract_h = [&](int buf, auto hc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr int NITEM = KS == 2 ? (CPS * NTAP + 1 - H) / 2 : CPS * NTAP;     // pairs H, H + 2, ...
+        const char* ab = smem + buf * STAGE + a_off;
+        const char* bb = smem + buf * STAGE + b_off;
+        bf16x8 fa[2][2], fb[2][NT][2];
+        auto issue = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, it = KS == 2 ? 2 * k + H : k;
+            constexpr int cc = it / NTAP, tap = it % NTAP, ky = tap / KW, kx = tap % KW;
+            fa[k & 1][0] = *reinterpret_cast<const bf16x8*>(ab + cc * SUB + (ky * PW + kx) * ROWB);
+            fa[k & 1][1] = *reinterpret_cast<const bf16x8*>(ab + cc * SUB + (ky * PW + kx) * ROWB + 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fb[k & 1][t][0] = *reinterpret_cast<const bf16x8*>(bb + cc * SUB + (tap * BN + t * 32) * ROWB);
+                fb[k & 1][t][1] = *reinterpret_cast<const bf16x8*>(bb + cc * SUB + (tap * BN + t * 32) * ROWB + 32);
+            }
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NITEM>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (k + 1 < NITEM) issue(std::integral_constant<int, k + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k & 1][1], fb[k & 1][t][0], acc[t], 0, 0, 0);   // a_lo * b_hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k & 1][0], fb[k & 1][t][1], acc[t], 0, 0, 0);   // a_hi * b_lo
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k & 1][0], fb[k & 1][t][0], acc[t], 0, 0, 0);   // a_hi * b_hi
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int kh_s = __builtin_amdgcn_readfirstlane(kh);
+    auto contract = [&](int buf) {
+        if (KS == 2 && kh_s == 1) contract_h(buf, std::integral_constant<int, 1>{});
+        else contract_h(buf, std::integral_constant<int, 0>{});
+    };
+
+    XPROBE(1);
+    static_for<0, PD>([&](auto jc) { load_stage(decltype(jc)::value, jc); });
+    store_stage(0, std::integral_constant<int, 0>{});
+    __syncthreads();
+    XPROBE(2);
+    for (int c = 0; c < nst; c += PD) {
+        static_for<0, PD>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int cur = c + j;
+            if (cur < nst) {
+                load_stage(cur + PD, jc);                                  // set j held stage `cur`, which is in LDS already
+                contract(cur & 1);
+#ifdef SSR_PROBE
+                const unsigned long long tm_ = __builtin_amdgcn_s_memtime();      // stage 0: end of the MFMAs / end of the LDS store
+#endif
+                if (cur + 1 < nst) store_stage((cur + 1) & 1, std::integral_constant<int, (j + 1) % PD>{});
+#ifdef SSR_PROBE
+                if (threadIdx.x == 0 && cur == 0) { g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 24 + 20] = tm_; g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 24 + 21] = __builtin_amdgcn_s_memtime(); }
+#endif
+                __syncthreads();
+#ifdef SSR_PROBE
+                if (cur < 12) XPROBE(3 + cur);
+#endif
+            }
+        });
+    }
+    XPROBE(15);
+
+    char* slab = smem + (size_t)MW * 16 * 64 * sizeof(float) + (size_t)wave * EPI_STAGE_BYTES;
+    auto epilogue = [&](const f32x16& a, int t) {
+        conv_epilogue<float>(d, a, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+    };
+    if (KS == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) epilogue(acc[t], t);
+    } else {
+        float* red = reinterpret_cast<float*>(smem);          // [MW][16][64]
+        float* mine = red + (wm * 16) * 64 + lane;
+        if (NT == 2) {
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[1][r];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][r] += mine[r * 64];
+            }
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            } else {
+                epilogue(acc[1], 1);
+            }
+        } else {
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r * 64] = acc[0][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += mine[r * 64];
+                epilogue(acc[0], 0);
+            }
+        }
+    }
+    XPROBE(17);
+}
+
+template <int KH, int KW, int NT, int MW, int KS, int CPS, int PD>
+__global__ __launch_bounds__(64 * MW * KS) void conv_x3p_kernel(const ssr_conv_desc d) {
+    conv_body_x3p<KH, KW, NT, MW, KS, CPS, PD>(d);
+}
+
+template <int KH, int KW, int NT, int MW, int KS, int CPS, int PD>
+int launch_conv_x3p(const ssr_conv_desc& d, hipStream_t st) {
+    constexpr int BN = 32 * NT, TH = 2 * MW, TW = 16, PH = TH - 1 + KH, PW = TW - 1 + KW;
+    constexpr size_t stage = (size_t)CPS * (PH * PW + KH * KW * BN) * 80;
+    constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
+    constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_x3p_kernel<KH, KW, NT, MW, KS, CPS, PD>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, 1), dim3(64 * MW * KS), lds, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+// the deep-pipeline kernel reaches its tensors through 32-bit byte offsets and takes a pipeline stage from ONE input view
+bool x3p_ok(const ssr_conv_desc& d, int cps) {
+    static const bool off = [] { const char* e = getenv("SSR_X3_PIPE"); return e && e[0] == '0'; }();
+    if (off) return false;
+    const long lim = 0x7fffff00L, npx = (long)d.N * d.Hi * d.Wi * 4;
+    if (npx * d.x.cs > lim || (d.x2.p && npx * d.x2.cs > lim)) return false;
+    if (d.x2.p && (d.Cin % (16 * cps)) != 0) return false;
+    return true;
+}
+
 template <int KH, int KW>
 int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
     bool nt2, small;
@@ -537,6 +817,11 @@ int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
     // 38.1 ms without small tiles, 60.0 ms with small tiles everywhere.  SSR_X3_SMALL = threshold in 8x16 tiles (tuning hook).
     static const long thr = [] { const char* e = getenv("SSR_X3_SMALL"); return e ? atol(e) : 0L; }();
     small = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32)) < thr;
+    if (!small) {      // round 5: deep load pipeline (two chunks per stage at 32 output channels, three register stages at 64)
+        static const bool p2 = [] { const char* e = getenv("SSR_X3_PIPE2"); return e && e[0] == '1'; }();   // 64 output channels: measured slower than the plain pipeline (r05b: 10.4 vs 9.6 ms per step), opt-in
+        if (nt2 && p2 && x3p_ok(d, 1)) return launch_conv_x3p<KH, KW, 2, 4, 2, 1, 3>(d, st);
+        if (!nt2 && x3p_ok(d, 2)) return launch_conv_x3p<KH, KW, 1, 4, 2, 2, 2>(d, st);
+    }
     if (nt2) return small ? launch_conv_x3<KH, KW, 2, 2, 2>(d, st) : launch_conv_x3<KH, KW, 2, 4, 2>(d, st);
     return small ? launch_conv_x3<KH, KW, 1, 2, 2>(d, st) : launch_conv_x3<KH, KW, 1, 4, 2>(d, st);
 }

@@ -628,22 +628,23 @@ __device__ __forceinline__ void conv_body_x3p(const ssr_conv_desc& d) {
         for (int q = 0; q < NWV; ++q)
             rw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wcc[q] < cleft ? wgo[q] + wbase : X3_OOB, 0, 0);
     };
-    auto store_stage = [&](int buf, auto jc) {
-        constexpr int j = decltype(jc)::value;
+    // one vector of register set j -> LDS stage `buf` (u < NPV: a patch vector, split here; else a weight vector)
+    auto store_unit = [&](int buf, auto jc, auto uc) {
+        constexpr int j = decltype(jc)::value, u = decltype(uc)::value;
         char* base = smem + buf * STAGE;
-        uint2 hi, lo;
-#pragma unroll
-        for (int q = 0; q < NPV; ++q) {
-            split4(rp[j][q], hi, lo);
-            if ((q + 1) * NTHR <= PVEC || plo[q] >= 0) {
-                *reinterpret_cast<uint2*>(base + plo[q]) = hi;
-                *reinterpret_cast<uint2*>(base + plo[q] + 32) = lo;
+        if constexpr (u < NPV) {
+            uint2 hi, lo;
+            split4(rp[j][u], hi, lo);
+            if ((u + 1) * NTHR <= PVEC || plo[u] >= 0) {
+                *reinterpret_cast<uint2*>(base + plo[u]) = hi;
+                *reinterpret_cast<uint2*>(base + plo[u] + 32) = lo;
             }
-        }
-#pragma unroll
-        for (int q = 0; q < NWV; ++q)
+        } else {
+            constexpr int q = u - NPV;
             if ((q + 1) * NTHR <= WVEC || wlo[q] >= 0) *reinterpret_cast<u32x4*>(base + wlo[q]) = rw[j][q];
+        }
     };
+    auto store_stage = [&](int buf, auto jc) { static_for<0, NPV + NWV>([&](auto uc) { store_unit(buf, jc, uc); }); };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -657,7 +658,7 @@ __device__ __forceinline__ void conv_body_x3p(const ssr_conv_desc& d) {
     // A wave's share of a stage: the (chunk, tap) pairs of its parity (KS = 2) as STRAIGHT-LINE code (one instantiation per
     // k-half, picked by a scalar branch): the operand reads of pair k + 1 are issued before the MFMAs of pair k and pinned there
     // (left alone hipcc sinks every ds_read next to its MFMA: read, wait, MFMA chains).
-    auto contract_h = [&](int buf, auto hc) {
+    auto contract_h = [&](int buf, auto hc, auto&& between) {
         constexpr int H = decltype(hc)::value;
         constexpr int NITEM = KS == 2 ? (CPS * NTAP + 1 - H) / 2 : CPS * NTAP;     // pairs H, H + 2, ...
         const char* ab = smem + buf * STAGE + a_off;
@@ -686,13 +687,31 @@ __device__ __forceinline__ void conv_body_x3p(const ssr_conv_desc& d) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k & 1][0], fb[k & 1][t][1], acc[t], 0, 0, 0);   // a_hi * b_lo
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k & 1][0], fb[k & 1][t][0], acc[t], 0, 0, 0);   // a_hi * b_hi
             }
+            __builtin_amdgcn_sched_barrier(0);
+            between(kc, std::integral_constant<int, NITEM>{});
         });
         __builtin_amdgcn_sched_barrier(0);
     };
     const int kh_s = __builtin_amdgcn_readfirstlane(kh);
-    auto contract = [&](int buf) {
-        if (KS == 2 && kh_s == 1) contract_h(buf, std::integral_constant<int, 1>{});
-        else contract_h(buf, std::integral_constant<int, 0>{});
+    // The next stage's LDS store (split of the staged fp32 patch vectors + the writes) rides INSIDE the MFMA stream of this stage,
+    // one or two vectors behind each (chunk, tap) pair: as a phase of its own it cost 1.2 k of a stage's 4.7 k ticks with the matrix
+    // pipe idle (tools/x3_probe.hip, profiles/r05*_x3_probe.txt); the other LDS buffer is the target, so the stage's one barrier stays.
+    auto contract = [&](int buf, auto jn, bool store_next) {       // jn: register set that holds the next stage
+        auto none = [](auto, auto) {};
+        auto units = [&](auto kc, auto nc) {
+            constexpr int k = decltype(kc)::value, NI = decltype(nc)::value, NU = NPV + NWV, PER = (NU + NI - 1) / NI;
+            static_for<0, PER>([&](auto ec) {
+                constexpr int u = k * PER + decltype(ec)::value;
+                if constexpr (u < NU) store_unit(buf ^ 1, jn, std::integral_constant<int, u>{});
+            });
+        };
+        if (store_next) {
+            if (KS == 2 && kh_s == 1) contract_h(buf, std::integral_constant<int, 1>{}, units);
+            else contract_h(buf, std::integral_constant<int, 0>{}, units);
+        } else {
+            if (KS == 2 && kh_s == 1) contract_h(buf, std::integral_constant<int, 1>{}, none);
+            else contract_h(buf, std::integral_constant<int, 0>{}, none);
+        }
     };
 
     XPROBE(1);
@@ -706,11 +725,10 @@ __device__ __forceinline__ void conv_body_x3p(const ssr_conv_desc& d) {
             const int cur = c + j;
             if (cur < nst) {
                 load_stage(cur + PD, jc);                                  // set j held stage `cur`, which is in LDS already
-                contract(cur & 1);
+                contract(cur & 1, std::integral_constant<int, (j + 1) % PD>{}, cur + 1 < nst);
 #ifdef SSR_PROBE
-                const unsigned long long tm_ = __builtin_amdgcn_s_memtime();      // stage 0: end of the MFMAs / end of the LDS store
+                const unsigned long long tm_ = __builtin_amdgcn_s_memtime();      // stage 0: end of the MFMAs + the interleaved LDS store
 #endif
-                if (cur + 1 < nst) store_stage((cur + 1) & 1, std::integral_constant<int, (j + 1) % PD>{});
 #ifdef SSR_PROBE
                 if (threadIdx.x == 0 && cur == 0) { g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 24 + 20] = tm_; g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 24 + 21] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -799,8 +817,12 @@ int launch_conv_x3p(const ssr_conv_desc& d, hipStream_t st) {
 
 // the deep-pipeline kernel reaches its tensors through 32-bit byte offsets and takes a pipeline stage from ONE input view
 bool x3p_ok(const ssr_conv_desc& d, int cps) {
-    static const bool off = [] { const char* e = getenv("SSR_X3_PIPE"); return e && e[0] == '0'; }();
-    if (off) return false;
+    // Opt-in (SSR_X3_PIPE=1).  Measured r05b / r05d (tools/x3_probe.hip): parity-equal and NOT faster - per 32-channel stage the
+    // MFMA phase takes 2.7 k ticks for 1.7 k of MFMAs, the split + LDS store 1.2 k, the barrier 0.7 k, and neither deeper load
+    // prefetch nor riding the store inside the MFMA stream changes the sum (a wave's VALU / LDS-store work does not overlap its own
+    // MFMAs); a launch carries ~11.7 k ticks of fixed parts (set-up 1.7 k, first loads 4.8 k, reduce + epilogue 5.2 k).
+    static const bool on = [] { const char* e = getenv("SSR_X3_PIPE"); return e && e[0] == '1'; }();
+    if (!on) return false;
     const long lim = 0x7fffff00L, npx = (long)d.N * d.Hi * d.Wi * 4;
     if (npx * d.x.cs > lim || (d.x2.p && npx * d.x2.cs > lim)) return false;
     if (d.x2.p && (d.Cin % (16 * cps)) != 0) return false;
@@ -846,9 +868,18 @@ bool ssr_conv_thin_qualifies(const ssr_conv_desc& d);
 bool ssr_conv_big_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
 bool ssr_conv_big_qualifies(const ssr_conv_desc& d);
 bool ssr_conv_big_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int* rc);
+// big-tile kernel of the split-bf16 mode (conv_big_x3.hip)
+bool ssr_conv_bigx3_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
+bool ssr_conv_bigx3_qualifies(const ssr_conv_desc& d);
+bool ssr_conv_bigx3_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, int* rc);
 
 extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_S2D"); return e && e[0] == '0'; }();
+    if (dtype == SSR_F32X3) {   // split-bf16 mode: 16-channel chunks (conv_big_x3.hip)
+        static const bool offx = [] { const char* e = getenv("SSR_X3_BIGTILE"); return e && e[0] == '0'; }();
+        const int cpx = Cin / 16;
+        return !off && !offx && Cin >= 16 && (Cin % 16) == 0 && (cpx & (cpx - 1)) == 0 && (CoutPad % 64) == 0 && (Cout % 8) == 0;
+    }
     const int cpc = Cin / 32;
     return !off && dtype == SSR_BF16 && Cin >= 32 && (Cin % 32) == 0 && (cpc & (cpc - 1)) == 0 && (CoutPad % 64) == 0 && (Cout % 8) == 0;
 }
@@ -856,6 +887,7 @@ extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
+    if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
     if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
     if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
     if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
@@ -889,9 +921,12 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
             return SSR_EINVAL;
         ssr_conv_desc e = d;
         e.KH = e.KW = 2; e.stride = 1; e.pad_y = e.pad_x = 0; e.Cin = 4 * d.Cin;
+        if (d.dtype == SSR_F32X3) return ssr_conv_bigx3_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
         return ssr_conv_big_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
     }
-    if (d.dtype == SSR_F32X3) {   // fp32 storage, split-bf16 matrix math (stride-1 2x2 / 3x3); 4x4 stride 2: the exact fp32 kernel
+    if (d.dtype == SSR_F32X3) {   // fp32 storage, split-bf16 matrix math (stride-1 2x2 / 3x3); 4x4 stride 2 without s2d: the exact fp32 kernel
+        if (impl == 4) return ssr_conv_bigx3_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 0 && ssr_conv_bigx3_try(d, st, &rc, false)) return rc;
         if (d.KH == 3 && d.KW == 3 && d.stride == 1) return dispatch_tile_x3<3, 3>(d, st);
         if (d.KH == 2 && d.KW == 2 && d.stride == 1) return dispatch_tile_x3<2, 2>(d, st);
         ssr_conv_desc e = d;
@@ -984,6 +1019,10 @@ extern "C" int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream
                ds[k].Gh == ds[0].Gh && ds[k].Gw == ds[0].Gw && ds[k].CoutPad == ds[0].CoutPad && ds[k].Cin == ds[0].Cin &&
                ds[k].Cin2 == ds[0].Cin2 && ds[k].Hi == ds[0].Hi && ds[k].Wi == ds[0].Wi && ds[k].up == ds[0].up;
     static const bool off = [] { const char* e = getenv("SSR_CONV_BATCH"); return e && e[0] == '0'; }();
+    if (!off && ds[0].dtype == SSR_F32X3 && ds[0].KH == 2 && ds[0].KW == 2 && ds[0].stride == 1) {   // split-bf16 mode: the classes in one big-tile launch
+        int rcx = 0;
+        if (ssr_conv_bigx3_batch_try(ds, n, reinterpret_cast<hipStream_t>(stream), &rcx)) return rcx;
+    }
     if (same && !off) {
         for (int k = 0; k < n; ++k) {
             const ssr_conv_desc& d = ds[k];

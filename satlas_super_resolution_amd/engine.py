@@ -102,7 +102,7 @@ class ParamStore:
             s2d = bool(s.k == 4 and s.stride == 2 and s.s2d is not False and L.ssr_conv2d_s2d_ok(dtype, s.cin, s.cout, rup(s.cout, 32)))
             self.s2d[s.name] = s2d
             if s2d:
-                ck_f = 32
+                ck_f = 32 if dtype == hip.BF16 else 16     # (split-bf16 mode: 16-channel chunks, csrc/conv_big_x3.hip)
             cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck_f)
             cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck_d)
             self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)

@@ -1,0 +1,193 @@
+"""GPU parity of the split-bf16 (fp32x3) big-tile kernel, csrc/conv_big_x3.hip: 32x16-pixel x 64-channel workgroup tiles, 16-channel
+LDS chunks of [hi | lo] rows, three MFMAs per product, workgroups persistent over images, 16-byte fp32 epilogue.
+
+Every case is checked against an independent float64 torch computation of what the descriptor contract (include/ssr_hip.h,
+ssr_conv_desc) prescribes, at 1e-4 of max|ref| (the mode rounds a product at 2^-16: ~1e-5 per layer) - the layers are
+nn.Conv2d 3x3 / 4x4 stride 2 and their dgrads of /root/reference/ssr/archs/discriminator_arch.py:28-40,45-69 and
+rrdbnet_arch.py:109-112,127-136."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _mods():
+    from satlas_super_resolution_amd import engine, hip
+    return engine, hip
+
+
+def _nchw(t, c):
+    return t.double().cpu().permute(0, 3, 1, 2)[:, :c]
+
+
+def _reference(d, w, bias, xb, y_init, r1, r2, m, up=1, cin=None):
+    cout = d.Cout
+    x = _nchw(xb, w.shape[1] if cin is None else cin)
+    if up == 2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    acc = F.conv2d(x, w.double(), None if bias is None else bias.double(), padding=1)
+    v = F.leaky_relu(acc, 0.2) if d.act == 1 else acc
+    s0 = d.alpha * v
+    s1 = s0.clone()
+    if d.r1.p:
+        s1 += d.beta1 * _nchw(r1, cout)
+    if d.r2.p:
+        s1 += d.beta2 * _nchw(r2, cout)
+    if d.accumulate:
+        s1 += _nchw(y_init, cout)
+    y = s1
+    if d.m.p:
+        mm = _nchw(m, cout)
+        y = s1 * torch.where(mm > 0, torch.ones_like(mm), torch.full_like(mm, 0.2))
+    return {"y": y, "y0": s0, "y1": s1}
+
+
+VARIANTS = ["plain", "lrelu", "lrelu_r1_y0", "mask", "mask_acc", "mask_r1", "generic"]
+
+
+def _run_3x3(variant, cin, cout, H, W, B, up=1, impl=4):
+    engine, hip = _mods()
+    dt = hip.F32X3
+    torch.manual_seed(cin + cout + H + len(variant))
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    cinp = engine.rup(cin, 8)
+    Ho, Wo = H * up, W * up
+    mk = lambda h, w, c: (torch.randn(B, h, w, c, device="cuda") * 0.5).contiguous()
+    xb = mk(H, W, cinp)
+    xb[..., cin:] = 0
+    r1, r2, m, y_init = mk(Ho, Wo, cout), mk(Ho, Wo, cout), mk(Ho, Wo, cout), mk(Ho, Wo, cout)
+    y, y0, y1 = y_init.clone(), torch.zeros_like(y_init), torch.zeros_like(y_init)
+    cb = engine._ConvBuilder(st, B)
+    L = engine.Launcher()
+    kw = dict(act=hip.ACT_LRELU if variant in ("lrelu", "lrelu_r1_y0", "generic") else hip.ACT_NONE, cin=cinp, up=up)
+    if variant in ("mask_r1", "lrelu_r1_y0", "generic"):
+        kw.update(r1=hip.view(r1), r1_nc=cout, beta1=0.5)
+    if variant == "lrelu_r1_y0":
+        kw.update(y0=hip.view(y0))
+    if variant == "generic":
+        kw.update(alpha=0.7, y0=hip.view(y0), r2=hip.view(r2), r2_nc=cout, beta2=-0.25)
+    d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(y), **kw)
+    if variant.startswith("mask") or variant == "generic":
+        d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+    if variant in ("mask_acc", "generic"):
+        d.accumulate = 1
+    if variant == "generic":
+        d.y1 = hip.view(y1)
+    hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+    torch.cuda.synchronize()
+    ref = _reference(d, st.tensor("c.weight").cpu(), st.tensor("c.bias").cpu(), xb, y_init, r1, r2, m, up, cin=cin)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2).double(), ref["y"]) < TOL, (variant, "y", rel_err(y.cpu().permute(0, 3, 1, 2).double(), ref["y"]))
+    if variant in ("lrelu_r1_y0", "generic"):
+        assert rel_err(y0.cpu().permute(0, 3, 1, 2).double(), ref["y0"]) < TOL, (variant, "y0")
+    if variant == "generic":
+        assert rel_err(y1.cpu().permute(0, 3, 1, 2).double(), ref["y1"]) < TOL, (variant, "y1")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("cin,cout,H,W,B", [(128, 64, 32, 32, 2), (96, 128, 37, 21, 1), (64, 64, 16, 48, 1), (3, 64, 40, 24, 2), (24, 64, 33, 17, 1)])
+def test_big_tile_x3_conv(variant, cin, cout, H, W, B):
+    """every epilogue feature, ragged sizes, input widths that do not fill a 16-channel chunk (3 -> 8, 24)"""
+    _run_3x3(variant, cin, cout, H, W, B)
+
+
+def test_big_tile_x3_nearest_x2_read_and_automatic_choice():
+    """conv_up1 / conv_up2 read their input through the nearest x2 view (rrdbnet_arch.py:127-128); a grid that fills half the chip
+    picks the big tile by itself (ssr_conv2d_variant digit 9), the generator's 32 x 32 body does not"""
+    engine, hip = _mods()
+    _run_3x3("lrelu", 64, 64, 16, 24, 2, up=2)
+    _run_3x3("lrelu", 64, 64, 64, 64, 8, up=1, impl=0)
+    st = engine.ParamStore([engine.ConvSpec("a", 64, 64, 3, 1, True, False), engine.ConvSpec("b", 64, 192, 3, 1, True, False)], hip.F32X3)
+    cb = engine._ConvBuilder(st, 32)
+    L = engine.Launcher()
+    big = torch.zeros(32, 128, 128, 64, device="cuda")
+    d1 = cb.conv(L, "a", hip.view(big), 128, 128, hip.view(big.clone()))
+    body_in, body_out = torch.zeros(32, 32, 32, 192, device="cuda"), torch.zeros(32, 32, 32, 64, device="cuda")
+    d2 = cb.conv(L, "b", hip.view(body_in), 32, 32, hip.view(body_out))
+    assert hip.lib().ssr_conv2d_variant(C.byref(d1)) % 10 == 9 and hip.lib().ssr_conv2d_variant(C.byref(d2)) % 10 != 9
+
+
+@pytest.mark.parametrize("groups", ["1", "2"])
+def test_big_tile_x3_persistent_over_images(groups, monkeypatch):
+    """B = 3 with one / two image groups per tile position: the chunk stream crosses image boundaries (in-stream epilogue with the
+    next image's first chunk already in LDS), single-chunk images included"""
+    monkeypatch.setenv("SSR_CONV_BIG_G", groups)
+    for variant in ("plain", "lrelu_r1_y0", "mask_acc", "generic"):
+        _run_3x3(variant, 128, 64, 32, 32, 3)
+    _run_3x3("lrelu", 16, 64, 37, 21, 3)          # a single chunk per image
+    _run_3x3("lrelu", 8, 64, 20, 20, 3)
+    test_stride2_dgrad_x3_parity_classes(128, 64, 32, 32, 3, monkeypatch)
+    test_stride2_forward_x3_space_to_depth(64, 128, 32, 32, 3)
+    test_stride2_forward_x3_space_to_depth(16, 64, 66, 34, 3)      # one chunk per parity class
+
+
+@pytest.mark.parametrize("cout,cin,gh,gw,B", [(128, 64, 32, 32, 2), (64, 64, 20, 24, 1), (256, 128, 16, 16, 1)])
+def test_stride2_dgrad_x3_parity_classes(cout, cin, gh, gw, B, monkeypatch):
+    """dgrad of a 4x4 stride-2 conv (discriminator_arch.py:31-33) = four 2x2 parity-class convs: each class forced onto the big-tile
+    kernel, and all four in ONE launch through ssr_conv2d_batch, against torch's conv_transpose2d in float64 with the step's
+    epilogue (residual + LeakyReLU-backward mask)"""
+    engine, hip = _mods()
+    dt = hip.F32X3
+    torch.manual_seed(cout + cin + gh)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 4, 2, False, True)], dt)
+    w = torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5)
+    st.load_state_dict({"c.weight_orig": w, "c.weight_u": torch.randn(cout), "c.weight_v": torch.randn(cin * 16)})
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    sigma = float(st.sigma[0])
+    mk = lambda h, ww, c: (torch.randn(B, h, ww, c, device="cuda") * 0.5).contiguous()
+    dy, r1, m = mk(gh, gw, cout), mk(2 * gh, 2 * gw, cin), mk(2 * gh, 2 * gw, cin)
+    ref = F.conv_transpose2d(_nchw(dy, cout), (w / sigma).double(), stride=2, padding=1) + _nchw(r1, cin)
+    mm = _nchw(m, cin)
+    ref = ref * torch.where(mm > 0, torch.ones_like(mm), torch.full_like(mm, 0.2))
+    for mode in ("big_each", "big_batch"):
+        y = torch.zeros(B, 2 * gh, 2 * gw, cin, device="cuda")
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        cb.dgrad(L, "c", hip.view(dy), gh, gw, hip.view(y), r1=hip.view(r1), r1_nc=cin, beta1=1.0, m=hip.view(m), m_c0=0, m_c1=cin)
+        fn, args, _ = L.calls[0]
+        arr, n = args[0], args[1]
+        if mode == "big_batch":
+            monkeypatch.setenv("SSR_X3_BIGTILE2", "2")
+            hip.check(hip.lib().ssr_conv2d_batch(arr, n, hip.stream_ptr()), "batch")
+            monkeypatch.delenv("SSR_X3_BIGTILE2")
+        else:
+            for k in range(n):
+                hip.check(hip.lib().ssr_conv2d_impl(C.byref(arr[k]), hip.stream_ptr(), 4), mode)
+        torch.cuda.synchronize()
+        e = rel_err(y.cpu().permute(0, 3, 1, 2).double(), ref)
+        assert e < TOL, (mode, e)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 32, 32, 2), (128, 256, 24, 40, 1), (256, 512, 16, 16, 2), (16, 64, 66, 34, 1)])
+def test_stride2_forward_x3_space_to_depth(cin, cout, H, W, B):
+    """4x4 stride-2 spectral-norm conv + LeakyReLU (discriminator_arch.py:31-33,45-47) through ssr_conv_desc.s2d in the split mode: a
+    2x2 conv over a space-to-depth view gathered by the staging loads, weights packed in that order in 16-channel chunks"""
+    engine, hip = _mods()
+    dt = hip.F32X3
+    torch.manual_seed(cin + cout + H)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 4, 2, False, True)], dt)
+    assert st.s2d["c"], "shape should qualify for the space-to-depth path"
+    w = torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5)
+    st.load_state_dict({"c.weight_orig": w, "c.weight_u": torch.randn(cout), "c.weight_v": torch.randn(cin * 16)})
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    sigma = float(st.sigma[0])
+    xb = (torch.randn(B, H, W, cin, device="cuda") * 0.5).contiguous()
+    yb = torch.zeros(B, H // 2, W // 2, cout, device="cuda")
+    cb = engine._ConvBuilder(st, B)
+    L = engine.Launcher()
+    d = cb.conv(L, "c", hip.view(xb), H, W, hip.view(yb), act=hip.ACT_LRELU)
+    assert d.s2d == 1 and hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 9
+    L.run()
+    torch.cuda.synchronize()
+    yr = F.leaky_relu(F.conv2d(_nchw(xb, cin), (w / sigma).double(), None, stride=2, padding=1), 0.2)
+    e = rel_err(yb.cpu().permute(0, 3, 1, 2).double(), yr)
+    assert e < TOL, e

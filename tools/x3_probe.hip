@@ -19,6 +19,9 @@ bool ssr_conv_thin_qualifies(const ssr_conv_desc&) { return false; }
 bool ssr_conv_big_try(const ssr_conv_desc&, hipStream_t, int*, bool) { return false; }
 bool ssr_conv_big_qualifies(const ssr_conv_desc&) { return false; }
 bool ssr_conv_big_batch_try(const ssr_conv_desc*, int, hipStream_t, int*) { return false; }
+bool ssr_conv_bigx3_try(const ssr_conv_desc&, hipStream_t, int*, bool) { return false; }
+bool ssr_conv_bigx3_qualifies(const ssr_conv_desc&) { return false; }
+bool ssr_conv_bigx3_batch_try(const ssr_conv_desc*, int, hipStream_t, int*) { return false; }
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 32, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = argc > 3 ? atoi(argv[3]) : 32;

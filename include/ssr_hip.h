@@ -128,7 +128,8 @@ int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream);
 /* test / tuning hook: force a kernel family. 0 = automatic (ssr_conv2d), 1 = weight-stationary persistent
  * kernel (SSR_EUNSUP if the descriptor does not fit it), 2 = skip it (K-resident or pipelined kernel),
  * 3 = pipelined kernel only, 4 = big-tile kernel (32x16 pixels x 64 channels per workgroup; SSR_EUNSUP if unfit),
- * 5 = thin-output VALU kernel (Cout <= 8, Cin <= 64; SSR_EUNSUP if unfit). */
+ * 5 = thin-output VALU kernel (Cout <= 8, Cin <= 64; SSR_EUNSUP if unfit).  SSR_F32X3 descriptors: 4 = the split-mode big-tile
+ * kernel (csrc/conv_big_x3.hip), 6 = the producer / MFMA-wave ring kernel for small grids (csrc/conv_x3q.hip). */
 int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
 /* Which kernel instantiation ssr_conv2d dispatches this descriptor to, encoded as
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);

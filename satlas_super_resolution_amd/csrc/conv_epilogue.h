@@ -16,7 +16,11 @@
 
 constexpr int EPI_STAGE_BYTES = 32 * 32 * 4;   // wave-private LDS slab (fp32 worst case)
 
-template <typename T>
+// column of pixel slot pi (0..31) of a wave's 2 x 16-pixel tile.  ROT != 0 (csrc/conv_x3q.hip): the second row is rotated by ROT
+// columns, so that the LDS rows a 16-lane read group touches are distinct mod 16 for every tap (conflict-free operand reads)
+template <int ROT> __device__ __forceinline__ int epi_col(int pi) { return ROT ? ((pi & 15) + (pi >= 16 ? ROT : 0)) & 15 : (pi & 15); }
+
+template <typename T, int ROT = 0>
 __device__ __forceinline__ void conv_epilogue(const ssr_conv_desc& d, const f32x16& acc, int co_base, int n,
                                               int gy_row0, int gx0, int lane, char* stage) {
     constexpr int VEC = DT<T>::VEC;
@@ -38,7 +42,7 @@ __device__ __forceinline__ void conv_epilogue(const ssr_conv_desc& d, const f32x
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int pi = mfma32_row(r, g);
-        const int gy = gy_row0 + (pi >> 4), gx = gx0 + (pi & 15);
+        const int gy = gy_row0 + (pi >> 4), gx = gx0 + epi_col<ROT>(pi);
         const int cy = gy < d.Gh ? gy : d.Gh - 1, cx = gx < d.Gw ? gx : d.Gw - 1;
         pc[r] = (n * d.Ho + cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;
         po[r] = (gy < d.Gh && gx < d.Gw) ? pc[r] : -1;
@@ -104,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ssr_conv_desc& d, const f32x
         for (int h = 0; h < NV; ++h) {
             const int v = h * 64 + lane;
             const int pix = v / PARTS, part = v - pix * PARTS;
-            const int gy = gy_row0 + (pix >> 4), gx = gx0 + (pix & 15);
+            const int gy = gy_row0 + (pix >> 4), gx = gx0 + epi_col<ROT>(pix);
             const int c = co_base + part * VEC;
             const u32x4 val = *reinterpret_cast<const u32x4*>(sl + pix * 32 + part * VEC);
             if (gy < d.Gh && gx < d.Gw && c < d.Cout) {

@@ -191,3 +191,55 @@ def test_stride2_forward_x3_space_to_depth(cin, cout, H, W, B):
     yr = F.leaky_relu(F.conv2d(_nchw(xb, cin), (w / sigma).double(), None, stride=2, padding=1), 0.2)
     e = rel_err(yb.cpu().permute(0, 3, 1, 2).double(), yr)
     assert e < TOL, e
+
+
+# ---- the producer / MFMA-wave ring kernel of the small grids (csrc/conv_x3q.hip), forced through ssr_conv2d_impl(impl = 6) ----
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_r1", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 32, 32, 2), (160, 32, 32, 32, 1), (192, 64, 32, 32, 2), (96, 32, 21, 37, 1), (24, 64, 9, 7, 1),
+                                            (16, 32, 8, 16, 3), (128, 96, 16, 40, 1)])
+def test_ring_x3_conv(variant, cin, cout, H, W, B):
+    """every epilogue feature, the dense block's widths (4 .. 12 chunks: the ring wraps up to three times), ragged tiles, a single
+    chunk (no refill), three 32-channel output groups"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=6)
+
+
+@pytest.mark.parametrize("c1,c2,cout", [(96, 64, 32), (32, 64, 32), (128, 64, 64), (16, 64, 32)])
+def test_ring_x3_conv_two_input_views(c1, c2, cout):
+    """the gather form of the dense-block backward contracts over the channel concatenation [x | x2] of two buffers
+    (engine.gather_dgrad): a 16-channel chunk comes from one view, the switch happens between chunks"""
+    engine, hip = _mods()
+    B, H, W = 2, 32, 32
+    torch.manual_seed(c1 + c2 + cout)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, c1 + c2, 3, 1, True, False)], hip.F32X3)
+    w = torch.randn(cout, c1 + c2, 3, 3) * (1.0 / ((c1 + c2) * 9) ** 0.5)
+    st.load_state_dict({"c.weight": w, "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    mk = lambda c: (torch.randn(B, H, W, c, device="cuda") * 0.5).contiguous()
+    big1, big2 = mk(192), mk(64)                      # views into wider buffers, as in the step
+    x1, x2 = hip.view(big1, 32), hip.view(big2, 0)
+    m = mk(cout)
+    for impl in (6, 3):
+        y = torch.zeros(B, H, W, cout, device="cuda")
+        cb = engine._ConvBuilder(st, B)
+        L = engine.Launcher()
+        d = cb.conv(L, "c", x1, H, W, hip.view(y), cin=c1)
+        d.x2, d.Cin2 = x2, c2
+        d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), impl), f"impl {impl}")
+        torch.cuda.synchronize()
+        x = torch.cat([_nchw(big1, 192)[:, 32:32 + c1], _nchw(big2, c2)], 1)
+        ref = F.conv2d(x, w.double(), st.tensor("c.bias").cpu().double(), padding=1)
+        mm = _nchw(m, cout)
+        ref = ref * torch.where(mm > 0, torch.ones_like(mm), torch.full_like(mm, 0.2))
+        e = rel_err(y.cpu().permute(0, 3, 1, 2).double(), ref)
+        assert e < TOL, (impl, e)
+
+
+def test_ring_x3_is_the_automatic_choice_for_the_body():
+    engine, hip = _mods()
+    st = engine.ParamStore([engine.ConvSpec("b", 32, 160, 3, 1, True, False)], hip.F32X3)
+    cb = engine._ConvBuilder(st, 32)
+    L = engine.Launcher()
+    buf = torch.zeros(32, 32, 32, 192, device="cuda")
+    d = cb.conv(L, "b", hip.view(buf, 0), 32, 32, hip.view(buf, 160), act=hip.ACT_LRELU, cin=160)
+    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 6

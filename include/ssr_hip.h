@@ -378,6 +378,15 @@ int ssr_relu_maxpool2_bwd(ssr_view f, ssr_view gp, ssr_view gf, int32_t dtype, i
 /* SSR_F32X3 weight gradients: split an fp32 buffer (n % 4 == 0 elements) into bf16 planes hi = bf16(x), lo = bf16(x - hi); the
  * bf16 wgrad kernel then accumulates (x_hi, dy_hi) + (x_hi, dy_lo) + (x_lo, dy_hi) into the fp32 gradient. */
 int ssr_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
+/* the same for a device table of buffers in ONE launch (every n % 8 == 0, 16-byte aligned pointers; max_n = the largest n): what
+ * engine.WgradBatch issues in front of the three split passes of a batch */
+typedef struct ssr_split_item {
+    const float* x;
+    void* hi;
+    void* lo;
+    int64_t n;
+} ssr_split_item;
+int ssr_split_bf16_multi(const ssr_split_item* items_dev, int32_t n_items, int64_t max_n, void* stream);
 
 /* library / device info: writes "gfx950 CUs=256 ..." style text */
 int ssr_device_info(char* buf, int32_t buflen);

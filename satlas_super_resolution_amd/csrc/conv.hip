@@ -891,7 +891,8 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
     if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
-    if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 6;     // digit 6 = producer / MFMA-wave ring
+    if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
+        return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
     if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
     if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
     if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile

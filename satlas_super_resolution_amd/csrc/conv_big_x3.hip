@@ -415,8 +415,12 @@ bool ssr_conv_bigx3_shape_ok(const ssr_conv_desc& d) {
 bool ssr_conv_bigx3_qualifies(const ssr_conv_desc& d) {
     static const bool off = [] { const char* e = getenv("SSR_X3_BIGTILE"); return e && e[0] == '0'; }();
     if (off || !ssr_conv_bigx3_shape_ok(d) || d.KH != 3) return false;
-    const long wgs = (long)d.N * ((d.Gh + XB_TH - 1) / XB_TH) * ((d.Gw + XB_TW - 1) / XB_TW) * (d.CoutPad / 64);
-    return wgs >= 128 && d.Gh >= 24;                          // at least half the CUs get a 512-pixel tile, and the 32-row tiles are not half empty
+    // The choice depends on the LAYER only, never on the batch: an image's result must not depend on how many images are launched
+    // together (whole-tile inference deals chunks to ranks and batches; a last partial batch on another kernel would change bytes -
+    // tests/test_gpu_baseline_shapes.py::test_infer_grid_tile_end_to_end_vs_oracle).  >= 4 tile x channel-group workgroups per image
+    // (64 x 64 grids and up, or >= 256 output channels at 32 x 32), 32-row tiles not half empty; the 32 x 32 body goes to conv_x3q.hip.
+    const long per_img = (long)((d.Gh + XB_TH - 1) / XB_TH) * ((d.Gw + XB_TW - 1) / XB_TW) * (d.CoutPad / 64);
+    return per_img >= 4 && d.Gh >= 24;
 }
 
 bool ssr_conv_bigx3_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
@@ -437,8 +441,8 @@ bool ssr_conv_bigx3_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, in
         if (ds[k].N != d.N || ds[k].Gh != d.Gh || ds[k].Gw != d.Gw || ds[k].CoutPad != d.CoutPad || ds[k].Cin != d.Cin || ds[k].Hi != d.Hi || ds[k].Wi != d.Wi ||
             ds[k].up != d.up)
             return false;
-    const long wgs = (long)d.N * ((d.Gh + XB_TH - 1) / XB_TH) * ((d.Gw + XB_TW - 1) / XB_TW) * (d.CoutPad / 64) * n;
-    if (!always && (wgs < 192 || d.Gh < 24)) return false;   // small grids / half-empty 32-row tiles: pipelined kernel
+    const long per_img = (long)((d.Gh + XB_TH - 1) / XB_TH) * ((d.Gw + XB_TW - 1) / XB_TW) * (d.CoutPad / 64) * n;
+    if (!always && (per_img < 8 || d.Gh < 24)) return false;  // small grids / half-empty 32-row tiles: pipelined kernel (batch-independent rule)
     *rc = launch_bigx3<2>(ds, n, st);
     return true;
 }

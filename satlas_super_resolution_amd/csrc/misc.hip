@@ -1089,4 +1089,37 @@ extern "C" int ssr_split_bf16(const float* x, void* hi, void* lo, int64_t n, voi
     return SSR_OK;
 }
 
+// all the buffers of a weight-gradient batch in ONE launch (round 5: the fp32x3 step issued 190 split launches of ~17 us - 3.2 ms -
+// each a grid-stride loop of 16-byte loads and 8-byte stores at 3 TB/s): blockIdx.y = buffer, a thread moves 8 floats (two 16-byte
+// loads -> one 16-byte store per plane)
+namespace {
+__global__ __launch_bounds__(256) void split_bf16_multi_kernel(const ssr_split_item* __restrict__ items) {
+    const ssr_split_item it = items[blockIdx.y];
+    const long n8 = it.n >> 3;
+    const f32x4* __restrict__ x = reinterpret_cast<const f32x4*>(it.x);
+    u32x4* __restrict__ hi = reinterpret_cast<u32x4*>(it.hi);
+    u32x4* __restrict__ lo = reinterpret_cast<u32x4*>(it.lo);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+        const f32x4 v0 = x[2 * e], v1 = x[2 * e + 1];
+        bf16x8 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (__bf16)v0[k];
+            l[k] = (__bf16)(v0[k] - (float)h[k]);
+            h[4 + k] = (__bf16)v1[k];
+            l[4 + k] = (__bf16)(v1[k] - (float)h[4 + k]);
+        }
+        hi[e] = __builtin_bit_cast(u32x4, h);
+        lo[e] = __builtin_bit_cast(u32x4, l);
+    }
+}
+}  // namespace
+
+extern "C" int ssr_split_bf16_multi(const ssr_split_item* items_dev, int32_t n_items, int64_t max_n, void* stream) {
+    if (!items_dev || n_items <= 0 || max_n <= 0) return SSR_EINVAL;
+    hipLaunchKernelGGL(split_bf16_multi_kernel, dim3(grid_for(max_n / 8, 256, 2048), n_items), dim3(256), 0, ST(stream), items_dev);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
 extern "C" int ssr_abi_version(void) { return 2; }

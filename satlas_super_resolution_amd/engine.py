@@ -255,7 +255,7 @@ class ParamStore:
         if self.sn_names:
             hip.check(hip.lib().ssr_spectral_norm_bwd(self.sn_bwd_table.data_ptr(), len(self.sn_names),
                                                       self.sn_max_elems, hip.stream_ptr()), "ssr_spectral_norm_bwd")
-            self.grad_sn.zero_()
+            hip.check(hip.lib().ssr_fill(self.grad_sn.data_ptr(), self.grad_sn.numel(), hip.F32, 0.0, hip.stream_ptr()), "ssr_fill")
 
 
 class Launcher:
@@ -511,6 +511,7 @@ class WgradBatch:
         self.items: List[WgradItem] = []
         self.layer_tab = self.item_tab = None
         self.split_tabs: List[torch.Tensor] = []
+        self.split_tab = None
         self.splits: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
         # deterministic mode: a layer that is split over pixel ranges gets one layer-table entry PER SPLIT whose dw / db point
         # at a partial buffer of that split alone (one writer per gradient element and launch); ssr_wgrad_reduce then adds the
@@ -711,8 +712,14 @@ class WgradBatch:
 
     def _launch_wgrad(self, L: Launcher, lib):
         if self.dtype == hip.F32X3:
-            for parent, hi_t, lo_t in self.splits:
-                L.add(lib.ssr_split_bf16, parent.data_ptr(), hi_t.data_ptr(), lo_t.data_ptr(), parent.numel(), what="split bf16")
+            if all(p.numel() % 8 == 0 for p, _, _ in self.splits):          # every buffer of the batch in ONE launch (ssr_split_bf16_multi)
+                if self.split_tab is None:
+                    self.split_tab = hip.device_table([hip.SplitItem(p.data_ptr(), h.data_ptr(), l.data_ptr(), p.numel()) for p, h, l in self.splits])
+                L.add(lib.ssr_split_bf16_multi, self.split_tab.data_ptr(), len(self.splits), max(p.numel() for p, _, _ in self.splits),
+                      what="split bf16")
+            else:
+                for parent, hi_t, lo_t in self.splits:
+                    L.add(lib.ssr_split_bf16, parent.data_ptr(), hi_t.data_ptr(), lo_t.data_ptr(), parent.numel(), what="split bf16")
             for tab in self.split_tabs:
                 L.add(lib.ssr_conv2d_wgrad, tab.data_ptr(), self.item_tab.data_ptr(), len(self.items), hip.BF16, self.k, self.k,
                       self.stride, what="wgrad batch (split pass)")

@@ -106,6 +106,10 @@ class ReduceItem(C.Structure):
                 ("pad_", C.c_int32)]
 
 
+class SplitItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("n", C.c_int64)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("ema", C.c_void_p), ("n", C.c_int64), ("lr", C.c_void_p), ("step", C.c_void_p),
@@ -118,7 +122,7 @@ ABI_SYMBOLS = [
     "ssr_conv2d", "ssr_conv2d_fixup", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
-    "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
+    "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_split_bf16_multi", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
     "ssr_device_info", "ssr_abi_version",
 ]
 
@@ -175,6 +179,7 @@ def lib() -> C.CDLL:
     l.ssr_metric_shift_sums.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     l.ssr_metric_ssim_sums.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     l.ssr_split_bf16.argtypes = [vp, vp, vp, i64, vp]
+    l.ssr_split_bf16_multi.argtypes = [vp, i32, i64, vp]
     l.ssr_channel_affine.argtypes = [View, View, i32, i64, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp]
     l.ssr_relu_maxpool2_fwd.argtypes = [View, View, i32, i32, i32, i32, i32, vp]
     l.ssr_relu_maxpool2_bwd.argtypes = [View, View, View, i32, i32, i32, i32, i32, i32, vp]

@@ -221,6 +221,11 @@ class ESRGANTrainStep:
                                              hip.View(buf.data_ptr(), buf.shape[-1], coff), self.dt, 1, 1, scale, st), "old_hr")
 
     # ------------------------------------------------------------------ phases
+    @staticmethod
+    def _zero(t: torch.Tensor):
+        """fp32 arena <- 0 by the library's own fill kernel: no ATen launch inside the (captured) step"""
+        hip.check(hip.lib().ssr_fill(t.data_ptr(), t.numel(), hip.F32, 0.0, hip.stream_ptr()), "ssr_fill")
+
     def _bce(self, target, weight, loss_idx, mean_idx, with_grad=True, plan=None):
         d = plan or self.d_plan
         lp, ls = self.losses.data_ptr(), 4 * self.loss_stride
@@ -236,8 +241,8 @@ class ESRGANTrainStep:
 
     def _phase_g(self, run_bwd: bool = True):
         cfg = self.cfg
-        self.g_store.grad.zero_()
-        self.losses.zero_()
+        self._zero(self.g_store.grad)
+        self._zero(self.losses)
         self.g_store.pack()
         self.g_plan.fwd.run()                                              # :140
         hip.check(hip.lib().ssr_l1_loss(view(self.fake_in), view(self.l1_tgt), view(self.grad_l1), self.loss_dt,
@@ -256,14 +261,14 @@ class ESRGANTrainStep:
 
     def _phase_g_skipped(self):
         """current_iter fails the gate at :144: only the forward runs (self.output is still needed)."""
-        self.losses.zero_()
+        self._zero(self.losses)
         self.g_store.pack()
         self.g_plan.fwd.run()
 
     def _phase_d(self):
         cfg = self.cfg
-        self.d_store.grad.zero_()                                          # optimizer_d.zero_grad() :215
-        self.d_store.grad_sn.zero_()
+        self._zero(self.d_store.grad)                                      # optimizer_d.zero_grad() :215
+        self._zero(self.d_store.grad_sn)
         self._d_forward(self.real_in)                                      # :217
         self._bce(cfg.real_label, 1.0, 2, 3)                               # :218-220
         self.d_plan.backward_plan(self.real_in, param_grads=True, input_grad=False).run()   # :221

@@ -30,6 +30,8 @@ def test_struct_layouts_match_header():
     """ctypes mirrors must have the C layout (sizes computed from the header's field lists)."""
     from satlas_super_resolution_amd import hip
     assert ctypes.sizeof(hip.View) == 16
+    assert ctypes.sizeof(hip.SplitItem) == 32                        # ssr_split_item: three pointers + int64
+    assert hip.lib().ssr_split_bf16_multi(None, 0, 0, None) == -1
     # ssr_conv_desc: verified against the C compiler's sizeof through the descriptor validation path:
     d = hip.ConvDesc()
     assert hip.lib().ssr_conv2d(ctypes.byref(d), None) == -1          # all-zero descriptor -> SSR_EINVAL, no launch

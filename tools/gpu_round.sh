@@ -1,8 +1,8 @@
 #!/bin/bash
-# One GPU-box visit: the whole -m gpu suite, HBM-traffic PMC passes (headline mode + the parity legs), the default bench line (which
-# then carries roofline.traffic for this very build), rocprofv3 kernel stats (overlapped and serial), SQ/GRBM counters, and the
-# other BASELINE.json configurations.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r04a'
+# One GPU-box visit: the whole -m gpu suite, HBM-traffic PMC passes (the headline mode fp32x3 + the bf16 / fp32 legs), the default bench
+# line (which then carries roofline.traffic for this very build), rocprofv3 kernel stats of the headline mode (overlapped and serial),
+# SQ/GRBM counters, and the other BASELINE.json configurations.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r05z'
 # Env: SKIP_TESTS=1, SKIP_TRAFFIC=1, SKIP_LEG_TRAFFIC=1, SKIP_PROF=1, SKIP_CONFIGS=1, PYTEST_ARGS, BENCH_ARGS
 TAG=${1:-run}
 R=$(pwd)
@@ -10,7 +10,7 @@ O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 PYT="python -m pytest -q -p no:cacheprovider"
-PMC_BENCH="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode"
+PMC_BENCH="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout 1500 $PYT tests -m gpu --durations=12 -s ${PYTEST_ARGS:-} > $O/${TAG}_tests.log 2>&1
   echo "pytest rc=$?" >> $O/${TAG}_tests.log
@@ -18,24 +18,25 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
   grep -E "^(FAILED|ERROR)" $O/${TAG}_tests.log | head -40
 fi
 if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then      # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one), --kernel-trace only
-  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
-  (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
-  python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic.json > /dev/null && cp $O/${TAG}_traffic.json profiles/traffic.json && python -c "
-import json; d=json.load(open('$O/${TAG}_traffic.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
+  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
+  SSR_PMC_DTYPE=fp32x3 python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic_fp32x3.json > /dev/null && cp $O/${TAG}_traffic_fp32x3.json profiles/traffic_fp32x3.json && python -c "
+import json; d=json.load(open('$O/${TAG}_traffic_fp32x3.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
 fi
 if [ "${SKIP_LEG_TRAFFIC:-0}" != "1" ]; then  # the parity legs' dominant kernels -> profiles/traffic_<dtype>.json (bench.py legs.*.roofline.traffic)
-  for DT in fp32x3 fp32; do
+  for DT in bf16 fp32; do
     (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_${TAG}_$DT -- python $R/bench.py --dtype $DT ${PMC_BENCH/--steps 2/--steps 1} > /tmp/pmcf_${TAG}_$DT.log 2>&1)
     (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_${TAG}_$DT -- python $R/bench.py --dtype $DT ${PMC_BENCH/--steps 2/--steps 1} > /tmp/pmcw_${TAG}_$DT.log 2>&1)
-    SSR_PMC_DTYPE=$DT python tools/pmc_traffic.py /tmp/pmc_fetch_${TAG}_$DT /tmp/pmc_write_${TAG}_$DT $O/${TAG}_traffic_$DT.json > /dev/null && cp $O/${TAG}_traffic_$DT.json profiles/traffic_$DT.json && echo "traffic $DT collected"
+    TJ=profiles/traffic_$DT.json; [ "$DT" = bf16 ] && TJ=profiles/traffic.json
+    SSR_PMC_DTYPE=$DT python tools/pmc_traffic.py /tmp/pmc_fetch_${TAG}_$DT /tmp/pmc_write_${TAG}_$DT $O/${TAG}_traffic_$DT.json > /dev/null && cp $O/${TAG}_traffic_$DT.json $TJ && echo "traffic $DT collected"
   done
 fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py ${BENCH_ARGS:-} > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; tail -1 $O/${TAG}_bench.json | cut -c1-1200
 if [ "${SKIP_PROF:-0}" != "1" ]; then
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/prof_$TAG.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs > /tmp/prof_$TAG.log 2>&1)
   F=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp $F $O/${TAG}_kernel_stats.csv && head -8 $F | cut -c1-160
-  (cd /tmp && SSR_OVERLAP_D=0 SSR_G_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-parity-mode > /tmp/profs_$TAG.log 2>&1)
+  (cd /tmp && SSR_OVERLAP_D=0 SSR_G_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs > /tmp/profs_$TAG.log 2>&1)
   F=$(find /tmp/profs_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp $F $O/${TAG}_kernel_stats_serial.csv
   (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY \
       --kernel-trace --output-format csv -d /tmp/pmc_$TAG -- python $R/bench.py $PMC_BENCH > /tmp/pmc_$TAG.log 2>&1)
@@ -43,10 +44,10 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
 fi
 if [ "${SKIP_CONFIGS:-0}" != "1" ]; then      # the other BASELINE.json configurations on this build, one JSON line each
   : > $O/${TAG}_bench_configs.jsonl
-  for ARGS in "--frames 1 --batch 16" "--frames 32 --batch 16" "--feed-disc-lr" "--perceptual" "--dtype fp32x3 --no-parity-mode" "--dtype fp32 --no-parity-mode"; do
-    SSR_VGG19_RANDOM=1 python bench.py $ARGS --no-cpu-baseline --no-parity-mode 2>/dev/null | tail -1 >> $O/${TAG}_bench_configs.jsonl
+  for ARGS in "--frames 1 --batch 16" "--frames 32 --batch 16" "--feed-disc-lr" "--perceptual" "--dtype bf16" "--dtype bf16 --frames 1 --batch 16" "--dtype bf16 --frames 32 --batch 16" "--dtype fp32"; do
+    SSR_VGG19_RANDOM=1 python bench.py $ARGS --no-cpu-baseline --no-legs 2>/dev/null | tail -1 >> $O/${TAG}_bench_configs.jsonl
   done
-  SSR_DETERMINISTIC=1 python bench.py --no-cpu-baseline --no-parity-mode 2>/dev/null | tail -1 | python -c "
+  SSR_DETERMINISTIC=1 python bench.py --no-cpu-baseline --no-legs 2>/dev/null | tail -1 | python -c "
 import sys, json; d = json.loads(sys.stdin.read()); d['config']['deterministic'] = True; print(json.dumps(d))" >> $O/${TAG}_bench_configs.jsonl
   python -c "
 import json

@@ -23,6 +23,10 @@ def symbol(name: str):
     import re
     m = re.search(r"conv_x3_kernel<(\d), \d, (\d), (\d), \d>", name)        # <KH, KW, NT, MW, KS>: bench.py's conv_kernel<fp32x3,K..,S1,NT..,W..>
     if m: return f"conv_kernel<fp32x3,K{m.group(1)},S1,NT{m.group(2)},W{m.group(3)}>"
+    m = re.search(r"conv_x3q_kernel<(\d)>", name)                             # the ring kernel of the fp32x3 body: <NT>
+    if m: return f"conv_kernel<fp32x3,K3,S1,NT{m.group(1)},W6>"
+    if re.search(r"conv_bigx3_kernel4<3>", name): return "conv_kernel<fp32x3,K3,S1,NT2,W9>"      # the fp32x3 big-tile kernel, 3x3 layers
+    if re.search(r"conv_bigx3_kernel4<2>", name): return "conv_bigx3_kernel4<2>"                 # (2x2: parity classes and s2d forward share it)
     m = re.search(r"wgrad_kernel<float, (\d),", name)
     if m: return f"wgrad_kernel<fp32,K{m.group(1)}>"
     if "conv_big_kernel" in name: return "conv_big_kernel"

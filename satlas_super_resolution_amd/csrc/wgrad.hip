@@ -150,6 +150,9 @@ int dispatch_wgrad(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, i
 // bf16: transpose-read MFMA kernel (wgrad_bf16.hip)
 int ssr_wgrad_bf16_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW,
                             int S, hipStream_t st);
+// fp32x3, 3x3 stride 1: fp32 tiles split on the way into LDS, three products per fragment pair (wgrad_x3.hip)
+int ssr_wgrad_x3_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW, int S,
+                          hipStream_t st);
 
 extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH) {
     const int th = dtype == SSR_BF16 ? wgrad_bf16_th(KH) : WG_TH;
@@ -157,8 +160,8 @@ extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dt
 }
 
 // width of the input-channel tile of one work item (host helper for building items)
-extern "C" int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH) { return (dtype == SSR_BF16 && KH == 3) ? 64 : 32; }
-extern "C" int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH) { return (dtype == SSR_BF16 && KH == 3) ? 64 : 32; }
+extern "C" int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH) { return ((dtype == SSR_BF16 || dtype == SSR_F32X3) && KH == 3) ? 64 : 32; }
+extern "C" int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH) { return ((dtype == SSR_BF16 || dtype == SSR_F32X3) && KH == 3) ? 64 : 32; }
 
 extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
                                 int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream) {
@@ -166,5 +169,6 @@ extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgr
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SSR_F32) return dispatch_wgrad<float>(layers_dev, items_dev, n_items, KH, KW, stride, st);
     if (dtype == SSR_BF16) return ssr_wgrad_bf16_dispatch(layers_dev, items_dev, n_items, KH, KW, stride, st);
+    if (dtype == SSR_F32X3) return ssr_wgrad_x3_dispatch(layers_dev, items_dev, n_items, KH, KW, stride, st);   // fp32 buffers
     return SSR_EUNSUP;
 }

@@ -1,0 +1,394 @@
+// fp32x3 (split-bf16) weight gradient of the 3x3 stride-1 layers in ONE pass over the fp32 buffers (round 5).
+//   dW[co][ci][ky][kx] += alpha * sum_pixels dY[p][co] * X[p + (ky,kx) - pad][ci]      (autograd of nn.Conv2d at
+//   /root/reference/ssr/archs/rrdbnet_arch.py:30-34,104-113 and discriminator_arch.py:28-40, executed by
+//   l_g_total.backward() / l_d_real.backward() / l_d_fake.backward(): ssr/models/ssr_esrgan_model.py:188,219,227)
+//
+// Until round 5 the mode ran `ssr_split_bf16` over every activation and gradient buffer (7 GB of HBM traffic per step, 2.8 ms) and
+// then the bf16 kernel of wgrad_bf16.hip three times over the planes (x_hi, dy_hi), (x_hi, dy_lo), (x_lo, dy_hi): 28 bytes moved
+// per (x, dy) element pair, three write-outs per item.  Here the LOADER waves read the fp32 tiles themselves (8 bytes per pair,
+// once) and split them on the way into LDS (hi = bf16(v), lo = bf16(v - hi), the same arithmetic as ssr_split_bf16); the MFMA waves
+// issue the three products of every (dY, X) fragment pair into ONE accumulator set.  Everything else is wgrad_bf16_k3_kernel's
+// design: ds_read_b64_tr_b16 transpose reads of dense [pixel][32 ch] planes, 4 loader + 4 MFMA waves, two-stage LDS ring with flag
+// hand-over, rolling three-row window of X fragments, paired items (two 32-co dY planes against one 64-ci patch), write-out
+// transposed in LDS to OIHW rows.  A stage holds hi AND lo planes, so the pixel tile is 8 x 16 instead of 16 x 16:
+//   stage = 4 dY planes [128 px][32 co] (plane A hi, lo, plane B hi, lo) + 4 X planes [10 x 18 px][32 ci] (half 0 hi, lo, half 1 hi, lo)
+//         = 78,848 B; two stages + the control words = 158,208 B of the 160 KB.
+// Per k-step (one tile row of 16 pixels) a wave reads 2 dY fragments and the 6 fragments of the new patch row for 27 MFMAs
+// (bf16 kernel: 4 reads per 9 MFMAs).
+#include "wgrad_common.h"
+
+namespace {
+
+typedef short wx_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) wx_s16x4 wx_lds_s16x4;
+typedef const __attribute__((address_space(1))) char* wx_gptr;          // global memory, explicitly: never a flat access
+
+__device__ __forceinline__ bf16x8 wx_tr_pair(const __bf16* lo, const __bf16* hi) {
+    const wx_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wx_lds_s16x4*)(lo));
+    const wx_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wx_lds_s16x4*)(hi));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ int wx_ld(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void wx_sync4(int* cnt, int& phase, int lane) {   // barrier of the four MFMA waves
+    phase += 4;
+    if (lane == 0) __atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED);
+    while (wx_ld(cnt) < phase) {}
+}
+__device__ const u32x4 g_wx_zero32[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // where the loads of lanes outside the image go
+
+#ifndef WX3_PF
+#define WX3_PF 4      // operand fragments read ahead of their MFMAs (register budget: 144 accumulators + three patch rows of hi / lo fragments)
+#endif
+struct Wx3 {
+    static constexpr int TH = 8, PH = 10, PW = 18, ROW = 32;
+    static constexpr int DYP = TH * WG_TW * 64;              // bytes of one dY plane [128 px][32 co] bf16
+    static constexpr int XP = PH * PW * 64;                  // bytes of one X plane [180 px][32 ci] bf16
+    static constexpr int XBASE = 4 * DYP;
+    static constexpr int STAGE = 4 * DYP + 4 * XP;           // 78,848 B
+    static constexpr int NDYU = TH * WG_TW * 8;              // loader units (8 fp32 channels of a pixel = 32 B): 1024 of dY (two planes)
+    static constexpr int NXU = PH * PW * 8;                  // 1440 of X (64 channels)
+    static constexpr int NLU = (NDYU + NXU + 255) / 256;     // 10 per loader thread
+    static constexpr int QDY = NDYU / 256;                   // a thread's first 4 units are dY units
+    static constexpr int NST = 2;
+    static constexpr int CTL = NST * STAGE;
+    static constexpr int LDS = CTL + 512;
+    static_assert(NDYU % 256 == 0 && NLU == 10, "operand lists of wait_tile / hold");
+    static_assert(LDS <= 160 * 1024 && 32 * 64 * 9 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
+};
+constexpr int WXC_READY = 0;    // [NST] loader waves that have stored their part of the stage's current tile
+constexpr int WXC_DONE = 8;     // [4] tiles MFMA wave w is finished with
+constexpr int WXC_SYNC = 12;    // write-out barrier counter
+constexpr int WXC_LSYNC = 13;   // loader-wave barrier counter
+constexpr int WXC_BIAS = 16;    // [64] floats: bias-gradient partial sums of the loader threads, both planes
+
+// One wave's share of a tile: NR tile rows (k-steps of 16 pixels), ONE dY plane (hi + lo), ONE 32-channel half of the X patch
+// (hi + lo), all nine taps.  Read stream: patch rows 0, 1 (3 column shifts x hi / lo = 6 fragments each), then per k-step i:
+// dY hi, dY lo, the six fragments of patch row i + 2.  The 27 MFMAs of a k-step are dealt over the eight read slots so that
+// every group runs when its newest operand is PF reads old.
+//   lap / lbp: this lane's source address in the wave's dY (X) hi plane at its first row; the lo plane is DYP (XP) bytes behind.
+template <int NR>
+__device__ __forceinline__ void wx3_rows(f32x16 (&acc)[9], const __bf16* lap, const __bf16* lbp, int* done_word, int k, int lane) {
+    constexpr int ROW = Wx3::ROW, PW = Wx3::PW;
+    constexpr int NOP = 12 + 8 * NR, PF = WX3_PF;
+    constexpr int DYLO = Wx3::DYP / 2, XLO = Wx3::XP / 2;    // bf16 elements between a hi plane and its lo plane
+    bf16x8 op[NOP];
+    auto issue = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 12) {
+            const __bf16* bp = lbp + (n & 1) * XLO + ((n / 6) * PW + (n % 6) / 2) * ROW;
+            op[n] = wx_tr_pair(bp, bp + 4 * ROW);
+        } else if constexpr ((n - 12) % 8 < 2) {
+            const __bf16* ap = lap + ((n - 12) % 8) * DYLO + ((n - 12) / 8) * WG_TW * ROW;
+            op[n] = wx_tr_pair(ap, ap + 4 * ROW);
+        } else {
+            constexpr int r = (n - 12) % 8 - 2;
+            const __bf16* bp = lbp + (r & 1) * XLO + (((n - 12) / 8 + 2) * PW + r / 2) * ROW;
+            op[n] = wx_tr_pair(bp, bp + 4 * ROW);
+        }
+    };
+    static_for<0, PF>([&](auto nc) { issue(nc); });
+    static_for<0, NOP>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
+        if constexpr (n + PF == NOP - 1) {
+            if (lane == 0) __atomic_store_n(done_word, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n >= 12) {
+            constexpr int i = (n - 12) / 8, r = (n - 12) % 8, a = 12 + 8 * i;
+            auto group = [&](auto kyc, auto kxc) {
+                constexpr int ky = decltype(kyc)::value, kx = decltype(kxc)::value, prow = i + ky;
+                constexpr int xh = prow < 2 ? prow * 6 + kx * 2 : 12 + 8 * (prow - 2) + 2 + kx * 2;
+                constexpr int t = ky * 3 + kx;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 1], op[xh], acc[t], 0, 0, 0);       // dy_lo . x_hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[xh + 1], acc[t], 0, 0, 0);       // dy_hi . x_lo
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[xh], acc[t], 0, 0, 0);           // dy_hi . x_hi
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            if constexpr (r == 1) { group(I0{}, I0{}); group(I0{}, I1{}); }
+            if constexpr (r == 2) group(I0{}, I2{});
+            if constexpr (r == 3) group(I1{}, I0{});
+            if constexpr (r == 4) group(I1{}, I1{});
+            if constexpr (r == 5) { group(I1{}, I2{}); group(I2{}, I0{}); }
+            if constexpr (r == 6) group(I2{}, I1{});
+            if constexpr (r == 7) group(I2{}, I2{});
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512) void wgrad_x3_k3_kernel(const ssr_wgrad_layer* __restrict__ layers,
+                                                          const ssr_wgrad_item* __restrict__ items) {
+    using C = Wx3;
+    constexpr int TH = C::TH, PW = C::PW, NST = C::NST, NLU = C::NLU, QDY = C::QDY;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ctl = reinterpret_cast<int*>(smem + C::CTL);
+    const ssr_wgrad_item it = items[blockIdx.x];
+    const bool pair = it.nco == 2;
+    const ssr_wgrad_layer L = layers[it.layer];
+    const ssr_wgrad_layer LB = layers[pair ? it.layer_b : it.layer];   // layer of the second dY plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
+    const int ntile = it.tile_end - it.tile_begin;
+    if (tid < 128) ctl[tid] = 0;
+    __syncthreads();   // the only barrier
+
+    if (wave >= 4) {
+        // =============================== loader waves ===============================
+        // unit u = lt + 256 q: q < 4: dY pixel (lt >> 3) + 32 q of the tile, part lt & 7 = (plane, channel octet); q >= 4: X patch
+        // pixel (lt >> 3) + 32 (q - 4), part lt & 7 = (32-channel half, octet).  A unit is 8 fp32 channels = two 16-byte loads,
+        // and becomes one 16-byte store into the hi plane and one into the lo plane.
+        const int lt = tid - 256;
+        const int upshift = L.up == 2 ? 1 : 0;
+        const int LH = L.Hi << upshift, LW = L.Wi << upshift;
+        const int hb = (lt >> 2) & 1, oct = lt & 3;
+        const ssr_view dyv = hb ? LB.dy : L.dy;
+        const int dy_co0 = hb ? it.co0_b : it.co0;
+        const bool dy_ok = (hb == 0 || pair) && dy_co0 + oct * 8 < (hb ? LB.Cout : L.Cout);
+        int yx[NLU];                                           // (y, x) relative to the tile origin; 0x7fff7fff = never inside
+#pragma unroll
+        for (int q = 0; q < NLU; ++q) {
+            if (q < QDY) {
+                const int pix = (lt >> 3) + 32 * q;
+                yx[q] = dy_ok ? ((pix >> 4) | ((pix & 15) << 16)) : 0x7fff7fff;
+            } else {
+                const int vx = lt + (q - QDY) * 256;
+                const int pix = vx >> 3, part = vx & 7;
+                const int py = pix / PW, px = pix - py * PW;
+                const int y = py - L.pad_y, x = px - L.pad_x;
+                yx[q] = (vx < C::NXU && it.ci0 + part * 8 < L.Cin) ? ((y & 0xffff) | (x << 16)) : 0x7fff7fff;
+            }
+        }
+        const int lo_dy = hb * 2 * C::DYP + (lt >> 3) * 64 + oct * 16;
+        const int lo_x = C::XBASE + hb * 2 * C::XP + (lt >> 3) * 64 + oct * 16;
+        const bool wr_dy = hb == 0 || pair;
+        const int x_c8 = (lt & 7) * 8;
+        const bool bias_a = L.db != nullptr && it.ci0 == 0, bias_b = pair && LB.db != nullptr && it.ci0 == 0;
+        const bool do_bias = hb ? bias_b : bias_a;
+        float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4 ra[2 * NLU], rb[2 * NLU];
+        // hand-issued loads, hand-waited (wgrad_bf16.hip, lesson 32): every lane loads (outside the image: a zero block), exactly
+        // one tile (2 NLU loads per lane) stays in flight across every store
+        const wx_gptr zero32 = (wx_gptr)&g_wx_zero32[0];
+        const wx_gptr dyg1 = (wx_gptr)(reinterpret_cast<const float*>(dyv.p) + dyv.coff + dy_co0);
+        const wx_gptr xg1 = (wx_gptr)reinterpret_cast<const float*>(L.x.p);
+        auto load_tile = [&](int k, u32x4 (&r)[2 * NLU]) {
+            int b = it.tile_begin + k;
+            const int tx_i = b % tiles_x; b /= tiles_x;
+            const int ty_i = b % tiles_y;
+            const int n = b / tiles_y;
+            const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
+            const wx_gptr dyb = dyg1 + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * dyv.cs * 4;
+            const wx_gptr xb = xg1 + (((size_t)(n * L.Hi + (gy0 >> upshift)) * L.Wi + (gx0 >> upshift)) * L.x.cs + L.x.coff + it.ci0) * 4;
+#pragma unroll
+            for (int q = 0; q < NLU; ++q) {
+                int yxq = yx[q];
+                asm volatile("" : "+v"(yxq));                  // keeps the offsets below from being hoisted into more registers
+                const int y = (int)(short)(yxq & 0xffff), x = yxq >> 16;
+                wx_gptr src;
+                if (q < QDY) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyb + ((y * L.Gw + x) * dyv.cs + oct * 8) * 4 : zero32;
+                else src = ((unsigned)(gy0 + y) < (unsigned)LH && (unsigned)(gx0 + x) < (unsigned)LW)
+                               ? xb + (((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + x_c8) * 4 : zero32;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[2 * q]) : "v"(src) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[2 * q + 1]) : "v"(src) : "memory");
+            }
+        };
+        // every load older than the newest 2 NLU has landed; the registers pass through the asm so that no use can move above it
+        auto pass = [&](u32x4 (&r)[2 * NLU]) {
+            asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]) :: "memory");
+            asm volatile("" : "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19]) :: "memory");
+        };
+        auto wait_tile = [&](u32x4 (&r)[2 * NLU]) {
+            pass(r);
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            pass(r);
+        };
+        auto put = [&](int k, int st, u32x4 (&r)[2 * NLU]) {
+            wait_tile(r);
+            if (k >= NST) {
+                for (;;) {
+                    u32x4 dn;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"((int)(C::CTL + 4 * WXC_DONE)) : "memory");
+                    if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= k - NST + 1) break;
+                }
+            }
+            char* base = smem + st * C::STAGE;
+#pragma unroll
+            for (int q = 0; q < NLU; ++q) {
+                const f32x4 v0 = __builtin_bit_cast(f32x4, r[2 * q]), v1 = __builtin_bit_cast(f32x4, r[2 * q + 1]);
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (__bf16)v0[e];
+                    l[e] = (__bf16)(v0[e] - (float)h[e]);
+                    h[4 + e] = (__bf16)v1[e];
+                    l[4 + e] = (__bf16)(v1[e] - (float)h[4 + e]);
+                }
+                if (q < QDY) {
+                    if (wr_dy) {
+                        *reinterpret_cast<u32x4*>(base + lo_dy + q * 2048) = __builtin_bit_cast(u32x4, h);
+                        *reinterpret_cast<u32x4*>(base + lo_dy + C::DYP + q * 2048) = __builtin_bit_cast(u32x4, l);
+                    }
+                    if (do_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bacc[e] += v0[e];
+                            bacc[4 + e] += v1[e];
+                        }
+                    }
+                } else if (lt + (q - QDY) * 256 < C::NXU) {
+                    *reinterpret_cast<u32x4*>(base + lo_x + (q - QDY) * 2048) = __builtin_bit_cast(u32x4, h);
+                    *reinterpret_cast<u32x4*>(base + lo_x + C::XP + (q - QDY) * 2048) = __builtin_bit_cast(u32x4, l);
+                }
+            }
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WXC_READY + st))), "v"(1) : "memory");
+        };
+        // two tiles in flight, no branch around a load (past the end the last tile is loaded again and never stored)
+        const int last = ntile - 1;
+        if (ntile > 0) {
+            load_tile(0, ra);
+            load_tile(min(1, last), rb);
+        }
+        int k = 0;
+        for (; k + 1 < ntile; k += 2) {                        // even tiles -> stage 0 from ra, odd tiles -> stage 1 from rb
+            put(k, 0, ra);
+            load_tile(min(k + 2, last), ra);
+            put(k + 1, 1, rb);
+            load_tile(min(k + 3, last), rb);
+        }
+        if (k < ntile) put(k, 0, ra);
+        // the loads past the end: their registers stay allocated until they have landed
+        pass(ra); pass(rb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pass(ra); pass(rb);
+        if (bias_a || bias_b) {
+            // 32 threads share each channel octet of a plane ((hb, oct) = lane & 7): xor-shuffle tree over the 8 lanes of a wave
+            // with the same (hb, oct), then the four loader waves in turn, then one global add per channel (fixed order)
+            volatile float* bl = reinterpret_cast<volatile float*>(ctl + WXC_BIAS);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bacc[e] = do_bias ? bacc[e] : 0.f;
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bacc[e] += __shfl_xor(bacc[e], m);
+            const int lw = lt >> 6;
+            while (wx_ld(ctl + WXC_LSYNC) < lw) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 8) {          // lane = hb * 4 + oct
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bl[hb * 32 + oct * 8 + e] = lw == 0 ? bacc[e] : bl[hb * 32 + oct * 8 + e] + bacc[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __atomic_fetch_add(ctl + WXC_LSYNC, 1, __ATOMIC_RELAXED);
+            while (wx_ld(ctl + WXC_LSYNC) < 4) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lt < 64) {
+                const int h = lt >> 5, c = lt & 31;
+                const ssr_wgrad_layer& LC = h ? LB : L;
+                const int co = (h ? it.co0_b : it.co0) + c;
+                if ((h ? bias_b : bias_a) && co < LC.Cout) atomicAdd(LC.db + co, LC.alpha * bl[lt]);
+            }
+        }
+        return;
+    }
+
+    // =============================== MFMA waves ===============================
+    const int g = lane >> 5;
+    const int t16 = lane & 15;
+    const int src_px = 8 * g + (t16 >> 2);
+    const int src_ch = 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+    // wave -> (dY plane p, 32-channel half h of the X patch, share q of nq of the tile's 8 rows): always nine taps = nine
+    // accumulators.  paired, 64 ci: (w & 1, w >> 1, all rows); paired, <= 32 ci: (w & 1, 0, rows halved); single, 64 ci:
+    // (0, w & 1, rows halved); single, <= 32 ci: (0, 0, rows quartered).  Row shares are summed in the write-out.
+    const int nci_a = min(64, L.Cin_w - it.ci0), nci_b = min(64, LB.Cin_w - it.ci0);
+    const bool full = max(nci_a, nci_b) > 32;
+    const int wp = pair ? (wave & 1) : 0;
+    const int wh = !full ? 0 : pair ? (wave >> 1) : (wave & 1);
+    const int nq = pair ? (full ? 1 : 2) : (full ? 2 : 4);
+    const int wq = nq == 1 ? 0 : nq == 2 ? (wave >> 1) : wave;
+    const int r0 = wq * (TH / nq);
+    const int la_off = wp * C::DYP + (r0 * WG_TW + src_px) * C::ROW + src_ch;                  // bf16 elements from the stage base
+    const int lb_off = C::XBASE / 2 + wh * C::XP + (r0 * PW + src_px) * C::ROW + src_ch;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // one tile loop per instance (with the instances inside ONE loop the register allocator spills accumulators at every join)
+    auto run = [&](auto nrc) {
+        int st = 0, target = 4;
+        int* dw_ = ctl + WXC_DONE + wave;
+        for (int k = 0; k < ntile; ++k) {
+            while (wx_ld(ctl + WXC_READY + st) < target) {}
+            const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+            wx3_rows<decltype(nrc)::value>(acc, ldy + la_off, ldy + lb_off, dw_, k, lane);
+            if (st == 1) target += 4;
+            st ^= 1;
+        }
+    };
+    if (nq == 1) run(std::integral_constant<int, 8>{});
+    else if (nq == 2) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, 2>{});
+    // =============================== write-out ===============================
+    // D[row = co][col = ci] of the nine taps -> LDS tile [32 co][64 ci][9 taps] (stride 9 floats between lanes: conflict-free),
+    // the row shares one after the other (the first stores, the others add) -> contiguous fp32 atomic adds (each co row of
+    // the tile is 64 * 9 consecutive floats); one dY plane after the other through the same 73.7 KB
+    float* red = reinterpret_cast<float*>(smem);
+    int phase = 0;
+    wx_sync4(ctl + WXC_SYNC, phase, lane);   // all four waves are finished reading the ring
+    const int i = lane & 31;
+    constexpr int NOUT = 32 * 64 * 9;
+    static_for<0, 2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c == 0 || pair) {
+            const ssr_wgrad_layer& LC = c ? LB : L;
+            const int co0 = c ? it.co0_b : it.co0, nci = c ? nci_b : nci_a;
+            const float alpha = c ? LB.alpha : L.alpha;
+            for (int qq = 0; qq < nq; ++qq) {
+                if (wp == c && wq == qq) {
+                    float al = alpha;
+                    asm volatile("" : "+v"(al));               // the 144 products are not loop invariants to be kept (and spilled)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float* dst = red + (mfma32_row(r, g) * 64 + wh * 32 + i) * 9 + t;
+                            *dst = qq == 0 ? al * acc[t][r] : *dst + al * acc[t][r];
+                        }
+                }
+                wx_sync4(ctl + WXC_SYNC, phase, lane);
+            }
+            float* __restrict__ dw = LC.dw;
+#pragma unroll 8
+            for (int q = 0; q < NOUT / 256; ++q) {
+                const int e = tid + q * 256;
+                const int co = e / 576, rem = e - co * 576;
+                if (co0 + co < LC.Cout && rem < nci * 9) {
+                    float* dst = dw + ((size_t)(co0 + co) * LC.Cin_w + it.ci0) * 9 + rem;
+                    atomicAdd(dst, red[e]);
+                }
+            }
+            if (c == 0 && pair) wx_sync4(ctl + WXC_SYNC, phase, lane);   // the tile is read before the second plane overwrites it
+        }
+    });
+}
+
+}  // namespace
+
+int ssr_wgrad_x3_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW, int S,
+                          hipStream_t st) {
+    if (!(KH == 3 && KW == 3 && S == 1)) return SSR_EUNSUP;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_k3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wx3::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_x3_k3_kernel, dim3(n_items), dim3(512), Wx3::LDS, st, layers, items);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}

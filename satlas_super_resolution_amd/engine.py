@@ -496,9 +496,11 @@ def _device_cus():
 class WgradBatch:
     """Device tables for one batched ssr_conv2d_wgrad launch (layers sharing KHxKW/stride).
 
-    hip.F32X3 (fp32 storage, split-bf16 matrix math): the bf16 transpose-read kernel runs three times over bf16 hi/lo planes
-    of the fp32 buffers — (x_hi, dy_hi) + (x_hi, dy_lo) + (x_lo, dy_hi), accumulated in the fp32 gradient arena — after one
-    ssr_split_bf16 pass per distinct parent buffer (x = hi + lo to 2^-17; the dropped lo*lo term is 2^-16 relative)."""
+    hip.F32X3 (fp32 storage, split-bf16 matrix math; x = hi + lo to 2^-17, the dropped lo*lo term is 2^-16 relative):
+    3x3 stride-1 layers: ONE launch of csrc/wgrad_x3.hip over the fp32 buffers - its loader waves split the tiles on the way
+    into LDS and the three products (dy_lo.x_hi + dy_hi.x_lo + dy_hi.x_hi) go into one accumulator set (round 5; SSR_X3_WGRAD_FUSED=0
+    = the older form).  Other layers (4x4 stride 2): the bf16 transpose-read kernel runs three times over bf16 hi/lo planes of the
+    fp32 buffers, accumulated in the fp32 gradient arena, after one ssr_split_bf16_multi pass over the distinct parent buffers."""
 
     # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits (SSR_WGRAD_T3 / _T4: tuning hooks)
     MAX_TILES_PER_ITEM = {3: int(os.environ.get("SSR_WGRAD_T3", "128")), 4: int(os.environ.get("SSR_WGRAD_T4", "64"))}
@@ -506,7 +508,9 @@ class WgradBatch:
     def __init__(self, dtype: int, k: int, stride: int, force_atomic: bool = False, det: Optional[bool] = None):
         self.dtype, self.k, self.stride = dtype, k, stride
         self.force_atomic = force_atomic       # another launch accumulates into the same gradients concurrently
-        self.kdt = hip.BF16 if dtype == hip.F32X3 else dtype      # element type the wgrad kernel reads
+        # element type the wgrad kernel reads: bf16 planes of the fp32 buffers in the split passes, the fp32 buffers themselves in the fused 3x3 kernel
+        fused = dtype == hip.F32X3 and k == 3 and stride == 1 and os.environ.get("SSR_X3_WGRAD_FUSED", "1") == "1"
+        self.kdt = hip.F32X3 if fused else hip.BF16 if dtype == hip.F32X3 else dtype
         self.layers: List[WgradLayer] = []
         self.items: List[WgradItem] = []
         self.layer_tab = self.item_tab = None
@@ -527,7 +531,8 @@ class WgradBatch:
         li = len(self.layers)
         self.layers.append(WgradLayer(x, dy, N, hi, wi, up, cin, cout, 1, 1, gh, gw, alpha, dw_ptr, cin_w, db_ptr))
         tiles = hip.lib().ssr_wgrad_tiles(N, gh, gw, self.kdt, self.k)
-        splits = max(1, -(-tiles // self.MAX_TILES_PER_ITEM.get(self.k, 128)))
+        # (the fused fp32x3 kernel walks 8 x 16-pixel tiles, half the bf16 kernel's: the same pixels per item)
+        splits = max(1, -(-tiles // (self.MAX_TILES_PER_ITEM.get(self.k, 128) * (2 if self.kdt == hip.F32X3 else 1))))
         per = -(-tiles // splits)
         lsp = [li] * splits                   # layer-table entry of split sp
         if self.det and splits > 1:
@@ -688,7 +693,7 @@ class WgradBatch:
         self.items = self._xcd_order(self.items) if os.environ.get("SSR_WGRAD_ORDER", "heavy") == "xcd" else \
             sorted(self.items, key=lambda it: -self._cost(it))                    # longest items first
         self.item_tab = hip.device_table(self.items)
-        if self.dtype != hip.F32X3:
+        if self.kdt != hip.BF16 or self.dtype == hip.BF16:
             self.layer_tab = hip.device_table(self.layers)
             return
         # three passes over hi/lo planes; the bias gradient (sum of dy) comes out of the first two (dy_hi + dy_lo)
@@ -711,7 +716,7 @@ class WgradBatch:
             L.add(lib.ssr_wgrad_reduce, self.reduce_tab.data_ptr(), self.n_reduce, self.max_reduce, what="wgrad partials -> grad (fixed order)")
 
     def _launch_wgrad(self, L: Launcher, lib):
-        if self.dtype == hip.F32X3:
+        if self.dtype == hip.F32X3 and self.kdt == hip.BF16:
             if all(p.numel() % 8 == 0 for p, _, _ in self.splits):          # every buffer of the batch in ONE launch (ssr_split_bf16_multi)
                 if self.split_tab is None:
                     self.split_tab = hip.device_table([hip.SplitItem(p.data_ptr(), h.data_ptr(), l.data_ptr(), p.numel()) for p, h, l in self.splits])
@@ -725,7 +730,7 @@ class WgradBatch:
                       self.stride, what="wgrad batch (split pass)")
             return
         L.add(lib.ssr_conv2d_wgrad, self.layer_tab.data_ptr(), self.item_tab.data_ptr(), len(self.items),
-              self.dtype, self.k, self.k, self.stride, what="wgrad batch")
+              self.kdt, self.k, self.k, self.stride, what="wgrad batch")
 
 
 # =====================================================================================================

@@ -38,6 +38,9 @@ def test_struct_layouts_match_header():
     assert hip.lib().ssr_conv2d_wgrad(None, None, 0, 0, 3, 3, 1, None) == -1
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.F32, 3) == 16 * 4 * 2
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.BF16, 3) == 16 * 2 * 2   # 16x16-pixel tiles
+    assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.F32X3, 3) == 16 * 4 * 2  # the one-pass fp32x3 kernel: 8x16 (hi AND lo planes in a stage)
+    assert hip.lib().ssr_wgrad_ci_tile(hip.F32X3, 3) == 64 and hip.lib().ssr_wgrad_co_tile(hip.F32X3, 3) == 64
+    assert hip.lib().ssr_wgrad_ci_tile(hip.F32X3, 4) == 32                    # 4x4 stride 2 stays on the three bf16 passes
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):

@@ -18,6 +18,7 @@ def symbol(name: str):
     if "rdbt_kernel<16, false>" in name or "rdbt_kernelILi16ELb0" in name: return "rdbt_kernel<16, false>"
     if "rdb_kernel<true>" in name or "rdb_kernelILb1" in name: return "rdb_kernel<true>"
     if "rdb_kernel<false>" in name or "rdb_kernelILb0" in name: return "rdb_kernel<false>"
+    if "wgrad_x3_k3_kernel" in name: return "wgrad_kernel<fp32x3,K3>"
     if "wgrad_bf16_k3_kernel" in name: return "wgrad_kernel<bf16,K3>"
     if "wgrad_bf16_kernel" in name: return "wgrad_kernel<bf16,K4>"
     import re

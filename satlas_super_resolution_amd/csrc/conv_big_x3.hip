@@ -39,7 +39,8 @@ template <int KT> struct XbT {
     static constexpr int WBYTES = WROWS * AROW;                // 46,080 / 20,480
     static constexpr int BUF = PATCH + WBYTES;
     static constexpr int BIAS = BUF;                           // 64 floats
-    static constexpr int LDS = BIAS + 256;
+    static constexpr int SLABS = BIAS + 256;                   // four wave-private epilogue slabs [32 px][64 co] fp32, 272-byte rows
+    static constexpr int LDS = SLABS + 4 * 32 * 272;
     static constexpr int NPV = (NPIX * VPP + 255) / 256;       // patch vectors per thread: 10 / 9
     static constexpr int NWV = (WROWS * VPP + 255) / 256;      // weight vectors per thread: 9 / 4
     static constexpr int NSTEP = KT * KT;                      // k-steps (taps) per chunk, 24 MFMAs each
@@ -49,7 +50,16 @@ template <int KT> struct XbT {
 };
 
 #define XB_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef SSR_PROBE   // tools/bigx3_probe.hip: phase sums of wave 0 (s_memtime ticks): [0] whole, [1] prologue, [2] wait for everyone to leave the previous
+                   // chunk, [3] store (incl. the wait for the staging loads), [4] barrier behind the store, [5] k-steps, [6] epilogues, [7] chunks
+#define XB_T() (__builtin_amdgcn_s_memtime())
+#define XB_ACC(k, t0) do { const unsigned long long t1_ = XB_T(); xb_t[k] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define XB_T() 0ull
+#define XB_ACC(k, t0) do { } while (0)
+#endif
 constexpr int XB_OOB = 0x7ffffff0;
+constexpr int XB_SLAB_PITCH = 272, XB_SLAB = 32 * XB_SLAB_PITCH;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xb_rsrc(const void* p, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffff00L ? 0x7fffff00L : (bytes < 0 ? 0 : bytes)), 0x00020000);
 }
@@ -94,6 +104,9 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
     const int T_ = nimg * nchunks;                             // length of this workgroup's chunk stream
     const int ximg = d.Hi * d.Wi * d.x.cs * 4, oimg = d.Ho * d.Wo;   // per-image strides (bytes of x / output pixels)
 
+    unsigned long long xb_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xb_t0 = XB_T();
+    const unsigned long long xb_start = xb_t0;
+    (void)xb_t; (void)xb_start;
     float* bias_lds = reinterpret_cast<float*>(smem + T::BIAS);
     if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
 
@@ -186,23 +199,19 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
     };
 
     // ---- this lane's pixels (one per pixel tile) ----
-    int a_off[4], ppx[4];
-    bool pval[4];
+    int a_off[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         int row, col;
         xb_pixel<KT>(wave, m, i, row, col);
         a_off[m] = (row * PW + col) * AROW + g * 16;
-        const int gy = gy0 + row, gx = gx0 + col;
-        pval[m] = gy < d.Gh && gx < d.Gw;
-        const int cy = pval[m] ? gy : d.Gh - 1, cx = pval[m] ? gx : d.Gw - 1;
-        ppx[m] = (cy * d.oys + d.oyo) * d.Wo + cx * d.oxs + d.oxo;     // image-relative output pixel (+ nn * oimg)
     }
     const int b_off = PATCH + i * AROW + g * 16;
     const int co_l = 4 * g;                                    // + t*32 + 8*q4 + e: this lane's 16 channels of a channel tile
 
     load_chunk(n0, 0);
     __syncthreads();                                           // bias table
+    XB_ACC(1, xb_t0);
     f32x16 acc[4][2];
     auto acc_init = [&]() {                                    // accumulators start at the bias
 #pragma unroll
@@ -217,74 +226,124 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
             }
     };
 
-    // ---- epilogue of image nn: the whole ssr_conv_desc contract on 16-byte fp32 vectors (this lane: one pixel x 4 channels
-    //      per (pixel tile, channel tile, q4)); the operands of one (pixel tile, channel tile) are requested together ----
-    auto epilogue = [&](int nn) {
-        // (resources and flags are set up HERE, not ahead of the chunk stream: six descriptors and a dozen scalars live across the
-        // main loop cost 100 - 600 spilled SGPRs)
+    // ---- epilogue of image nn: the whole ssr_conv_desc contract on 16-byte fp32 vectors.  The accumulators of a pixel tile (lane =
+    //      one pixel x 16 channels per channel tile) go through a wave-private LDS slab [32 px][64 co] (272-byte rows: conflict-free
+    //      both ways) and come back as lane = (pixel 4h + lane / 16, channels 4 (lane % 16) ..): a wave's load / store instruction
+    //      then covers the whole 256-byte rows of 4 pixels.  (Round 5, tools/bigx3_probe: stored straight from the MFMA layout - 32
+    //      pixels x 32 bytes per instruction, every 128-byte line written in four pieces - the epilogues took 32 k ticks per image,
+    //      as long as the 64-channel layers' MFMAs; 59 k with a residual and a second output.) ----
+    char* slab = smem + T::SLABS + wave * XB_SLAB;
+    // Straight-line code: the feature set is two template flags picked by two uniform branches per image (OPS: any of r1 / r2 /
+    // accumulate / mask - absent ones are loaded through an out-of-range offset, i.e. as zeros, and enter with a zero factor; Y01: the
+    // second / third outputs).  With run-time `if (has_r1) ...` inside the unrolled element loops the epilogue was 2,500 branches
+    // of code and 23 k of its 32 k ticks per image were branch issue (lesson 2 of round 1, relearned).
+    auto epilogue_impl = [&](int nn, auto opsc, auto y01c) __attribute__((always_inline)) {
+        constexpr bool OPS = decltype(opsc)::value, Y01 = decltype(y01c)::value;
+        // (resources are set up HERE, not ahead of the chunk stream: six descriptors live across the main loop cost 100 - 600 spilled SGPRs)
         const long obytes = (long)d.N * oimg * 4;
         const __amdgpu_buffer_rsrc_t rs_r1 = xb_rsrc(d.r1.p, d.r1.p ? obytes * d.r1.cs : 0), rs_r2 = xb_rsrc(d.r2.p, d.r2.p ? obytes * d.r2.cs : 0),
                                      rs_m = xb_rsrc(d.m.p, d.m.p ? obytes * d.m.cs : 0), rs_y = xb_rsrc(d.y.p, obytes * d.y.cs),
                                      rs_y0 = xb_rsrc(d.y0.p, d.y0.p ? obytes * d.y0.cs : 0), rs_y1 = xb_rsrc(d.y1.p, d.y1.p ? obytes * d.y1.cs : 0);
         const bool has_r1 = d.r1.p != nullptr, has_r2 = d.r2.p != nullptr, has_m = d.m.p != nullptr, has_acc = d.accumulate != 0,
-                   has_y0 = d.y0.p != nullptr, has_y1 = d.y1.p != nullptr;
-        const int act = d.act, m_relu = d.m_relu;
-        const float alpha = d.alpha, beta1 = d.beta1, beta2 = d.beta2;
+                   has_y0 = d.y0.p != nullptr, has_y1 = d.y1.p != nullptr, m_relu = d.m_relu != 0;
+        // act(x) = max(x, slope x): LeakyReLU 0.2, ReLU 0, none 1
+        const float slope = d.act == SSR_ACT_LRELU ? 0.2f : d.act == SSR_ACT_RELU ? 0.f : 1.f;
+        const float alpha = d.alpha, beta1 = has_r1 ? d.beta1 : 0.f, beta2 = has_r2 ? d.beta2 : 0.f, gacc = has_acc ? 1.f : 0.f;
+        const int y_cs = d.y.cs, y_co = d.y.coff, y0_cs = d.y0.cs, y0_co = d.y0.coff, y1_cs = d.y1.cs, y1_co = d.y1.coff;
+        const int r1_cs = d.r1.cs, r1_co = d.r1.coff, r2_cs = d.r2.cs, r2_co = d.r2.coff, m_cs = d.m.cs, m_co = d.m.coff;
+        const int Gh = d.Gh, Gw = d.Gw, oys = d.oys, oyo = d.oyo, oxs = d.oxs, oxo = d.oxo, Wo = d.Wo;
         const int pimg = nn * oimg;
+        const int hp = lane >> 4, c = co0 + (lane & 15) * 4;
+        const bool cok = c < d.Cout;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int pp = pimg + ppx[m];
+            int po[8];                                          // output pixel of slot 4h + hp (clamped into the grid), sign bit = outside
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                u32x4 q1[4], q2[4], qa[4], qm[4];
+            for (int h = 0; h < 8; ++h) {
+                int row, col;
+                xb_pixel<KT>(wave, m, 4 * h + hp, row, col);
+                const int gy = gy0 + row, gx = gx0 + col;
+                const bool ok = gy < Gh && gx < Gw;
+                const int cy = gy < Gh ? gy : Gh - 1, cx = gx < Gw ? gx : Gw - 1;
+                po[h] = (pimg + (cy * oys + oyo) * Wo + cx * oxs + oxo) | (ok && cok ? 0 : (int)0x80000000);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const bool cok = c < d.Cout;
-                    if (has_r1) q1[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, cok ? (pp * d.r1.cs + d.r1.coff + c) * 4 : XB_OOB, 0, 0);
-                    if (has_r2) q2[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, cok ? (pp * d.r2.cs + d.r2.coff + c) * 4 : XB_OOB, 0, 0);
-                    if (has_acc) qa[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, cok ? (pp * d.y.cs + d.y.coff + c) * 4 : XB_OOB, 0, 0);
-                    if (has_m) qm[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, cok ? (pp * d.m.cs + d.m.coff + c) * 4 : XB_OOB, 0, 0);
+                    const f32x4 v = {acc[m][t][4 * q4], acc[m][t][4 * q4 + 1], acc[m][t][4 * q4 + 2], acc[m][t][4 * q4 + 3]};
+                    *reinterpret_cast<f32x4*>(slab + i * XB_SLAB_PITCH + (t * 32 + 8 * q4 + co_l) * 4) = v;
+                }
+            // (the operands of four pixel slots at a time: 64 registers in flight, not 128)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                u32x4 q1[OPS ? 4 : 1], q2[OPS ? 4 : 1], qa[OPS ? 4 : 1], qm[OPS ? 4 : 1];
+                if constexpr (OPS) {
+#pragma unroll
+                    for (int h4 = 0; h4 < 4; ++h4) {
+                        const int pp = po[4 * hh + h4] & 0x7fffffff;
+                        q1[h4] = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, cok && has_r1 ? (pp * r1_cs + r1_co + c) * 4 : XB_OOB, 0, 0);
+                        q2[h4] = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, cok && has_r2 ? (pp * r2_cs + r2_co + c) * 4 : XB_OOB, 0, 0);
+                        qa[h4] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, cok && has_acc ? (pp * y_cs + y_co + c) * 4 : XB_OOB, 0, 0);
+                        qm[h4] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, cok && has_m ? (pp * m_cs + m_co + c) * 4 : XB_OOB, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int c = co0 + t * 32 + 8 * q4 + co_l;
-                    const bool ok = pval[m] && c < d.Cout;
+                for (int h4 = 0; h4 < 4; ++h4) {
+                    const int h = 4 * hh + h4;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (4 * h + hp) * XB_SLAB_PITCH + (lane & 15) * 16);
+                    const bool ok = po[h] >= 0;
+                    const int pp = po[h] & 0x7fffffff;
                     f32x4 v, s0, s1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[m][t][4 * q4 + e];
-                        if (act == SSR_ACT_LRELU) x = lrelu_max(x);
-                        else if (act == SSR_ACT_RELU) x = fmaxf(x, 0.f);
-                        x *= alpha;
+                        float x = fmaxf(a[e], slope * a[e]) * alpha;
                         s0[e] = x;
-                        if (has_r1) x += beta1 * __builtin_bit_cast(f32x4, q1[q4])[e];
-                        if (has_r2) x += beta2 * __builtin_bit_cast(f32x4, q2[q4])[e];
-                        if (has_acc) x += __builtin_bit_cast(f32x4, qa[q4])[e];
-                        s1[e] = x;
-                        if (has_m) {
-                            const float mv = __builtin_bit_cast(f32x4, qm[q4])[e];
-                            x *= m_relu ? (mv > 0.f ? 1.f : 0.f) : lrelu_grad_from_out(mv);
+                        if constexpr (OPS) {
+                            x += beta1 * __builtin_bit_cast(f32x4, q1[h4])[e] + beta2 * __builtin_bit_cast(f32x4, q2[h4])[e] + gacc * __builtin_bit_cast(f32x4, qa[h4])[e];
+                            s1[e] = x;
+                            const float mv = __builtin_bit_cast(f32x4, qm[h4])[e];
+                            const float f = m_relu ? (mv > 0.f ? 1.f : 0.f) : lrelu_grad_from_out(mv);
+                            x *= has_m ? f : 1.f;
+                        } else {
+                            s1[e] = x;
                         }
                         v[e] = x;
                     }
-                    if (has_y0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), rs_y0, ok ? (pp * d.y0.cs + d.y0.coff + c) * 4 : XB_OOB, 0, 0);
-                    if (has_y1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), rs_y1, ok ? (pp * d.y1.cs + d.y1.coff + c) * 4 : XB_OOB, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, ok ? (pp * d.y.cs + d.y.coff + c) * 4 : XB_OOB, 0, 0);
+                    if constexpr (Y01) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), rs_y0, ok && has_y0 ? (pp * y0_cs + y0_co + c) * 4 : XB_OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), rs_y1, ok && has_y1 ? (pp * y1_cs + y1_co + c) * 4 : XB_OOB, 0, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, ok ? (pp * y_cs + y_co + c) * 4 : XB_OOB, 0, 0);
                 }
             }
+        }
+    };
+    auto epilogue = [&](int nn) __attribute__((always_inline)) {
+        const bool ops = d.r1.p != nullptr || d.r2.p != nullptr || d.m.p != nullptr || d.accumulate != 0;
+        const bool y01 = d.y0.p != nullptr || d.y1.p != nullptr;
+        if (ops) {
+            if (y01) epilogue_impl(nn, std::true_type{}, std::true_type{});
+            else epilogue_impl(nn, std::true_type{}, std::false_type{});
+        } else {
+            if (y01) epilogue_impl(nn, std::false_type{}, std::true_type{});
+            else epilogue_impl(nn, std::false_type{}, std::false_type{});
         }
     };
 
     // ---- one chunk: (store) - barrier - 9 / 4 k-steps of 24 MFMAs with the fragment reads of the next step and the staging loads of
     //      the next chunk between them ----
-    auto chunk = [&](int c, bool stored, int nn1, int c1, auto hnc) {   // c = stream position; (nn1, c1) = position c + 1
+    auto chunk = [&](int c, bool stored, int nn1, int c1, auto hnc) __attribute__((always_inline)) {   // c = stream position; (nn1, c1) = position c + 1
         constexpr bool has_next = decltype(hnc)::value;
+        xb_t0 = XB_T();
         if (!stored) {                                         // (an image's first chunk was stored before the previous epilogue)
             if (c > 0) XB_BAR();                               // everyone is finished reading the previous chunk
+            XB_ACC(2, xb_t0);
             store_chunk();
+            XB_ACC(3, xb_t0);
         }
         XB_BAR();
+        XB_ACC(4, xb_t0);
         const LoadPos lp1 = load_pos(nn1, c1);
         bf16x8 wq[2][2][2], pq[2][4][2];                       // [step parity][tile][hi | lo]
         auto issue1 = [&](auto sc, auto kc) {                  // memory operation k (0..11) of step s: 4 weight fragments, 8 pixel fragments
@@ -313,6 +372,8 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
             });
         });
         __builtin_amdgcn_sched_barrier(0);
+        XB_ACC(5, xb_t0);
+        xb_t[7] += 1;
     };
     // every chunk but the stream's last one runs in the loops; the last chunk is peeled (no further loads)
     int gc = 0;
@@ -327,14 +388,27 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
         if (!last_img) {
             // image boundary: the next image's first chunk leaves the staging registers BEFORE the epilogue; its LDS stores, and the
             // epilogue's global stores, drain under the next MFMAs
+            xb_t0 = XB_T();
             XB_BAR();
+            XB_ACC(2, xb_t0);
             store_chunk();
+            XB_ACC(3, xb_t0);
             epilogue(nn);
+            XB_ACC(6, xb_t0);
         }
     }
     const int nl = n0 + (nimg - 1) * G;
     chunk(gc, nimg > 1 && nchunks == 1, nl, 0, std::false_type{});
+    xb_t0 = XB_T();
     epilogue(nl);
+    XB_ACC(6, xb_t0);
+#ifdef SSR_PROBE
+    if (tid == 0) {
+        xb_t[0] = XB_T() - xb_start;
+        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int k = 0; k < 8; ++k) g_probe[b * 8 + k] = xb_t[k];
+    }
+#endif
     (void)T_;
 }
 
@@ -354,7 +428,7 @@ int launch_bigx3(const ssr_conv_desc* ds, int n, hipStream_t st) {
     const ssr_conv_desc& d = ds[0];
     // grid.x = (tile positions per image) x G image groups; G minimises rounds x images-per-workgroup on the device's CUs
     const int tpi = ((d.Gh + XB_TH - 1) / XB_TH) * ((d.Gw + XB_TW - 1) / XB_TW);
-    static const int ncu = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    static const int ncu = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; return v > 0 ? v : 256; }();
     int G = d.N;
     {
         const long per_img = (long)tpi * (d.CoutPad / 64) * n;

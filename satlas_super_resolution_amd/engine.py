@@ -1096,12 +1096,14 @@ class SplitGeneratorPlan:
 # =====================================================================================================
 # Discriminator
 # =====================================================================================================
-def discriminator_specs(num_in_ch, num_feat=64, in_hw: Optional[Tuple[int, int]] = None) -> List[ConvSpec]:
-    """discriminator_arch.py:28-40.  `in_hw` (input size the store will serve, if known) only steers kernel choice: the
+def discriminator_specs(num_in_ch, num_feat=64, in_hw: Optional[Tuple[int, int]] = None, dtype: Optional[int] = None) -> List[ConvSpec]:
+    """discriminator_arch.py:28-40.  `in_hw` (input size the store will serve, if known) and `dtype` only steer kernel choice: the
     space-to-depth form of a stride-2 layer works on 32x16-pixel tiles and loses to the pipelined kernel on output grids
-    below 24 rows (r01 per-layer times at B=32: conv3, 16x16 grid, 82 vs 66 us; conv1/conv2 67/51 vs 99/87 us)."""
+    below 24 rows (r01 per-layer times at B=32: conv3, 16x16 grid, 82 vs 66 us; conv1/conv2 67/51 vs 99/87 us).  In the split-bf16
+    mode the alternative is the exact fp32 MFMA (conv3: 340 us), so half-empty tiles still win there: 16 rows and up."""
     nf = num_feat
-    grid = lambda k: None if in_hw is None or min(in_hw[0] >> k, in_hw[1] >> k) >= 24 else False
+    min_rows = 16 if dtype == hip.F32X3 else 24
+    grid = lambda k: None if in_hw is None or min(in_hw[0] >> k, in_hw[1] >> k) >= min_rows else False
     return _disc_specs(num_in_ch, nf, grid)
 
 

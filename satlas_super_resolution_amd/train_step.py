@@ -89,7 +89,7 @@ class ESRGANTrainStep:
         self.cin, self.cout, self.cd = cin, cout, cd
         self.g_store = g_store or engine.ParamStore(engine.generator_specs(**g_kwargs), self.dt)
         self.d_store = d_store or engine.ParamStore(
-            engine.discriminator_specs(cd, d_kwargs.get("num_feat", 64), in_hw=(4 * h, 4 * w)), self.dt)
+            engine.discriminator_specs(cd, d_kwargs.get("num_feat", 64), in_hw=(4 * h, 4 * w), dtype=self.dt), self.dt)
         tdt, dev = hip.torch_dtype(self.dt), self.g_store.device
         H, W = 4 * h, 4 * w
         self.H, self.W = H, W

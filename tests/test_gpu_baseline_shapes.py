@@ -133,7 +133,7 @@ def test_discriminator_every_layer_at_baseline_shape(mode, c_d, B):
     dt = _set_mode(mode)
     lmode = "bf16" if mode == "bf16" else "fp32"
     sd = _disc_state(c_d)
-    st = engine.ParamStore(engine.discriminator_specs(c_d, NF, in_hw=(128, 128)), dt)
+    st = engine.ParamStore(engine.discriminator_specs(c_d, NF, in_hw=(128, 128), dtype=dt), dt)
     st.load_state_dict(sd)
     plan = engine.DiscriminatorPlan(st, B, 128, 128, num_in_ch=c_d, num_feat=NF, skip_connection=True)
     tdt = hip.torch_dtype(dt)
@@ -511,7 +511,7 @@ def test_discriminator_vs_reference_class_at_full_size(mode, name, monkeypatch):
     r = torch.randn(1, 1, 128, 128, generator=g)
     monkeypatch.setattr(engine, "X3_FIXUP", [mode.endswith("-fix")])     # "-fix": with the LeakyReLU decision fix-up (reported)
     dt = _set_mode(mode.split("-")[0])
-    st = engine.ParamStore(engine.discriminator_specs(c_d, 64, in_hw=(128, 128)), dt)
+    st = engine.ParamStore(engine.discriminator_specs(c_d, 64, in_hw=(128, 128), dtype=dt), dt)
     st.load_state_dict(sd)
     plan = engine.DiscriminatorPlan(st, 1, 128, 128, num_in_ch=c_d, num_feat=64, skip_connection=True)
     xb = torch.zeros(1, 128, 128, plan.cdp, device="cuda")

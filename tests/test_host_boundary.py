@@ -130,6 +130,9 @@ def test_discriminator_specs_steer_the_space_to_depth_path_by_grid_size():
     assert flags((128, 128)) == {"conv1": None, "conv2": None, "conv3": False}      # grids 64, 32, 16
     assert flags((32, 32)) == {"conv1": False, "conv2": False, "conv3": False}      # the small parity shapes
     assert flags((256, 96)) == {"conv1": None, "conv2": None, "conv3": False}       # min side decides: 48, 24, 12
+    from satlas_super_resolution_amd import hip   # split-bf16 mode: the alternative is the exact fp32 MFMA, 16 rows are enough
+    x3 = {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=(128, 128), dtype=hip.F32X3) if s.k == 4}
+    assert x3 == {"conv1": None, "conv2": None, "conv3": None}
     names = [s.name for s in engine.discriminator_specs(3, 64)]
     assert names == ["conv%d" % i for i in range(10)]
 

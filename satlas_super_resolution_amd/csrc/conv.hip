@@ -890,6 +890,7 @@ extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
+    if (dp->dtype != SSR_BF16 && ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;        // digit 7 = thin-output VALU kernel
     if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
     if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
         return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
@@ -931,7 +932,9 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     }
     if (d.dtype == SSR_F32X3) {   // fp32 storage, split-bf16 matrix math (stride-1 2x2 / 3x3); 4x4 stride 2 without s2d: the exact fp32 kernel
         if (impl == 4) return ssr_conv_bigx3_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
         if (impl == 6) return ssr_conv_x3q_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 0 && ssr_conv_thin_try(d, st, &rc, false)) return rc;
         if (impl == 0 && ssr_conv_bigx3_try(d, st, &rc, false)) return rc;
         if (impl == 0 && ssr_conv_x3q_try(d, st, &rc, false)) return rc;
         if (d.KH == 3 && d.KW == 3 && d.stride == 1) return dispatch_tile_x3<3, 3>(d, st);

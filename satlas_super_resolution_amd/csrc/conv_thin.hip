@@ -1,4 +1,4 @@
-// Thin-output 3x3 convolution (bf16, Cout <= 8, Cin <= 64): the logit / RGB heads and the dgrad into a 3-channel input.
+// Thin-output 3x3 convolution (Cout <= 8, Cin <= 64; bf16 below, the fp32 modes further down): the logit / RGB heads and the dgrad into a 3-channel input.
 //
 // conv9 (64 -> 1), conv_last (64 -> 3) and conv0's dgrad (64 -> 3) at 128x128 cost 38..67 us each on the MFMA kernels
 // (r01 rocprofv3): a 32-wide MFMA tile is 97 % / 91 % padding there and the launch is all staging and epilogue.  The work
@@ -97,6 +97,136 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ssr_conv_desc d) {
     }
 }
 
+// ---- fp32 storage (SSR_F32 exact, SSR_F32X3 split-bf16 weights), round 5 ----
+// The same layers in the fp32 modes run on the pipelined MFMA kernels: 117 us each at B = 32 (conv9 x 3, conv_last, conv0's
+// dgrad: 0.59 ms of the fp32x3 step) for 0.6-4.8 GFLOP.  This form is correct (tests/test_gpu_conv_x3.py) but SLOWER there (165 us,
+// see ssr_conv_thin_qualifies) and therefore opt-in.  One thread = one pixel again; the input is staged 32 channels at a time
+// (144-byte rows: consecutive lanes 36 banks apart; 49 KB per workgroup, three workgroups per CU), the products are fp32 FMAs
+// against wave-uniform weights read with scalar loads from the packed rows [chunk16][tap][CoutPad][16]: plain fp32 in the exact
+// mode; [16 hi | 16 lo] bf16 in the split mode, where w = hi + lo enters as two FMAs (activations stay exact fp32: the result is
+// at least as accurate as the three-product MFMA form, 2^-17 per weight).
+constexpr int CTF_CB = 32, CTF_ROWB = CTF_CB * 4 + 16;        // channels staged per pass, bytes per LDS row
+
+template <int NCO, bool X3>
+__global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int cin = d.Cin;
+    const int tiles_x = (d.Gw + CT_TW - 1) / CT_TW, tiles_y = (d.Gh + CT_TH - 1) / CT_TH;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * CT_TH, gx0 = tx_i * CT_TW;
+    const float* __restrict__ xg = reinterpret_cast<const float*>(d.x.p);
+    const char* __restrict__ wg = reinterpret_cast<const char*>(d.w);
+    const int ty = tid >> 5, tx = tid & 31;
+    const char* pb = smem + (ty * CT_PW + tx) * CTF_ROWB;
+    float acc[NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) acc[c] = 0.f;
+    for (int c0 = 0; c0 < cin; c0 += CTF_CB) {
+        if (c0) __syncthreads();                              // everyone is finished with the previous 32 channels
+        // ---- stage channels [c0, c0 + 32) of the halo patch: vector v = pixel * 8 + part ----
+        for (int v = tid; v < CT_NPIX * 8; v += 256) {
+            const int pix = v >> 3, part = v & 7;
+            const int py = pix / CT_PW, px = pix - py * CT_PW;
+            const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi && c0 + part * 4 < cin)
+                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + c0 + part * 4);
+            *reinterpret_cast<u32x4*>(smem + pix * CTF_ROWB + part * 16) = val;
+        }
+        __syncthreads();
+        // a 16-channel chunk at a time: the NCO (<= 4 at once) packed rows of (chunk, tap) arrive as whole 64-byte scalar loads, then
+        // four pixel vectors x 4 channels run against them (padded channels: zero weights against zero pixels)
+        const int n16 = (min(cin - c0, CTF_CB) + 15) >> 4;
+        constexpr int CG = NCO > 4 ? 4 : NCO;
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* pr = pb + ((tap / 3) * CT_PW + tap % 3) * CTF_ROWB;
+            for (int h = 0; h < n16; ++h) {
+                const char* wk = wg + ((size_t)(((c0 >> 4) + h) * 9 + tap) * d.CoutPad) * 64;    // uniform: scalar loads
+#pragma unroll
+                for (int cg = 0; cg < NCO; cg += CG) {
+                    u32x4 row[CG][4];
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) row[c][q] = *reinterpret_cast<const u32x4*>(wk + (cg + c) * 64 + q * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(pr + (h * 4 + k) * 16);
+#pragma unroll
+                        for (int c = 0; c < CG; ++c) {
+                            float a = acc[cg + c];
+                            if (X3) {   // row = [16 hi | 16 lo] bf16: channels 4k .. 4k + 3 are dwords 2k, 2k + 1 of each half
+                                const unsigned h0 = row[c][k >> 1][(2 * k) & 3], h1 = row[c][k >> 1][(2 * k + 1) & 3];
+                                const unsigned l0 = row[c][2 + (k >> 1)][(2 * k) & 3], l1 = row[c][2 + (k >> 1)][(2 * k + 1) & 3];
+                                a = fmaf(xv.x, __builtin_bit_cast(float, l0 << 16), a);
+                                a = fmaf(xv.y, __builtin_bit_cast(float, l0 & 0xffff0000u), a);
+                                a = fmaf(xv.z, __builtin_bit_cast(float, l1 << 16), a);
+                                a = fmaf(xv.w, __builtin_bit_cast(float, l1 & 0xffff0000u), a);
+                                a = fmaf(xv.x, __builtin_bit_cast(float, h0 << 16), a);
+                                a = fmaf(xv.y, __builtin_bit_cast(float, h0 & 0xffff0000u), a);
+                                a = fmaf(xv.z, __builtin_bit_cast(float, h1 << 16), a);
+                                a = fmaf(xv.w, __builtin_bit_cast(float, h1 & 0xffff0000u), a);
+                            } else {
+                                const f32x4 w = __builtin_bit_cast(f32x4, row[c][k]);
+                                a = fmaf(xv.x, w.x, a); a = fmaf(xv.y, w.y, a); a = fmaf(xv.z, w.z, a); a = fmaf(xv.w, w.w, a);
+                            }
+                            acc[cg + c] = a;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue (ssr_conv_desc contract) on this pixel's Cout values ----
+    const int gy = gy0 + ty, gx = gx0 + tx;
+    if (gy >= d.Gh || gx >= d.Gw) return;
+    const size_t pp = (size_t)(n * d.Ho + gy * d.oys + d.oyo) * d.Wo + gx * d.oxs + d.oxo;
+    float* __restrict__ yp = reinterpret_cast<float*>(d.y.p);
+    float* __restrict__ y0p = reinterpret_cast<float*>(d.y0.p);
+    float* __restrict__ y1p = reinterpret_cast<float*>(d.y1.p);
+    const float* __restrict__ r1p = reinterpret_cast<const float*>(d.r1.p);
+    const float* __restrict__ r2p = reinterpret_cast<const float*>(d.r2.p);
+    const float* __restrict__ mp = reinterpret_cast<const float*>(d.m.p);
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        if (c >= d.Cout) break;
+        float v = acc[c] + (d.bias ? d.bias[c] : 0.f);
+        if (d.act == SSR_ACT_LRELU) v = lrelu(v);
+        else if (d.act == SSR_ACT_RELU) v = fmaxf(v, 0.f);
+        v *= d.alpha;
+        if (y0p) y0p[pp * d.y0.cs + d.y0.coff + c] = v;
+        if (r1p && c < d.r1_nc) v += d.beta1 * r1p[pp * d.r1.cs + d.r1.coff + c];
+        if (r2p && c < d.r2_nc) v += d.beta2 * r2p[pp * d.r2.cs + d.r2.coff + c];
+        if (d.accumulate) v += yp[pp * d.y.cs + d.y.coff + c];
+        if (y1p) y1p[pp * d.y1.cs + d.y1.coff + c] = v;
+        if (mp && c >= d.m_c0 && c < d.m_c1) {
+            const float mv = mp[pp * d.m.cs + d.m.coff + c];
+            v *= d.m_relu ? (mv > 0.f ? 1.f : 0.f) : lrelu_grad_from_out(mv);
+        }
+        yp[pp * d.y.cs + d.y.coff + c] = v;
+    }
+}
+
+template <int NCO, bool X3>
+int launch_thin_f32(const ssr_conv_desc& d, hipStream_t st) {
+    const size_t lds = (size_t)CT_NPIX * CTF_ROWB;             // 48,960 B: under the default limit
+    const int tiles = d.N * ((d.Gh + CT_TH - 1) / CT_TH) * ((d.Gw + CT_TW - 1) / CT_TW);
+    hipLaunchKernelGGL((conv_thin_f32_kernel<NCO, X3>), dim3(tiles), dim3(256), lds, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+template <bool X3>
+int launch_thin_f32_by_cout(const ssr_conv_desc& d, hipStream_t st) {
+    if (d.Cout == 1) return launch_thin_f32<1, X3>(d, st);
+    if (d.Cout <= 3) return launch_thin_f32<3, X3>(d, st);
+    if (d.Cout == 4) return launch_thin_f32<4, X3>(d, st);
+    return launch_thin_f32<8, X3>(d, st);
+}
+
 template <int NCO>
 int launch_thin(const ssr_conv_desc& d, hipStream_t st) {
     const size_t lds = (size_t)CT_NPIX * (d.Cin * 2 + 16);
@@ -117,21 +247,33 @@ int launch_thin(const ssr_conv_desc& d, hipStream_t st) {
 }  // namespace
 
 bool ssr_conv_thin_shape_ok(const ssr_conv_desc& d) {
-    if (d.dtype != SSR_BF16) return false;
-    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p || d.up != 1) return false;
+    const bool f32 = d.dtype == SSR_F32 || d.dtype == SSR_F32X3;
+    if (d.dtype != SSR_BF16 && !f32) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p || d.up != 1 || d.fix_list) return false;
     if (d.Cin > 64 || (d.Cin % 8) != 0 || d.Cout > 8 || d.Cout < 1) return false;
     if (d.Gh != d.Hi || d.Gw != d.Wi) return false;
+    if (f32) return (d.x.cs % 4) == 0 && (d.x.coff % 4) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0;
     return (d.x.cs % 8) == 0 && (d.x.coff % 8) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0;
 }
 
 bool ssr_conv_thin_qualifies(const ssr_conv_desc& d) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_THIN"); return e && e[0] == '0'; }();
     if (off || !ssr_conv_thin_shape_ok(d)) return false;
+    // fp32 modes: opt-in (SSR_CONV_THIN_F32=1).  Measured in the fp32x3 step (call r05o, B = 32, 128 x 128): 165 us per launch against
+    // 117 us on the MFMA kernels it would replace - twice the FMAs of the bf16 form (w = hi + lo), two staging passes, three serialized
+    // 64-byte scalar loads per (tap, chunk).  If chosen, then by the LAYER's grid only: an image's bytes must not depend on how many
+    // images are launched together (whole-tile inference deals chunks to ranks and batches; conv_last is such a layer).
+    if (d.dtype != SSR_BF16) {
+        static const bool on = [] { const char* e = getenv("SSR_CONV_THIN_F32"); return e && e[0] == '1'; }();
+        return on && (long)d.Gh * d.Gw >= 4096;
+    }
     return (long)d.N * d.Gh * d.Gw >= 65536;                  // enough 256-pixel tiles to fill the chip
 }
 
 bool ssr_conv_thin_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_thin_shape_ok(d) : !ssr_conv_thin_qualifies(d)) return false;
+    if (d.dtype == SSR_F32X3) { *rc = launch_thin_f32_by_cout<true>(d, st); return true; }
+    if (d.dtype == SSR_F32) { *rc = launch_thin_f32_by_cout<false>(d, st); return true; }
     if (d.Cout == 1) *rc = launch_thin<1>(d, st);
     else if (d.Cout <= 4) *rc = launch_thin<4>(d, st);
     else *rc = launch_thin<8>(d, st);

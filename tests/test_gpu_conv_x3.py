@@ -51,9 +51,9 @@ def _reference(d, w, bias, xb, y_init, r1, r2, m, up=1, cin=None):
 VARIANTS = ["plain", "lrelu", "lrelu_r1_y0", "mask", "mask_acc", "mask_r1", "generic"]
 
 
-def _run_3x3(variant, cin, cout, H, W, B, up=1, impl=4):
+def _run_3x3(variant, cin, cout, H, W, B, up=1, impl=4, mode="fp32x3"):
     engine, hip = _mods()
-    dt = hip.F32X3
+    dt = hip.dtype_code(mode)
     torch.manual_seed(cin + cout + H + len(variant))
     st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], dt)
     st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
@@ -201,6 +201,28 @@ def test_ring_x3_conv(variant, cin, cout, H, W, B):
     """every epilogue feature, the dense block's widths (4 .. 12 chunks: the ring wraps up to three times), ragged tiles, a single
     chunk (no refill), three 32-channel output groups"""
     _run_3x3(variant, cin, cout, H, W, B, impl=6)
+
+
+# ---- the thin-output VALU kernel of the fp32 modes (csrc/conv_thin.hip, conv_thin_f32_kernel), forced through ssr_conv2d_impl(impl = 5) ----
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 3, 32, 64, 2), (64, 1, 24, 40, 1), (40, 8, 9, 33, 2), (8, 4, 16, 16, 1), (24, 3, 8, 32, 3), (48, 5, 17, 5, 1)])
+def test_thin_output_conv_fp32_modes(mode, variant, cin, cout, H, W, B):
+    """conv9 / conv_last / conv0's dgrad (discriminator_arch.py:40,69; rrdbnet_arch.py:113,136): 1 .. 8 output channels, one or two
+    32-channel staging passes, a half-filled last 16-channel chunk (24, 40), ragged tiles, every epilogue feature"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=5, mode=mode)
+
+
+def test_thin_output_kernel_stays_opt_in_in_the_fp32_modes():
+    """measured slower than the MFMA kernels in the fp32x3 step (csrc/conv_thin.hip, ssr_conv_thin_qualifies): not the automatic choice,
+    at any batch"""
+    engine, hip = _mods()
+    for B in (1, 32):
+        st = engine.ParamStore([engine.ConvSpec("h", 3, 64, 3, 1, True, False)], hip.F32X3)
+        cb = engine._ConvBuilder(st, B)
+        x, y = torch.zeros(B, 128, 128, 64, device="cuda"), torch.zeros(B, 128, 128, 8, device="cuda")
+        d = cb.conv(engine.Launcher(), "h", hip.view(x), 128, 128, hip.view(y), cin=64)
+        assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 != 7
 
 
 @pytest.mark.parametrize("c1,c2,cout", [(96, 64, 32), (32, 64, 32), (128, 64, 64), (16, 64, 32)])

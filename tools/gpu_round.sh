@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 PYT="python -m pytest -q -p no:cacheprovider"
 PMC_BENCH="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1500 $PYT tests -m gpu --durations=12 -s ${PYTEST_ARGS:-} > $O/${TAG}_tests.log 2>&1
+  timeout 1800 $PYT tests -m gpu --durations=12 -s ${PYTEST_ARGS:-} > $O/${TAG}_tests.log 2>&1
   echo "pytest rc=$?" >> $O/${TAG}_tests.log
   grep -E "passed|failed|rc=" $O/${TAG}_tests.log | tail -5
   grep -E "^(FAILED|ERROR)" $O/${TAG}_tests.log | head -40

@@ -530,10 +530,17 @@ def main():
             out["parity_mode"] = legs["fp32x3"]
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, c_in, c_d)
-    if ctx.rank == 0:
-        print(json.dumps(out))
+    # the process group goes first: whatever the backend writes while it shuts down, the JSON line stays the LAST line of stdout
     if ctx.active:
         torch.distributed.destroy_process_group()
+        try:      # RCCL's start-up banner ("Hostname : ...", "Librccl path : ...") sits in the C library's stdout buffer until exit: emit it now
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if ctx.rank == 0:
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

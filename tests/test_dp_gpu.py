@@ -135,6 +135,27 @@ def test_bench_n_ranks_on_one_gpu_prints_one_json_line(world):
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
 
 
+@pytest.mark.gpu
+def test_bench_over_rccl_ends_stdout_with_the_json_line():
+    """backend nccl (= RCCL), data-parallel branch forced at world size 1: RCCL writes a start-up banner ("RCCL version : ...",
+    "Librccl path : ...") through the C library's buffered stdout, which used to surface at process exit - BEHIND the JSON line.
+    A reader that takes the last line of stdout must find the JSON."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSR_DP_FORCE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SSR_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "2", "--batch", "2", "--blocks", "1", "--no-cpu-baseline",
+           "--blocks-timed", "0", "--no-legs"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    out = json.loads(lines[-1])                                # the LAST line
+    assert sum(ln.startswith("{") for ln in lines) == 1 and out["losses_finite"] and out["dtype"] == "fp32x3"
+
+
 def _rccl_worker(port, outdir):
     """one rank, backend nccl (= RCCL on ROCm), data-parallel branch forced: phase graphs captured in thread-local mode,
     RCCL all-reduces of both gradient arenas on the side stream between them, event waits, 1/world in Adam."""

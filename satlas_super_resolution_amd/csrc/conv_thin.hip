@@ -98,20 +98,27 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ssr_conv_desc d) {
 }
 
 // ---- fp32 storage (SSR_F32 exact, SSR_F32X3 split-bf16 weights), round 5 ----
-// The same layers in the fp32 modes run on the pipelined MFMA kernels: 117 us each at B = 32 (conv9 x 3, conv_last, conv0's
-// dgrad: 0.59 ms of the fp32x3 step) for 0.6-4.8 GFLOP.  This form is correct (tests/test_gpu_conv_x3.py) but SLOWER there (165 us,
-// see ssr_conv_thin_qualifies) and therefore opt-in.  One thread = one pixel again; the input is staged 32 channels at a time
-// (144-byte rows: consecutive lanes 36 banks apart; 49 KB per workgroup, three workgroups per CU), the products are fp32 FMAs
-// against wave-uniform weights read with scalar loads from the packed rows [chunk16][tap][CoutPad][16]: plain fp32 in the exact
-// mode; [16 hi | 16 lo] bf16 in the split mode, where w = hi + lo enters as two FMAs (activations stay exact fp32: the result is
-// at least as accurate as the three-product MFMA form, 2^-17 per weight).
+// The same layers in the fp32 modes ran on the pipelined MFMA kernels: 111-117 us each at B = 32 (conv9 x 3, conv_last, conv0's
+// dgrad: 0.56 ms of the fp32x3 step) for 0.6-4.8 GFLOP - a 32-wide MFMA tile is 91-97 % padding there.  One thread = one pixel again:
+//   * the input is staged 32 channels at a time (144-byte rows: consecutive lanes 36 banks apart -> conflict-free ds_read_b128);
+//   * the layer's weights become ONE fp32 table in LDS, [tap][ci][NCOP] (NCOP = 1, 4 or 8), built once per workgroup from the packed
+//     rows [chunk16][tap][CoutPad][16]: plain fp32 in the exact mode, w = hi + lo of the [16 hi | 16 lo] bf16 rows in the split mode
+//     (activations stay exact fp32: at least as accurate as the three-product MFMA form, 2^-17 per weight);
+//   * the inner loop is a pixel vector (4 channels) + the weight vectors of those channels - all lanes read the SAME address:
+//     a broadcast - and one fp32 FMA per product.
+// (A first form read the packed rows with 64-byte scalar loads and converted hi / lo in the scalar unit: 165 us per launch - three
+//  serialized scalar-load latencies per (tap, chunk) and twice the FMAs, call r05o; with the LDS table 107 us; with all staging loads of
+//  a pass in flight and the next pass requested before the current one is contracted 79 us, call r05v.)
 constexpr int CTF_CB = 32, CTF_ROWB = CTF_CB * 4 + 16;        // channels staged per pass, bytes per LDS row
+constexpr int CTF_PATCH = CT_NPIX * CTF_ROWB;                 // 48,960 B
 
 template <int NCO, bool X3>
 __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc d) {
+    constexpr int NCOP = NCO == 1 ? 1 : NCO <= 4 ? 4 : 8;     // weight-table columns (a 16-byte vector holds 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem + CTF_PATCH);   // [tap][cin16][NCOP], cin16 = Cin rounded up to 16
     const int tid = threadIdx.x;
-    const int cin = d.Cin;
+    const int cin = d.Cin, cin16 = (cin + 15) & ~15;
     const int tiles_x = (d.Gw + CT_TW - 1) / CT_TW, tiles_y = (d.Gh + CT_TH - 1) / CT_TH;
     int b = blockIdx.x;
     const int tx_i = b % tiles_x; b /= tiles_x;
@@ -122,63 +129,88 @@ __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc 
     const char* __restrict__ wg = reinterpret_cast<const char*>(d.w);
     const int ty = tid >> 5, tx = tid & 31;
     const char* pb = smem + (ty * CT_PW + tx) * CTF_ROWB;
-    float acc[NCO];
+    float acc[NCOP];
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) acc[c] = 0.f;
-    for (int c0 = 0; c0 < cin; c0 += CTF_CB) {
-        if (c0) __syncthreads();                              // everyone is finished with the previous 32 channels
-        // ---- stage channels [c0, c0 + 32) of the halo patch: vector v = pixel * 8 + part ----
-        for (int v = tid; v < CT_NPIX * 8; v += 256) {
-            const int pix = v >> 3, part = v & 7;
-            const int py = pix / CT_PW, px = pix - py * CT_PW;
-            const int ly = gy0 + py - 1, lx = gx0 + px - 1;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi && c0 + part * 4 < cin)
-                val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + c0 + part * 4);
-            *reinterpret_cast<u32x4*>(smem + pix * CTF_ROWB + part * 16) = val;
+    for (int c = 0; c < NCOP; ++c) acc[c] = 0.f;
+    // ---- staging of 32 channels of the halo patch: vector q of a thread = slot tid + 256 q = pixel slot / 8, part slot % 8.  ALL loads of a
+    //      pass are issued before the first store (a load - wait - store loop costs one memory latency per vector: 11 in a row, twice),
+    //      through clamped addresses (a lane outside the image or the channel range reads pixel 0 and keeps zeros), and the next pass
+    //      is requested before the current one is contracted ----
+    constexpr int NSV = (CT_NPIX * 8 + 255) / 256;             // 11
+    int sofs[NSV];                                             // element offset of the vector's pixel (-1: zeros)
+#pragma unroll
+    for (int q = 0; q < NSV; ++q) {
+        const int v = tid + q * 256, pix = v >> 3;
+        const int py = pix / CT_PW, px = pix - py * CT_PW;
+        const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+        const bool ok = v < CT_NPIX * 8 && ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi;
+        sofs[q] = ok ? ((n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + (v & 7) * 4 : -1;
+    }
+    u32x4 sv[NSV];
+    auto load_pass = [&](int c0) {                              // (the zeroing waits for the data: it happens at the store)
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const bool ok = sofs[q] >= 0 && c0 + ((tid + q * 256) & 7) * 4 < cin;
+            sv[q] = *reinterpret_cast<const u32x4*>(xg + (ok ? sofs[q] + c0 : 0));
         }
-        __syncthreads();
-        // a 16-channel chunk at a time: the NCO (<= 4 at once) packed rows of (chunk, tap) arrive as whole 64-byte scalar loads, then
-        // four pixel vectors x 4 channels run against them (padded channels: zero weights against zero pixels)
-        const int n16 = (min(cin - c0, CTF_CB) + 15) >> 4;
-        constexpr int CG = NCO > 4 ? 4 : NCO;
+    };
+    auto store_pass = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int v = tid + q * 256;
+            const bool ok = sofs[q] >= 0 && c0 + (v & 7) * 4 < cin;
+            if (v < CT_NPIX * 8) *reinterpret_cast<u32x4*>(smem + (v >> 3) * CTF_ROWB + (v & 7) * 16) = ok ? sv[q] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_pass(0);
+    // ---- the weight table (padded channels / outputs: the packed rows hold zeros there) ----
+    for (int e = tid; e < 9 * cin16 * NCOP; e += 256) {
+        const int c = e % NCOP, q = e / NCOP, ci = q % cin16, tap = q / cin16;
+        float w = 0.f;
+        if (c < NCO) {
+            const char* row = wg + ((size_t)((ci >> 4) * 9 + tap) * d.CoutPad + c) * 64;
+            if (X3) {
+                const unsigned short h = reinterpret_cast<const unsigned short*>(row)[ci & 15], l = reinterpret_cast<const unsigned short*>(row)[16 + (ci & 15)];
+                w = __builtin_bit_cast(float, (unsigned)h << 16) + __builtin_bit_cast(float, (unsigned)l << 16);
+            } else {
+                w = reinterpret_cast<const float*>(row)[ci & 15];
+            }
+        }
+        wl[e] = w;
+    }
+    store_pass(0);
+    __syncthreads();                                           // patch pass 0 + the weight table
+    for (int c0 = 0; c0 < cin; c0 += CTF_CB) {
+        const bool more = c0 + CTF_CB < cin;
+        if (more) load_pass(c0 + CTF_CB);
+        const int nk = (min(cin16 - c0, CTF_CB)) >> 2;         // 4-channel groups of this pass: 4 or 8
         for (int tap = 0; tap < 9; ++tap) {
             const char* pr = pb + ((tap / 3) * CT_PW + tap % 3) * CTF_ROWB;
-            for (int h = 0; h < n16; ++h) {
-                const char* wk = wg + ((size_t)(((c0 >> 4) + h) * 9 + tap) * d.CoutPad) * 64;    // uniform: scalar loads
+            const float* wt = wl + (tap * cin16 + c0) * NCOP;
+            for (int k = 0; k < nk; ++k) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(pr + k * 16);
+                if constexpr (NCOP == 1) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wt + 4 * k);          // the 4 channels' weights: one broadcast read
+                    acc[0] = fmaf(xv.x, w.x, acc[0]); acc[0] = fmaf(xv.y, w.y, acc[0]);
+                    acc[0] = fmaf(xv.z, w.z, acc[0]); acc[0] = fmaf(xv.w, w.w, acc[0]);
+                } else {
 #pragma unroll
-                for (int cg = 0; cg < NCO; cg += CG) {
-                    u32x4 row[CG][4];
+                    for (int j = 0; j < 4; ++j) {
+                        const float xj = j == 0 ? xv.x : j == 1 ? xv.y : j == 2 ? xv.z : xv.w;
 #pragma unroll
-                    for (int c = 0; c < CG; ++c)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) row[c][q] = *reinterpret_cast<const u32x4*>(wk + (cg + c) * 64 + q * 16);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(pr + (h * 4 + k) * 16);
-#pragma unroll
-                        for (int c = 0; c < CG; ++c) {
-                            float a = acc[cg + c];
-                            if (X3) {   // row = [16 hi | 16 lo] bf16: channels 4k .. 4k + 3 are dwords 2k, 2k + 1 of each half
-                                const unsigned h0 = row[c][k >> 1][(2 * k) & 3], h1 = row[c][k >> 1][(2 * k + 1) & 3];
-                                const unsigned l0 = row[c][2 + (k >> 1)][(2 * k) & 3], l1 = row[c][2 + (k >> 1)][(2 * k + 1) & 3];
-                                a = fmaf(xv.x, __builtin_bit_cast(float, l0 << 16), a);
-                                a = fmaf(xv.y, __builtin_bit_cast(float, l0 & 0xffff0000u), a);
-                                a = fmaf(xv.z, __builtin_bit_cast(float, l1 << 16), a);
-                                a = fmaf(xv.w, __builtin_bit_cast(float, l1 & 0xffff0000u), a);
-                                a = fmaf(xv.x, __builtin_bit_cast(float, h0 << 16), a);
-                                a = fmaf(xv.y, __builtin_bit_cast(float, h0 & 0xffff0000u), a);
-                                a = fmaf(xv.z, __builtin_bit_cast(float, h1 << 16), a);
-                                a = fmaf(xv.w, __builtin_bit_cast(float, h1 & 0xffff0000u), a);
-                            } else {
-                                const f32x4 w = __builtin_bit_cast(f32x4, row[c][k]);
-                                a = fmaf(xv.x, w.x, a); a = fmaf(xv.y, w.y, a); a = fmaf(xv.z, w.z, a); a = fmaf(xv.w, w.w, a);
-                            }
-                            acc[cg + c] = a;
+                        for (int c4 = 0; c4 < NCOP / 4; ++c4) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (4 * k + j) * NCOP + 4 * c4);
+                            acc[4 * c4] = fmaf(xj, w.x, acc[4 * c4]); acc[4 * c4 + 1] = fmaf(xj, w.y, acc[4 * c4 + 1]);
+                            acc[4 * c4 + 2] = fmaf(xj, w.z, acc[4 * c4 + 2]); acc[4 * c4 + 3] = fmaf(xj, w.w, acc[4 * c4 + 3]);
                         }
                     }
                 }
             }
+        }
+        if (more) {
+            __syncthreads();                                  // everyone is finished with these 32 channels
+            store_pass(c0 + CTF_CB);
+            __syncthreads();
         }
     }
     // ---- epilogue (ssr_conv_desc contract) on this pixel's Cout values ----
@@ -213,9 +245,17 @@ __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc 
 
 template <int NCO, bool X3>
 int launch_thin_f32(const ssr_conv_desc& d, hipStream_t st) {
-    const size_t lds = (size_t)CT_NPIX * CTF_ROWB;             // 48,960 B: under the default limit
+    constexpr int NCOP = NCO == 1 ? 1 : NCO <= 4 ? 4 : 8;
+    const size_t lds = (size_t)CTF_PATCH + (size_t)9 * ((d.Cin + 15) & ~15) * NCOP * 4;     // <= 67,392 B
+    auto kern = conv_thin_f32_kernel<NCO, X3>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CTF_PATCH + 9 * 64 * 8 * 4);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
     const int tiles = d.N * ((d.Gh + CT_TH - 1) / CT_TH) * ((d.Gw + CT_TW - 1) / CT_TW);
-    hipLaunchKernelGGL((conv_thin_f32_kernel<NCO, X3>), dim3(tiles), dim3(256), lds, st, d);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }
@@ -259,13 +299,12 @@ bool ssr_conv_thin_shape_ok(const ssr_conv_desc& d) {
 bool ssr_conv_thin_qualifies(const ssr_conv_desc& d) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_THIN"); return e && e[0] == '0'; }();
     if (off || !ssr_conv_thin_shape_ok(d)) return false;
-    // fp32 modes: opt-in (SSR_CONV_THIN_F32=1).  Measured in the fp32x3 step (call r05o, B = 32, 128 x 128): 165 us per launch against
-    // 117 us on the MFMA kernels it would replace - twice the FMAs of the bf16 form (w = hi + lo), two staging passes, three serialized
-    // 64-byte scalar loads per (tap, chunk).  If chosen, then by the LAYER's grid only: an image's bytes must not depend on how many
-    // images are launched together (whole-tile inference deals chunks to ranks and batches; conv_last is such a layer).
+    // fp32 modes: by the LAYER's grid only (64 x 64 pixels and up) - an image's bytes must not depend on how many images are launched
+    // together (whole-tile inference deals chunks to ranks and batches; conv_last is such a layer).  Measured in the fp32x3 step
+    // (call r05v, B = 32, 128 x 128): 79 us per launch against 117 us on the MFMA kernel; SSR_CONV_THIN_F32=0 switches it off.
     if (d.dtype != SSR_BF16) {
-        static const bool on = [] { const char* e = getenv("SSR_CONV_THIN_F32"); return e && e[0] == '1'; }();
-        return on && (long)d.Gh * d.Gw >= 4096;
+        static const bool off32 = [] { const char* e = getenv("SSR_CONV_THIN_F32"); return e && e[0] == '0'; }();
+        return !off32 && (long)d.Gh * d.Gw >= 4096;
     }
     return (long)d.N * d.Gh * d.Gw >= 65536;                  // enough 256-pixel tiles to fill the chip
 }

@@ -213,15 +213,18 @@ def test_thin_output_conv_fp32_modes(mode, variant, cin, cout, H, W, B):
     _run_3x3(variant, cin, cout, H, W, B, impl=5, mode=mode)
 
 
-def test_thin_output_kernel_stays_opt_in_in_the_fp32_modes():
-    """measured slower than the MFMA kernels in the fp32x3 step (csrc/conv_thin.hip, ssr_conv_thin_qualifies): not the automatic choice,
-    at any batch"""
+def test_thin_output_kernel_is_chosen_by_layer_not_by_batch():
+    """the fp32 modes' heads at 128 x 128 run on the VALU kernel at every batch size (an image's bytes must not depend on the batch);
+    small grids stay on the MFMA kernels"""
     engine, hip = _mods()
     for B in (1, 32):
         st = engine.ParamStore([engine.ConvSpec("h", 3, 64, 3, 1, True, False)], hip.F32X3)
         cb = engine._ConvBuilder(st, B)
         x, y = torch.zeros(B, 128, 128, 64, device="cuda"), torch.zeros(B, 128, 128, 8, device="cuda")
         d = cb.conv(engine.Launcher(), "h", hip.view(x), 128, 128, hip.view(y), cin=64)
+        assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 7
+        x, y = torch.zeros(B, 32, 32, 64, device="cuda"), torch.zeros(B, 32, 32, 8, device="cuda")
+        d = cb.conv(engine.Launcher(), "h", hip.view(x), 32, 32, hip.view(y), cin=64)
         assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 != 7
 
 

@@ -322,3 +322,33 @@ def test_wgrad_items_are_paired_without_losing_or_duplicating_work():
     assert costs == sorted(costs, reverse=True) and order[0].nco == 2
     # the simulated balance never makes the launch longer
     assert wb._makespan(wb._balance(paired)) <= wb._makespan(paired)
+
+
+def test_wgrad_batches_of_the_split_mode_pick_the_one_pass_kernel_for_3x3_layers_only(monkeypatch):
+    """engine.WgradBatch in the fp32x3 mode: 3x3 stride-1 layers read the fp32 buffers themselves (csrc/wgrad_x3.hip: 8 x 16-pixel
+    tiles, paired 64-channel items, as many pixels per item as the bf16 kernel's), 4x4 stride-2 layers keep the split pass + three
+    bf16 launches, SSR_X3_WGRAD_FUSED=0 restores the older form everywhere; the pairing rules are the bf16 kernel's."""
+    from satlas_super_resolution_amd import engine, hip
+    V = hip.View
+    monkeypatch.delenv("SSR_X3_WGRAD_FUSED", raising=False)
+    wb = engine.WgradBatch(hip.F32X3, 3, 1)
+    assert wb.kdt == hip.F32X3
+    assert engine.WgradBatch(hip.F32X3, 4, 2).kdt == hip.BF16 and engine.WgradBatch(hip.BF16, 3, 1).kdt == hip.BF16
+    assert engine.WgradBatch(hip.F32, 3, 1).kdt == hip.F32
+    monkeypatch.setenv("SSR_X3_WGRAD_FUSED", "0")
+    assert engine.WgradBatch(hip.F32X3, 3, 1).kdt == hip.BF16
+    monkeypatch.delenv("SSR_X3_WGRAD_FUSED")
+    base = 0x10000000
+    for k in range(5):                                            # one dense block at B = 16 (a half-batch chain of the step)
+        cin, cout = 64 + 32 * k, (64 if k == 4 else 32)
+        dy = V(base + 0x1000000, 192, 64 + 32 * k) if k < 4 else V(base + 0x2000000, 192, 0)
+        wb.add(V(base, 192, 0), dy, 16, 32, 32, 1, cin, cout, 32, 32, 1.0, 0x5000 + 64 * k, cin, 0x6000)
+    wb.add(V(base + 0x9000000, 64, 0), V(base + 0xa000000, 64, 0), 16, 128, 128, 1, 64, 64, 128, 128, 1.0, 0x7000, 64, 0x8000)
+    body = [it for it in wb.items if it.layer < 5]
+    assert all((it.tile_begin, it.tile_end) == (0, 16 * 4 * 2) for it in body)        # 8 x 16 tiles: 128 per layer, one pixel range
+    assert len(body) == 1 + 2 + 2 + 3 + 2 * 3                                          # ci chunks of 64: 1, 2, 2, 3 and 3 x two co blocks
+    big = [it for it in wb.items if it.layer == 5]
+    assert len(big) == 2 * (16 * 16 * 8 // 256) and all(it.atomic == 1 for it in big)  # 2048 tiles in ranges of 256, two co blocks
+    paired = wb._pair(wb.items)
+    assert sum(it.nco == 2 for it in paired if it.layer < 5) == 6                      # as the bf16 kernel: 6 pairs + 2 singles per block
+    assert hip.lib().ssr_wgrad_tiles(16, 32, 32, wb.kdt, 3) == 128

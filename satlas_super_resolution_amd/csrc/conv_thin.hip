@@ -41,15 +41,30 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ssr_conv_desc d) {
     const int gy0 = ty_i * CT_TH, gx0 = tx_i * CT_TW;
     const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(d.x.p);
     const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(d.w);
-    // ---- stage the halo patch: vector v = pixel * nvec + part ----
-    for (int v = tid; v < CT_NPIX * nvec; v += 256) {
-        const int pix = v / nvec, part = v - pix * nvec;
-        const int py = pix / CT_PW, px = pix - py * CT_PW;
-        const int ly = gy0 + py - 1, lx = gx0 + px - 1;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi)
-            val = *reinterpret_cast<const u32x4*>(xg + ((size_t)(n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + part * 8);
-        *reinterpret_cast<u32x4*>(smem + pix * rowb + part * 16) = val;
+    // ---- stage the halo patch: vector v = pixel * nvec + part.  All loads are issued before the first store (a load - wait - store
+    //      loop is a chain of memory latencies: DESIGN.md lesson 60), through clamped addresses; lanes outside the image keep zeros ----
+    {
+        constexpr int NSV = (CT_NPIX * 8 + 255) / 256;        // 11 at 64 channels
+        const int total = CT_NPIX * nvec;
+        const float rn = 1.0f / (float)nvec;                  // v / nvec without an integer division: exact for v < 2720, nvec <= 8
+        u32x4 sv[NSV];
+        unsigned okm = 0;
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int v = tid + q * 256;
+            const int pix = (int)(((float)v + 0.5f) * rn), part = v - pix * nvec;
+            const int py = pix / CT_PW, px = pix - py * CT_PW;
+            const int ly = gy0 + py - 1, lx = gx0 + px - 1;
+            const bool ok = v < total && ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi;
+            okm |= ok ? 1u << q : 0u;
+            sv[q] = *reinterpret_cast<const u32x4*>(xg + (ok ? ((size_t)(n * d.Hi + ly) * d.Wi + lx) * d.x.cs + d.x.coff + part * 8 : (size_t)0));
+        }
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int v = tid + q * 256;
+            const int pix = (int)(((float)v + 0.5f) * rn), part = v - pix * nvec;
+            if (v < total) *reinterpret_cast<u32x4*>(smem + pix * rowb + part * 16) = (okm >> q) & 1u ? sv[q] : u32x4{0u, 0u, 0u, 0u};
+        }
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
@@ -292,7 +307,9 @@ bool ssr_conv_thin_shape_ok(const ssr_conv_desc& d) {
     if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p || d.up != 1 || d.fix_list) return false;
     if (d.Cin > 64 || (d.Cin % 8) != 0 || d.Cout > 8 || d.Cout < 1) return false;
     if (d.Gh != d.Hi || d.Gw != d.Wi) return false;
-    if (f32) return (d.x.cs % 4) == 0 && (d.x.coff % 4) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0;
+    if (f32)   // (the fp32 form keeps 32-bit element offsets of its staging vectors)
+        return (d.x.cs % 4) == 0 && (d.x.coff % 4) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0 &&
+               (long)d.N * d.Hi * d.Wi * d.x.cs < 0x7fffff00L;
     return (d.x.cs % 8) == 0 && (d.x.coff % 8) == 0 && ((uintptr_t)d.x.p % 16) == 0 && ((uintptr_t)d.w % 16) == 0;
 }
 

@@ -16,8 +16,9 @@
 //   * workgroups are persistent over images (same tile position, the image is a scalar offset): the chunk stream crosses image
 //     boundaries; every staging load is one unconditional buffer load (an out-of-range offset reads zeros);
 //   * operands swapped (A = weights, B = pixels): a lane ends with ONE pixel x 16 channels per channel tile, i.e. four 16-byte
-//     fp32 vectors - the epilogue loads its operands and stores its results as 16-byte vectors straight from / to memory (no LDS
-//     transpose: that was a bf16 problem), full ssr_conv_desc contract.
+//     fp32 vectors; the epilogue (full ssr_conv_desc contract) is straight-line code in four variants picked per image and sends
+//     each pixel tile through a wave-private LDS slab, so that a load / store instruction covers the whole 256-byte rows of four
+//     pixels (see `epilogue_impl`: the first form tested its feature flags per element and cost as much as the MFMAs).
 // Same descriptor, packed-weight layout ([chunk16][tap][CoutPad][16 hi | 16 lo]) and results (to fp32 summation order) as
 // conv_x3_kernel.
 //

@@ -22,7 +22,7 @@
 //     All polls are inline asm (a compiler-visible LDS read drains the wave's loads first: vmcnt(0));
 //   * the second pixel row of a tile is rotated by 14 columns (conv_big.hip's map): every 16-lane read group touches LDS rows that
 //     are distinct mod 16 under every tap shift - conflict-free ds_read_b128; conv_epilogue<float, 14> undoes it.
-// A workgroup = 8 x 16 pixels x 32 NT output channels, ring of 4 (NT = 2: 2) stages; the same tile, packed weights
+// A workgroup = 8 x 16 pixels x 32 NT output channels, ring of 2 stages (NT = 1: two 16-channel chunks per stage); the same tile, packed weights
 // ([chunk16][tap][CoutPad][16 hi | 16 lo]), epilogue contract and - up to fp32 summation order - results as conv_x3_kernel.
 //
 // Replaces nn.Conv2d 3x3 forward and dgrad of the dense blocks, /root/reference/ssr/archs/rrdbnet_arch.py:26-30,37-44 (and any other

@@ -875,6 +875,9 @@ bool ssr_conv_bigx3_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, in
 // producer / MFMA-wave ring kernel of the split-bf16 mode for small grids (conv_x3q.hip)
 bool ssr_conv_x3q_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
 bool ssr_conv_x3q_qualifies(const ssr_conv_desc& d);
+// register-tiled kernel of the split-bf16 mode for small grids, round 6 (conv_x3r.hip): takes the ring kernel's layers
+bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force);
+bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d);
 
 extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_S2D"); return e && e[0] == '0'; }();
@@ -892,6 +895,8 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
     if (dp->dtype != SSR_BF16 && ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;        // digit 7 = thin-output VALU kernel
     if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
+    if (dp->dtype == SSR_F32X3 && ssr_conv_x3r_qualifies(*dp))
+        return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 5;                              // digit 5 = register-tiled, K split over four waves (conv_x3r.hip)
     if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
         return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
     if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
@@ -934,8 +939,10 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
         if (impl == 4) return ssr_conv_bigx3_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
         if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
         if (impl == 6) return ssr_conv_x3q_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 7) return ssr_conv_x3r_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
         if (impl == 0 && ssr_conv_thin_try(d, st, &rc, false)) return rc;
         if (impl == 0 && ssr_conv_bigx3_try(d, st, &rc, false)) return rc;
+        if (impl == 0 && ssr_conv_x3r_try(d, st, &rc, false)) return rc;
         if (impl == 0 && ssr_conv_x3q_try(d, st, &rc, false)) return rc;
         if (d.KH == 3 && d.KW == 3 && d.stride == 1) return dispatch_tile_x3<3, 3>(d, st);
         if (d.KH == 2 && d.KW == 2 && d.stride == 1) return dispatch_tile_x3<2, 2>(d, st);

@@ -1,0 +1,529 @@
+// Split-bf16 (SSR_F32X3) 3x3 stride-1 convolution for the small-spatial generator body, round 6: 4 x 1 REGISTER TILING.  One MFMA
+// wave owns ALL four 32-pixel tiles of the workgroup's 8 x 16 pixels for a quarter of the contraction (K split over four waves, one
+// per SIMD); weight fragments go from L2 straight into registers - they never touch the LDS - and only the patch is staged.
+//
+// Why (round-5 counters of conv_x3q.hip, the kernel this replaces on the 32 x 32 body: 0.18 / 0.27 of 833 TF): with one pixel tile
+// per wave a (chunk, tap) step reads 2 pixel + 2 weight fragments from LDS for 3 MFMAs, the weight rows of a chunk (23 KB) are
+// copied global -> registers -> LDS by the MFMA waves first, and the ring holds 150 KB.  A stage moved 288 KB of fragment reads +
+// 75 KB of stores for 216 MFMAs, and the twelve waves met at a flag every 27 MFMAs.  Here, per (chunk, tap):
+//   * a wave issues 2 (NT = 2: 4) buffer loads of pre-split weight fragments ([chunk16][tap][CoutPad][16 hi | 16 lo] rows: lane
+//     (i, g) takes 16 bytes at row i, byte 16 g, and 32 bytes further) - every weight byte is fetched ONCE per workgroup, as before,
+//     but by the wave that multiplies with it, several steps ahead (WR steps deep in registers);
+//   * 8 ds_read_b128 of pixel fragments feed 12 (24) MFMAs: 0.67 KB of LDS reads per MFMA instead of 1.33, no weight stores;
+//   * the LDS holds the patch only: 14.4 KB per 16-channel chunk, an EIGHT-stage ring (the dense block's 4 .. 12 chunks: the
+//     producers run a whole conv1 / conv2 / conv3 ahead and never wait for ring space there);
+//   * hand-over: producer wave p counts the chunks it has stored in pdone[p], MFMA wave w the chunks it has finished reading in
+//     cdone[w]; a wave polls only when the count it saw last no longer covers the chunk it needs (one ds_read_b128 = all four words).
+// Work split: the 3 x nchunks (chunk, tap row) items go round-robin to the four MFMA waves (item g -> wave g & 3), three taps each;
+// every wave walks the chunks at the same pace.  The four K-quarters of a tile are summed in wave order 0 .. 3 through LDS (fixed
+// order: an image's bytes do not depend on the batch or on timing), wave m finishes pixel tile m; NT = 2: the four producer waves
+// finish the second 32-channel tile, so eight waves run the epilogue.
+// Epilogue: the dense block's three forms (bias + LeakyReLU; alpha (acc + bias) + beta1 r1 + beta2 r2; LeakyReLU-backward mask)
+// are straight-line code in the TRANSPOSED domain - the finished 32 x 32 tile goes through a 4-KB LDS slab, then every lane owns
+// 4 channels of 4 pixels: residual / mask loads and the result stores are whole 128-byte pixel rows by 16-byte buffer
+// instructions, absent operands read zeros through an out-of-range offset (DESIGN.md lessons 2, 52).  Everything else takes
+// conv_epilogue<float, 14> (conv_epilogue.h), the contract's generic form.
+//
+// Same tile, packed weights and per-acc product order (a_lo w_hi + a_hi w_lo + a_hi w_hi) as conv_x3q_kernel; results agree with it
+// up to the fp32 summation order of the K-quarters.
+//
+// Replaces nn.Conv2d 3x3 forward and dgrad of the dense blocks, /root/reference/ssr/archs/rrdbnet_arch.py:26-30,37-44 (and any
+// other stride-1 3x3 layer on a small grid) in the fp32x3 arithmetic mode.
+#include "conv_epilogue.h"
+#include <cstdlib>
+
+#ifdef SSR_PROBE   // tools/x3r_probe.hip: s_memtime stamps of one thread per role, 16 slots per workgroup
+#define RPROBE(cond, k) do { if (cond) g_probe[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RPROBE(cond, k)
+#endif
+
+namespace {
+
+constexpr int XR_NMFMA = 4, XR_NPROD = 4, XR_NTHR = 64 * (XR_NMFMA + XR_NPROD);
+constexpr int XR_ROWB = 80, XR_PH = 10, XR_PW = 18, XR_NPIX = XR_PH * XR_PW;       // 8 x 16 tile + halo, rows [16 hi | 16 lo | pad]
+constexpr int XR_SUB = XR_NPIX * XR_ROWB;                      // one 16-channel chunk of the patch: 14,400 B
+constexpr int XR_NS = 8;                                       // ring stages (one chunk each)
+constexpr int XR_RING = XR_NS * XR_SUB;                        // 115,200 B
+constexpr int XR_PV = XR_NPIX * 4;                             // 16-byte vectors of a chunk's patch: 720
+constexpr int XR_NPV = (XR_PV + 255) / 256;                    // per producer thread: 3
+#ifndef XR_PQ_DEPTH
+#define XR_PQ_DEPTH 4
+#endif
+constexpr int XR_PQ = XR_PQ_DEPTH;                             // patch chunks a producer keeps in flight in registers
+constexpr int XR_ROT = 14;                                     // rotation of a tile's second pixel row (32 - PW): conflict-free fragment reads
+constexpr int XR_OOB = 0x7ffffff0;
+constexpr int XR_SPIN_MAX = 1 << 22;                           // polls of a flag before a wave TRAPS (~0.3 s; a hand-over takes ~1 us)
+constexpr int XR_TILEB = 2 * XR_PW * XR_ROWB;                  // LDS bytes between the pixel tiles of a wave (two patch rows): 2,880
+constexpr int XR_SLOT = 32 * 32 * 4;                           // one 32 x 32 fp32 partial tile / one transpose slab
+
+template <int NT> struct XrT {
+    static constexpr int BN = 32 * NT;
+    static constexpr int WR = NT == 1 ? 6 : 3;                 // (chunk, tap) steps of weight fragments in flight per wave (8 / 16 registers each)
+    static constexpr int SLOTS = 4 * 4 * NT;                   // [source wave][pixel tile][channel tile] partial tiles of the K-quarter sum
+    static constexpr int RED = SLOTS * XR_SLOT;                // 64 / 128 KB (the ring is dead by then)
+    static constexpr int CTL = RED > XR_RING ? RED : XR_RING;  // control words behind both: pdone[4] | cdone[4]
+    static constexpr int LDS = CTL + 256;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xr_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffff00L ? 0x7fffff00L : (bytes < 0 ? 0 : bytes)), 0x00020000);
+}
+__device__ __forceinline__ void xr_split4(const u32x4& v, uint2& hi, uint2& lo) {
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    bf16x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = (__bf16)f[k];
+        l[k] = (__bf16)(f[k] - (float)h[k]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+typedef __attribute__((address_space(3))) int* xr_lds_int;
+
+// min of the four counters at LDS address `a` (one ds_read_b128).  Inline asm: a compiler-visible LDS read would make hipcc drain
+// the wave's global loads first (vmcnt(0)); "=&v": the output must not share registers with the address
+__device__ __forceinline__ int xr_min4(int a) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
+}
+
+enum { XR_EP_LRELU = 0, XR_EP_LIN = 1, XR_EP_MASK = 2, XR_EP_GENERIC = 3 };
+
+// the dense block's epilogues in the transposed domain: lane = (pixel slot lane >> 3 (+ 8 h), channels 4 (lane & 7) .. + 3)
+template <int EP>
+__device__ __forceinline__ void xr_epilogue(const ssr_conv_desc& d, const f32x16& acc, int co_base, int n, int gy_row0, int gx0, int lane,
+                                             char* slab) {
+    const int i = lane & 31, g = lane >> 5;
+    const int part = lane & 7, c = co_base + part * 4;
+    const bool cok = c < d.Cout;
+    const long npix = (long)d.N * d.Ho * d.Wo * 4;
+    const __amdgpu_buffer_rsrc_t rs_y = xr_rsrc(d.y.p, npix * d.y.cs);
+    int pp[4];
+    bool ok[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int pix = (lane >> 3) + 8 * h;
+        const int gy = gy_row0 + (pix >> 4), gx = gx0 + epi_col<XR_ROT>(pix);
+        ok[h] = cok && gy < d.Gh && gx < d.Gw;
+        pp[h] = (n * d.Ho + gy) * d.Wo + gx;
+    }
+    // ---- every load first ----
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) {
+        const __amdgpu_buffer_rsrc_t rs_b = xr_rsrc(d.bias, (long)d.Cout * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (c + k) * 4, 0, 0));   // beyond Cout: zeros
+    }
+    u32x4 q1[4], q2[4];
+    if constexpr (EP == XR_EP_LIN) {
+        const __amdgpu_buffer_rsrc_t rs_r1 = xr_rsrc(d.r1.p, d.r1.p ? npix * d.r1.cs : 0), rs_r2 = xr_rsrc(d.r2.p, d.r2.p ? npix * d.r2.cs : 0);
+        const bool h1 = d.r1.p != nullptr, h2 = d.r2.p != nullptr;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            q1[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, ok[h] && h1 ? (pp[h] * d.r1.cs + d.r1.coff + c) * 4 : XR_OOB, 0, 0);
+            q2[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, ok[h] && h2 ? (pp[h] * d.r2.cs + d.r2.coff + c) * 4 : XR_OOB, 0, 0);
+        }
+    }
+    if constexpr (EP == XR_EP_MASK) {
+        const __amdgpu_buffer_rsrc_t rs_m = xr_rsrc(d.m.p, npix * d.m.cs);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) q1[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, ok[h] ? (pp[h] * d.m.cs + d.m.coff + c) * 4 : XR_OOB, 0, 0);
+    }
+    // ---- transpose: [32 pixel slots][32 channels] fp32 ----
+    float* sl = reinterpret_cast<float*>(slab);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sl[mfma32_row(r, g) * 32 + i] = acc[r];
+    const float alpha = d.alpha, beta1 = d.beta1, beta2 = d.beta2;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int pix = (lane >> 3) + 8 * h;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sl + pix * 32 + part * 4);
+        if constexpr (EP == XR_EP_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu_max(v[k] + bv[k]);
+        } else if constexpr (EP == XR_EP_LIN) {
+            const f32x4 a = __builtin_bit_cast(f32x4, q1[h]), b = __builtin_bit_cast(f32x4, q2[h]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = alpha * (v[k] + bv[k]) + (beta1 * a[k] + beta2 * b[k]);
+        } else {
+            const f32x4 m = __builtin_bit_cast(f32x4, q1[h]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (v[k] + bv[k]) * lrelu_grad_from_out(m[k]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, ok[h] ? (pp[h] * d.y.cs + d.y.coff + c) * 4 : XR_OOB, 0, 0);
+    }
+}
+
+template <int NT, int EP>
+__global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d) {
+    using T = XrT<NT>;
+    constexpr int BN = T::BN, WR = T::WR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ctl = reinterpret_cast<int*>(smem + T::CTL);          // [0..3] pdone, [4..7] cdone
+    const int ctl_addr = (int)(size_t)(__attribute__((address_space(3))) char*)(smem + T::CTL);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (d.Gw + 15) / 16, tiles_y = (d.Gh + 7) / 8;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty_i * 8, gx0 = tx_i * 16;
+    const int co0 = blockIdx.y * BN;
+    const int Cin = d.Cin, Cin2 = d.Cin2;
+    const int nchunks = (Cin + Cin2 + 15) / 16;
+    const int cout_pad = d.CoutPad;
+    const int tapstride = cout_pad * 64, wchunk = 9 * tapstride;      // packed bytes per tap / per 16-channel chunk
+    RPROBE(tid == 0, 0);
+    if (tid < 8) ctl[tid] = 0;
+    __syncthreads();                                           // the only barrier before the reduce
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    if (wave >= XR_NMFMA) {
+        // =============================== producer waves: the patch ===============================
+        const int pw = wave - XR_NMFMA;
+        const int pt = tid - 64 * XR_NMFMA;                    // 0..255
+        const int part = pt & 3, p4 = pt >> 2;
+        // vector q of a thread = slot pt + 256 q: patch pixel p4 + 64 q, 16-byte part pt & 3
+        int ppix[XR_NPV];                                      // global pixel index of the patch vectors (-1: zeros)
+#pragma unroll
+        for (int q = 0; q < XR_NPV; ++q) {
+            const int pix = p4 + 64 * q;
+            const int py = pix / XR_PW, px = pix - py * XR_PW;
+            const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
+            const bool okp = pix < XR_NPIX && ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi;
+            ppix[q] = okp ? (n * d.Hi + ly) * d.Wi + lx : -1;
+        }
+        const int plo0 = p4 * XR_ROWB + part * 8;              // hi half of the row; the lo half lies 32 bytes further
+        const long xbytes = (long)d.N * d.Hi * d.Wi * 4;
+        const void* xp = d.x.p;
+        const void* x2p = d.x2.p ? d.x2.p : d.x.p;
+        const int x_cs = d.x.cs, x_coff = d.x.coff, x2_cs = d.x2.p ? d.x2.cs : d.x.cs, x2_coff = d.x2.p ? d.x2.coff : d.x.coff;
+        u32x4 rq[XR_PQ][XR_NPV];
+        auto load_chunk = [&](int c, auto jc) {                // chunk c -> register set j; past the end: zeros, no memory access
+            constexpr int j = decltype(jc)::value;
+            const bool live = c < nchunks;
+            const int c0 = c * 16;
+            const bool in_x = c0 < Cin;                        // a chunk lies in ONE of the two views (dispatcher: Cin % 16 == 0 with x2)
+            const int cb = in_x ? c0 : c0 - Cin, clim = live ? (in_x ? Cin : Cin2) : 0;
+            const int cs = in_x ? x_cs : x2_cs, coff = in_x ? x_coff : x2_coff;
+            const __amdgpu_buffer_rsrc_t rs = xr_rsrc(in_x ? xp : x2p, xbytes * cs);
+            const int k = cb + part * 4;
+#pragma unroll
+            for (int q = 0; q < XR_NPV; ++q) {
+                const int off = (ppix[q] * cs + coff + k) * 4;             // computed unconditionally, selected below: no branch around a load
+                const bool okl = (k < clim) & (ppix[q] >= 0);
+#ifdef XR_X_NOXLOAD   // (probe switch: the producers publish without loading)
+                rq[j][q] = u32x4{(unsigned)off, (unsigned)okl, 0u, 0u};
+#else
+                rq[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, okl ? off : XR_OOB, 0, 0);
+#endif
+            }
+        };
+        // (sched_barrier: hipcc otherwise REORDERS the independent loads of the sets - the last set's first - and the wait in front of
+        //  set 0's LDS store becomes vmcnt(0): the queue drains at every chunk; DESIGN.md lesson 51)
+        static_for<0, XR_PQ>([&](auto jc) { __builtin_amdgcn_sched_barrier(0); load_chunk(decltype(jc)::value, jc); __builtin_amdgcn_sched_barrier(0); });
+        RPROBE(pt == 0, 8);
+        int cfree = XR_NS;                                     // chunks below this index have a free ring place
+        for (int c0 = 0; c0 < nchunks; c0 += XR_PQ) {
+            static_for<0, XR_PQ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int c = c0 + j;
+                if (c < nchunks) {
+                    if (c >= cfree) {
+                        // the place is free once every MFMA wave has finished chunk c - NS
+                        int spin = 0;
+                        for (; spin < XR_SPIN_MAX; ++spin) {
+                            cfree = xr_min4(ctl_addr + 16) + XR_NS;
+                            if (c < cfree) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (spin == XR_SPIN_MAX) __builtin_trap();         // a protocol bug must be loud, not wrong activations
+                    }
+                    char* base = smem + (c % XR_NS) * XR_SUB;
+#pragma unroll
+                    for (int q = 0; q < XR_NPV; ++q) {
+                        uint2 hi, lo;
+                        xr_split4(rq[j][q], hi, lo);
+                        if (q < XR_NPV - 1 || pt < XR_PV - (XR_NPV - 1) * 256) {
+                            *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB) = hi;
+                            *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB + 32) = lo;
+                        }
+                    }
+                    // LDS operations of a wave execute in order: the count follows the data
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 4 * pw) = c + 1;
+                    asm volatile("" ::: "memory");
+                }
+                // refill unconditionally (past the end: out-of-range offsets) so that the number of loads in flight is the same on every
+                // path and the compiler's vmcnt bookkeeping keeps the queue PQ chunks deep
+                __builtin_amdgcn_sched_barrier(0);
+                load_chunk(c + XR_PQ, jc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        RPROBE(pt == 0, 9);
+    } else {
+        // =============================== MFMA waves: all four pixel tiles, a quarter of K ===============================
+        const int w = wave;
+        const int i = lane & 31, gq = lane >> 5;
+        const int a_lane = ((i >> 4) * XR_PW + epi_col<XR_ROT>(i)) * XR_ROWB + gq * 16;     // lane (i, g): channels 8 g .. 8 g + 7 of pixel slot i of tile 0
+        const __amdgpu_buffer_rsrc_t rsw = xr_rsrc(d.w, (long)nchunks * wchunk);
+        const int w_lane = (co0 + i) * 64 + gq * 16;
+        const int nitems = 3 * nchunks;
+        const int nj = nitems > w ? (nitems - w + 3) / 4 : 0;              // this wave's items g = w, w + 4, ...
+        const int glast = w + 4 * (nj - 1);
+        if (nj == 0) {
+            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = 0x3fffffff;
+        } else {
+            bf16x8 wf[WR][NT][2];                                          // weight fragments of WR (chunk, tap) steps: [hi | lo]
+            bf16x8 af[3][2][2];                                            // pixel fragments of three half-steps (two tiles each): [hi | lo]
+            auto load_w = [&](int g_, auto kxc, auto sc) {                 // step (item g, tap kx) -> register set s
+                constexpr int kx = decltype(kxc)::value, s = decltype(sc)::value;
+                const int gg = g_ < glast ? g_ : glast;                    // past the end: the last item again (never used)
+                const int c = gg / 3, ky = gg - 3 * c;
+                const int off = c * wchunk + (ky * 3 + kx) * tapstride + w_lane;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    wf[s][u][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, off + u * 2048, 0, 0));
+                    wf[s][u][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, off + u * 2048 + 32, 0, 0));
+                }
+            };
+            auto issue_a = [&](int base, auto kxc, auto thc, auto sc) {    // half-step (tap kx, tiles 2 th, 2 th + 1) -> register set s
+                constexpr int kx = decltype(kxc)::value, th = decltype(thc)::value, s = decltype(sc)::value;
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const char* p = smem + base + kx * XR_ROWB + (2 * th + t2) * XR_TILEB;
+                    af[s][t2][0] = *reinterpret_cast<const bf16x8*>(p);
+                    af[s][t2][1] = *reinterpret_cast<const bf16x8*>(p + 32);
+                }
+            };
+            int avail = 0;                                                 // chunks known to be in the ring
+            auto ensure = [&](int c) {
+                if (avail > c) return;
+                int spin = 0;
+                for (; spin < XR_SPIN_MAX; ++spin) {
+                    avail = xr_min4(ctl_addr);
+                    if (avail > c) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (spin == XR_SPIN_MAX) __builtin_trap();
+            };
+            auto base_of = [&](int g_) { const int c = g_ / 3, ky = g_ - 3 * c; return (c % XR_NS) * XR_SUB + ky * XR_PW * XR_ROWB + a_lane; };
+            // weights of the first WR steps (they depend on nobody), then the first chunk
+            static_for<0, WR>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(w + 4 * (s / 3), std::integral_constant<int, s % 3>{}, sc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            RPROBE(tid == 0, 1);
+            int g = w, c_cur = g / 3;
+            int base_cur = base_of(g);
+            ensure(c_cur);
+            RPROBE(tid == 0, 2);
+            issue_a(base_cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            issue_a(base_cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            // one item = three taps = six half-steps; JP = parity of the item (NT = 1: the weight ring is two items deep)
+            auto body = [&](int j, auto jpc) {
+                constexpr int JP = decltype(jpc)::value;
+                const int gn = g + 4 < glast ? g + 4 : glast;              // the next item (at the end: this one again, never used)
+                const int c_next = gn / 3;
+                const int base_next = base_of(gn);
+                static_for<0, 6>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value, kx = h / 2, th = h % 2;
+                    constexpr int ws = (JP * 3 + kx) % WR;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (h == 4) {
+                        // every fragment read of this item has been issued: the chunks below the next item's are finished
+                        if (c_next > c_cur) {
+                            asm volatile("" ::: "memory");
+                            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = c_next;
+                            asm volatile("" ::: "memory");
+                        }
+                        ensure(c_next);
+                    }
+#ifndef XR_X_NOA      // (tools/x3r_probe.hip switch: the fragment reads of the prologue are reused)
+                    if constexpr (h + 2 < 6) issue_a(base_cur, std::integral_constant<int, (h + 2) / 2>{}, std::integral_constant<int, (h + 2) % 2>{}, std::integral_constant<int, (h + 2) % 3>{});
+                    else issue_a(base_next, std::integral_constant<int, (h - 4) / 2>{}, std::integral_constant<int, (h - 4) % 2>{}, std::integral_constant<int, (h + 2) % 3>{});
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    // per accumulator: a_lo w_hi, a_hi w_lo, a_hi w_hi (conv_x3q's order); consecutive MFMAs go to different accumulators
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][1], wf[ws][u][0], acc[2 * th + t2][u], 0, 0, 0);
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][0], wf[ws][u][1], acc[2 * th + t2][u], 0, 0, 0);
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][0], wf[ws][u][0], acc[2 * th + t2][u], 0, 0, 0);
+                    if constexpr (th == 1) {                                // this step's weight registers are free: the step WR further on
+#ifndef XR_X_NOW      // (probe switch: the weight fragments of the prologue are reused)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_w(g + 4 * (WR / 3), std::integral_constant<int, kx>{}, std::integral_constant<int, ws>{});
+#endif
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                g += 4;
+                c_cur = c_next;
+                base_cur = base_next;
+#ifdef SSR_PROBE
+                if (j < 5) RPROBE(tid == 0, 3 + j);
+#endif
+            };
+            if constexpr (WR == 6) {
+                for (int j = 0; j < nj; j += 2) {
+                    body(j, std::integral_constant<int, 0>{});
+                    if (j + 1 < nj) body(j + 1, std::integral_constant<int, 1>{});
+                }
+            } else {
+                for (int j = 0; j < nj; ++j) body(j, std::integral_constant<int, 0>{});
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = 0x3fffffff;
+        }
+    }
+    __syncthreads();                                           // every wave is out of the ring: it becomes the partial-sum slots
+    RPROBE(tid == 0, 10);
+
+    // ---- sum the four K-quarters in wave order through LDS: slot [source wave][pixel tile][channel tile] = 16 registers x 64 lanes,
+    //      as four 16-byte vectors per lane ([q][lane][4]: contiguous, conflict-free); wave m keeps tile (m, 0) in registers ----
+    const bool is_mfma = wave < XR_NMFMA;
+    const int me = is_mfma ? wave : wave - XR_NMFMA;           // the pixel tile this wave finishes
+    if (is_mfma) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                if (!(t == me && u == 0)) {
+                    char* sp = smem + ((wave * 4 + t) * NT + u) * XR_SLOT + lane * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(sp + q * 1024) = v;
+                    }
+                }
+    }
+    __syncthreads();
+    const int ut = is_mfma ? 0 : 1;                            // channel tile this wave finishes
+    if (is_mfma || NT == 2) {
+        f32x16 own;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) own[r] = 0.f;
+        if (is_mfma) {                                         // runtime tile index -> static register selection
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t == me) own = acc[t][0];
+        }
+        f32x16 sum;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x16 part;
+            const char* sp = smem + ((s * 4 + me) * NT + ut) * XR_SLOT + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sp + q * 1024);
+                part[4 * q] = v[0]; part[4 * q + 1] = v[1]; part[4 * q + 2] = v[2]; part[4 * q + 3] = v[3];
+            }
+            const bool mine = is_mfma && s == me;              // (that slot was never written: its bytes are not used)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = mine ? own[r] : part[r];
+                sum[r] = s == 0 ? p : sum[r] + p;
+            }
+        }
+        // the transpose slab: a slot no other wave reads (an MFMA wave's own, never written, slot of its tile; a producer's: source wave 0's)
+        char* slab = smem + (((is_mfma ? me : 0) * 4 + me) * NT + ut) * XR_SLOT;
+        const int cb = co0 + 32 * ut;
+        if constexpr (EP == XR_EP_GENERIC) conv_epilogue<float, XR_ROT>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
+        else xr_epilogue<EP>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
+    }
+    RPROBE(tid == 0, 11);
+}
+
+template <int NT, int EP>
+int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
+    auto kern = conv_x3r_kernel<NT, EP>;
+    static bool attr_done[16] = {};                            // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XrT<NT>::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done[dev] = true;
+    }
+    const int tiles = ((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N;
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / (32 * NT), 1), dim3(XR_NTHR), XrT<NT>::LDS, st, d);
+    SSR_LAUNCH_CHECK();
+    return SSR_OK;
+}
+
+// which of the straight-line epilogues covers the descriptor (else the generic one)
+int xr_pick_epilogue(const ssr_conv_desc& d) {
+    static const bool generic_only = [] { const char* e = getenv("SSR_X3R_EPI"); return e && e[0] == '0'; }();
+    if (generic_only) return XR_EP_GENERIC;
+    const long lim = 0x7fffff00L, npx = (long)d.N * d.Ho * d.Wo * 4;
+    auto vok = [&](const ssr_view& v) { return (v.cs % 4) == 0 && (v.coff % 4) == 0 && ((uintptr_t)v.p % 16) == 0 && npx * v.cs <= lim; };
+    if (d.fix_list || d.y0.p || d.y1.p || d.accumulate || d.m_relu || (d.Cout % 4) != 0 || !vok(d.y)) return XR_EP_GENERIC;
+    if (d.oys != 1 || d.oxs != 1 || d.oyo != 0 || d.oxo != 0 || d.Ho < d.Gh || d.Wo < d.Gw) return XR_EP_GENERIC;
+    const bool r1 = d.r1.p != nullptr, r2 = d.r2.p != nullptr, m = d.m.p != nullptr;
+    if (d.act == SSR_ACT_LRELU && d.alpha == 1.f && !r1 && !r2 && !m) return XR_EP_LRELU;
+    if (d.act == SSR_ACT_NONE && !m && (!r1 || (d.r1_nc >= d.Cout && vok(d.r1))) && (!r2 || (d.r2_nc >= d.Cout && vok(d.r2)))) return XR_EP_LIN;
+    if (d.act == SSR_ACT_NONE && d.alpha == 1.f && m && !r1 && !r2 && d.m_c0 == 0 && d.m_c1 >= d.Cout && vok(d.m)) return XR_EP_MASK;
+    return XR_EP_GENERIC;
+}
+
+template <int NT>
+int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
+    switch (xr_pick_epilogue(d)) {
+        case XR_EP_LRELU: return launch_x3r<NT, XR_EP_LRELU>(d, st);
+        case XR_EP_LIN: return launch_x3r<NT, XR_EP_LIN>(d, st);
+        case XR_EP_MASK: return launch_x3r<NT, XR_EP_MASK>(d, st);
+        default: return launch_x3r<NT, XR_EP_GENERIC>(d, st);
+    }
+}
+
+}  // namespace
+
+bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d) {
+    if (d.dtype != SSR_F32X3 || d.fix_list) return false;
+    if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.up == 1 && !d.s2d)) return false;
+    if (d.Gh != d.Hi || d.Gw != d.Wi || (d.CoutPad % 32) != 0) return false;
+    if (d.x2.p && (d.Cin % 16) != 0) return false;            // a 16-channel chunk comes from ONE view
+    const long lim = 0x7fffff00L, npx = (long)d.N * d.Hi * d.Wi * 4;
+    if (npx * d.x.cs > lim || (d.x2.p && npx * d.x2.cs > lim)) return false;
+    if ((long)((d.Cin + d.Cin2 + 15) / 16) * 9 * d.CoutPad * 64 > lim) return false;
+    return true;
+}
+
+bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d) {
+    static const bool off = [] { const char* e = getenv("SSR_X3_REGTILE"); return e && e[0] == '0'; }();
+    if (off || !ssr_conv_x3r_shape_ok(d)) return false;
+    // small grids (the 32 x 32 body at any batch; conv_first / conv_body): the big-tile kernel takes the others
+    return d.Gh <= 64 && d.Gw <= 64 && d.Cin + d.Cin2 >= 16;
+}
+
+bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
+    if (force ? !ssr_conv_x3r_shape_ok(d) : !ssr_conv_x3r_qualifies(d)) return false;
+    static const bool nt2_off = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return e && e[0] == '0'; }();
+    *rc = ((d.CoutPad % 64) == 0 && !nt2_off) ? launch_x3r_ep<2>(d, st) : launch_x3r_ep<1>(d, st);
+    return true;
+}

@@ -203,6 +203,39 @@ def test_ring_x3_conv(variant, cin, cout, H, W, B):
     _run_3x3(variant, cin, cout, H, W, B, impl=6)
 
 
+# ---- the register-tiled kernel that took the body over in round 6 (csrc/conv_x3r.hip), forced through ssr_conv2d_impl(impl = 7) ----
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_r1", "lrelu_r1_y0", "mask_acc", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 32, 32, 2), (160, 32, 32, 32, 1), (192, 64, 32, 32, 2), (96, 32, 21, 37, 1), (24, 64, 9, 7, 1),
+                                            (16, 32, 8, 16, 3), (8, 32, 8, 16, 1), (128, 96, 16, 40, 1), (320, 64, 16, 16, 1), (40, 20, 24, 24, 1)])
+def test_regtile_x3_conv(variant, cin, cout, H, W, B):
+    """the three straight-line epilogues of the dense block (bias + LeakyReLU; alpha, bias, one residual; mask) and the generic one
+    (y0 / y1 / accumulate / mask + residual), 1 .. 20 chunks (one chunk: a wave without work; twenty: the eight-stage ring wraps twice),
+    ragged tiles, a half-filled chunk (24, 40), an output width that is no multiple of 32 (20), three 32-channel groups"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=7)
+
+
+def test_regtile_x3_linear_epilogue_with_two_residuals():
+    """conv5 of the third dense block of an RRDB: 0.04 (acc + b) + 0.2 x + x_rrdb (rrdbnet_arch.py:44,68) on the straight-line path"""
+    engine, hip = _mods()
+    B, H, W, cin, cout = 2, 32, 32, 192, 64
+    torch.manual_seed(7)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], hip.F32X3)
+    w = torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    st.load_state_dict({"c.weight": w, "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    mk = lambda c: (torch.randn(B, H, W, c, device="cuda") * 0.5).contiguous()
+    buf, nxt, rr = mk(192), torch.zeros(B, H, W, 192, device="cuda"), mk(192)
+    cb = engine._ConvBuilder(st, B)
+    d = cb.conv(engine.Launcher(), "c", hip.view(buf, 0), H, W, hip.view(nxt, 0), alpha=0.04, r1=hip.view(buf, 0), r1_nc=cout, beta1=0.2,
+                r2=hip.view(rr, 0), r2_nc=cout, beta2=1.0, cin=cin)
+    hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), 7), "impl 7")
+    torch.cuda.synchronize()
+    ref = 0.04 * F.conv2d(_nchw(buf, cin), w.double(), st.tensor("c.bias").cpu().double(), padding=1) + 0.2 * _nchw(buf, cout) + _nchw(rr, cout)
+    e = rel_err(nxt.cpu().permute(0, 3, 1, 2).double()[:, :cout], ref)
+    assert e < TOL, e
+    assert float(nxt[..., cout:].abs().max()) == 0.0           # the other channels of the destination buffer are untouched
+
+
 # ---- the thin-output VALU kernel of the fp32 modes (csrc/conv_thin.hip, conv_thin_f32_kernel), forced through ssr_conv2d_impl(impl = 5) ----
 @pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
 @pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "generic"])
@@ -243,7 +276,7 @@ def test_ring_x3_conv_two_input_views(c1, c2, cout):
     big1, big2 = mk(192), mk(64)                      # views into wider buffers, as in the step
     x1, x2 = hip.view(big1, 32), hip.view(big2, 0)
     m = mk(cout)
-    for impl in (6, 3):
+    for impl in (7, 6, 3):
         y = torch.zeros(B, H, W, cout, device="cuda")
         cb = engine._ConvBuilder(st, B)
         L = engine.Launcher()
@@ -260,11 +293,11 @@ def test_ring_x3_conv_two_input_views(c1, c2, cout):
         assert e < TOL, (impl, e)
 
 
-def test_ring_x3_is_the_automatic_choice_for_the_body():
+def test_regtile_x3_is_the_automatic_choice_for_the_body(monkeypatch):
     engine, hip = _mods()
     st = engine.ParamStore([engine.ConvSpec("b", 32, 160, 3, 1, True, False)], hip.F32X3)
     cb = engine._ConvBuilder(st, 32)
     L = engine.Launcher()
     buf = torch.zeros(32, 32, 32, 192, device="cuda")
     d = cb.conv(L, "b", hip.view(buf, 0), 32, 32, hip.view(buf, 160), act=hip.ACT_LRELU, cin=160)
-    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 6
+    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5            # digit 5 = csrc/conv_x3r.hip (6 = the ring kernel it replaced)

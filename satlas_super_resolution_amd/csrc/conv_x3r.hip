@@ -60,6 +60,11 @@ constexpr int XR_SLOT = 32 * 32 * 4;                           // one 32 x 32 fp
 template <int NT> struct XrT {
     static constexpr int BN = 32 * NT;
     static constexpr int WR = NT == 1 ? 6 : 3;                 // (chunk, tap) steps of weight fragments in flight per wave (8 / 16 registers each)
+#ifndef XR_TPS1
+#define XR_TPS1 4
+#endif
+    static constexpr int TPS = NT == 1 ? XR_TPS1 : 2;          // pixel tiles per fragment set: a sub-step's MFMAs rotate over TPS NT = 4 accumulators
+    static constexpr int NSETS = TPS == 4 ? 2 : 3;             // fragment sets in registers (32 / 16 registers each); reads run NSETS - 1 sub-steps ahead
     static constexpr int SLOTS = 4 * 4 * NT;                   // [source wave][pixel tile][channel tile] partial tiles of the K-quarter sum
     static constexpr int RED = SLOTS * XR_SLOT;                // 64 / 128 KB (the ring is dead by then)
     static constexpr int CTL = RED > XR_RING ? RED : XR_RING;  // control words behind both: pdone[4] | cdone[4]
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
             if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = 0x3fffffff;
         } else {
             bf16x8 wf[WR][NT][2];                                          // weight fragments of WR (chunk, tap) steps: [hi | lo]
-            bf16x8 af[3][2][2];                                            // pixel fragments of three half-steps (two tiles each): [hi | lo]
+            constexpr int TPS = T::TPS, SPT = 4 / TPS, NSUB = 3 * SPT, NSETS = T::NSETS, PD = NSETS - 1;
+            bf16x8 af[NSETS][TPS][2];                                      // pixel fragments of NSETS sub-steps (TPS tiles each): [hi | lo]
             auto load_w = [&](int g_, auto kxc, auto sc) {                 // step (item g, tap kx) -> register set s
                 constexpr int kx = decltype(kxc)::value, s = decltype(sc)::value;
                 const int gg = g_ < glast ? g_ : glast;                    // past the end: the last item again (never used)
@@ -299,14 +305,13 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                     wf[s][u][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, off + u * 2048 + 32, 0, 0));
                 }
             };
-            auto issue_a = [&](int base, auto kxc, auto thc, auto sc) {    // half-step (tap kx, tiles 2 th, 2 th + 1) -> register set s
-                constexpr int kx = decltype(kxc)::value, th = decltype(thc)::value, s = decltype(sc)::value;
+            // fragment reads of sub-step q (tap q / SPT, tiles TPS (q % SPT) ..) -> register set s: the lo halves (H = 1: what the first MFMA
+            // group of the sub-step multiplies) or the hi halves (H = 0) of all its tiles
+            auto issue_a = [&](int base, auto qc, auto sc, auto hc) {
+                constexpr int q = decltype(qc)::value, kx = q / SPT, part = q % SPT, s = decltype(sc)::value, H = decltype(hc)::value;
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const char* p = smem + base + kx * XR_ROWB + (2 * th + t2) * XR_TILEB;
-                    af[s][t2][0] = *reinterpret_cast<const bf16x8*>(p);
-                    af[s][t2][1] = *reinterpret_cast<const bf16x8*>(p + 32);
-                }
+                for (int t2 = 0; t2 < TPS; ++t2)
+                    af[s][t2][H] = *reinterpret_cast<const bf16x8*>(smem + base + kx * XR_ROWB + (part * TPS + t2) * XR_TILEB + 32 * H);
             };
             int avail = 0;                                                 // chunks known to be in the ring
             auto ensure = [&](int c) {
@@ -320,6 +325,8 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                 if (spin == XR_SPIN_MAX) __builtin_trap();
             };
             auto base_of = [&](int g_) { const int c = g_ / 3, ky = g_ - 3 * c; return (c % XR_NS) * XR_SUB + ky * XR_PW * XR_ROWB + a_lane; };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
             // weights of the first WR steps (they depend on nobody), then the first chunk
             static_for<0, WR>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
@@ -332,19 +339,41 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
             int base_cur = base_of(g);
             ensure(c_cur);
             RPROBE(tid == 0, 2);
-            issue_a(base_cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            issue_a(base_cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-            // one item = three taps = six half-steps; JP = parity of the item (NT = 1: the weight ring is two items deep)
+            static_for<0, PD>([&](auto qc) {
+                issue_a(base_cur, qc, std::integral_constant<int, decltype(qc)::value % NSETS>{}, I1{});
+                issue_a(base_cur, qc, std::integral_constant<int, decltype(qc)::value % NSETS>{}, I0{});
+            });
+            int gn = g + 4 < glast ? g + 4 : glast;                        // the next item (at the end: this one again, never used)
+            int c_next = gn / 3, base_next = base_of(gn);
+            int gnn = gn, c_nn = c_next, base_nn = base_next;
+            // one item = three taps = NSUB sub-steps of three MFMA groups (a_lo w_hi | a_hi w_lo | a_hi w_hi over the sub-step's TPS NT = 4
+            // accumulators: conv_x3q's order per accumulator).  One wave per SIMD hides about five other instructions per MFMA
+            // (MI355X_MICROARCH.md), and nothing hides what sits between the last MFMA of one item and the first of the next: the
+            // weight refill, the fragment reads and the next item's bookkeeping are spread BETWEEN the groups (tools/x3r_probe: an item
+            // without any memory instruction took 1.5 k ticks for 36 MFMAs with the bookkeeping at its head).
+            // JP = parity of the item (NT = 1: the weight ring is two items deep and the fragment sets alternate from item to item)
             auto body = [&](int j, auto jpc) {
                 constexpr int JP = decltype(jpc)::value;
-                const int gn = g + 4 < glast ? g + 4 : glast;              // the next item (at the end: this one again, never used)
-                const int c_next = gn / 3;
-                const int base_next = base_of(gn);
-                static_for<0, 6>([&](auto hc) {
-                    constexpr int h = decltype(hc)::value, kx = h / 2, th = h % 2;
-                    constexpr int ws = (JP * 3 + kx) % WR;
+                static_for<0, NSUB>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value, kx = q / SPT, part = q % SPT, qn = q + PD;
+                    constexpr int ws = (JP * 3 + kx) % WR, as = (JP * NSUB + q) % NSETS, asn = (JP * NSUB + qn) % NSETS;
+                    auto group = [&](auto pc) {
+                        constexpr int P = decltype(pc)::value;             // 0: a_lo w_hi, 1: a_hi w_lo, 2: a_hi w_hi
+#pragma unroll
+                        for (int t2 = 0; t2 < TPS; ++t2)
+#pragma unroll
+                            for (int u = 0; u < NT; ++u)
+                                acc[part * TPS + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[as][t2][P == 0 ? 1 : 0], wf[ws][u][P == 1 ? 1 : 0],
+                                                                                                 acc[part * TPS + t2][u], 0, 0, 0);
+                    };
+                    auto reads = [&](auto hc) {
+#ifndef XR_X_NOA      // (tools/x3r_probe.hip switch: the fragment reads of the prologue are reused)
+                        if constexpr (qn < NSUB) issue_a(base_cur, std::integral_constant<int, qn>{}, std::integral_constant<int, asn>{}, hc);
+                        else issue_a(base_next, std::integral_constant<int, qn - NSUB>{}, std::integral_constant<int, asn>{}, hc);
+#endif
+                    };
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (h == 4) {
+                    if constexpr (qn == NSUB) {
                         // every fragment read of this item has been issued: the chunks below the next item's are finished
                         if (c_next > c_cur) {
                             asm volatile("" ::: "memory");
@@ -352,39 +381,35 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                             asm volatile("" ::: "memory");
                         }
                         ensure(c_next);
-                    }
-#ifndef XR_X_NOA      // (tools/x3r_probe.hip switch: the fragment reads of the prologue are reused)
-                    if constexpr (h + 2 < 6) issue_a(base_cur, std::integral_constant<int, (h + 2) / 2>{}, std::integral_constant<int, (h + 2) % 2>{}, std::integral_constant<int, (h + 2) % 3>{});
-                    else issue_a(base_next, std::integral_constant<int, (h - 4) / 2>{}, std::integral_constant<int, (h - 4) % 2>{}, std::integral_constant<int, (h + 2) % 3>{});
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    // per accumulator: a_lo w_hi, a_hi w_lo, a_hi w_hi (conv_x3q's order); consecutive MFMAs go to different accumulators
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][1], wf[ws][u][0], acc[2 * th + t2][u], 0, 0, 0);
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][0], wf[ws][u][1], acc[2 * th + t2][u], 0, 0, 0);
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[2 * th + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h % 3][t2][0], wf[ws][u][0], acc[2 * th + t2][u], 0, 0, 0);
-                    if constexpr (th == 1) {                                // this step's weight registers are free: the step WR further on
-#ifndef XR_X_NOW      // (probe switch: the weight fragments of the prologue are reused)
                         __builtin_amdgcn_sched_barrier(0);
-                        load_w(g + 4 * (WR / 3), std::integral_constant<int, kx>{}, std::integral_constant<int, ws>{});
+                    }
+                    group(std::integral_constant<int, 0>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    reads(I1{});
+                    if constexpr (part == 0) {
+                        // the registers of the PREVIOUS step are free (all its MFMAs are issued): the step WR - 1 further on
+#ifndef XR_X_NOW      // (probe switch: the weight fragments of the prologue are reused)
+                        constexpr int wsp = (JP * 3 + kx + WR - 1) % WR, ioff = (kx + WR - 1) / 3, tap = (kx + WR - 1) % 3;
+                        // (the very first step reloads step WR - 1 into its own registers: no branch around a load, lesson 32)
+                        load_w(g + 4 * ioff, std::integral_constant<int, tap>{}, std::integral_constant<int, wsp>{});
 #endif
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    group(std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    reads(I0{});
+                    if constexpr (q == 0) {                                 // the item after the next one, under this sub-step's MFMAs
+                        gnn = g + 8 < glast ? g + 8 : glast;
+                        c_nn = gnn / 3;
+                        base_nn = base_of(gnn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    group(std::integral_constant<int, 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
                 });
-                __builtin_amdgcn_sched_barrier(0);
                 g += 4;
-                c_cur = c_next;
-                base_cur = base_next;
+                c_cur = c_next; base_cur = base_next;
+                gn = gnn; c_next = c_nn; base_next = base_nn;
 #ifdef SSR_PROBE
                 if (j < 5) RPROBE(tid == 0, 3 + j);
 #endif

@@ -134,8 +134,10 @@ class ESRGANTrainStep:
             probe = hip.RdbDesc()       # ask the library which dense-block kernel this launch shape gets instead of restating its rule
             probe.dtype, probe.N, probe.H, probe.W = hip.BF16, B, h, w
             wide = hip.lib().ssr_rdb_tile_of(C.byref(probe)) == 16
-            n_split = (1 if wide else 2) if env_split == "auto" else int(env_split)
-            split = n_split > 1 and not self.det and self.dt == hip.BF16 and B % n_split == 0 and B // n_split >= 16 \
+            # r06d (fp32x3, the register-tiled body kernel csrc/conv_x3r.hip: one workgroup per CU whatever the batch): two half-batch chains
+            # 27.00 -> 26.57 ms per step, same call - the chains' launch gaps and prologues fill each other's idle CUs
+            n_split = (2 if self.dt == hip.F32X3 else (1 if wide else 2)) if env_split == "auto" else int(env_split)
+            split = n_split > 1 and not self.det and self.dt in (hip.BF16, hip.F32X3) and B % n_split == 0 and B // n_split >= 16 \
                 and g_kwargs.get("num_feat", 64) == 64 and g_kwargs.get("num_grow_ch", 32) == 32
             if split:
                 self.g_plan = engine.SplitGeneratorPlan(self.g_store, B, h, w, training=True, out_buf=self.fake_in, d_out_buf=self.d_plan.g_in,

@@ -129,12 +129,17 @@ int ssr_conv2d_batch(const ssr_conv_desc* ds, int32_t n, void* stream);
  * kernel (SSR_EUNSUP if the descriptor does not fit it), 2 = skip it (K-resident or pipelined kernel),
  * 3 = pipelined kernel only, 4 = big-tile kernel (32x16 pixels x 64 channels per workgroup; SSR_EUNSUP if unfit),
  * 5 = thin-output VALU kernel (Cout <= 8, Cin <= 64; SSR_EUNSUP if unfit).  SSR_F32X3 descriptors: 4 = the split-mode big-tile
- * kernel (csrc/conv_big_x3.hip), 6 = the producer / MFMA-wave ring kernel for small grids (csrc/conv_x3q.hip). */
+ * kernel (csrc/conv_big_x3.hip), 6 = the producer / MFMA-wave ring kernel for small grids (csrc/conv_x3q.hip, round 5), 7 = the register-tiled
+ * kernel that took those layers over in round 6 (csrc/conv_x3r.hip: four pixel tiles per MFMA wave, K split over four waves). */
 int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
 /* Which kernel instantiation ssr_conv2d dispatches this descriptor to, encoded as
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
  * used by bench.py to attribute launch durations to kernel symbols.  Negative on error. */
 int ssr_conv2d_variant(const ssr_conv_desc* d);
+/* The kernel symbol ssr_conv2d launches for this descriptor as rocprofv3 prints it (without the "void (anonymous namespace)::" prefix and
+ * the argument list), e.g. "conv_x3r_kernel<1, 0>": the key under which bench.py, tools/pmc_traffic.py, tools/pmc_sq.py and
+ * tools/roofline_check.py file a launch, so that roofline.kernel can be found in profiles/ by name.  buflen >= 48. */
+int ssr_conv2d_symbol(const ssr_conv_desc* d, char* buf, int32_t buflen);
 /* input channels per packed weight chunk for a KHxKH kernel in `dtype` */
 int ssr_conv2d_ck(int32_t dtype, int32_t KH);
 /* 1 if a 4x4 stride-2 layer of this shape can run through the space-to-depth path (ssr_conv_desc.s2d), else 0 */

@@ -65,6 +65,15 @@ template <> __device__ __forceinline__ void mma16<__bf16>(f32x16& acc, const u32
 // C/D fragment of a 32x32 MFMA: lane l holds column (l & 31), rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
 __device__ __forceinline__ int mfma32_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: launchers remember it per device ordinal
+// (one process per GPU is the design, but a process that drives a second GPU must not launch without the opt-in there)
+constexpr int SSR_MAX_DEVICES = 32;
+inline int ssr_device_ordinal() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SSR_MAX_DEVICES) dev = 0;
+    return dev;
+}
+
 #define SSR_LAUNCH_CHECK()                       \
     do {                                         \
         hipError_t e__ = hipGetLastError();      \

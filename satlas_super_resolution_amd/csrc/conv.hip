@@ -21,6 +21,7 @@
 // corresponding backward masks / gradient fan-in sums folded into the load and the epilogue.
 #include "conv_epilogue.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -242,12 +243,13 @@ int launch_conv4(const ssr_conv_desc* ds, int n, hipStream_t st) {
     constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
     constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     auto kern = conv_kernel4<T, KH, KW, S, NT, MW, KS>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     ssr_conv_desc4 p;
     for (int k = 0; k < 4; ++k) p.d[k] = ds[k < n ? k : 0];
@@ -267,12 +269,13 @@ int launch_conv(const ssr_conv_desc& d, hipStream_t st) {
     constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_kernel<T, KH, KW, S, NT, MW, KS>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
     dim3 grid(tiles, d.CoutPad / BN, 1);
@@ -515,11 +518,12 @@ int launch_conv_x3(const ssr_conv_desc& d, hipStream_t st) {
     constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_x3_kernel<KH, KW, NT, MW, KS>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
     hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, 1), dim3(64 * MW * KS), lds, st, d);
@@ -803,11 +807,12 @@ int launch_conv_x3p(const ssr_conv_desc& d, hipStream_t st) {
     constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_x3p_kernel<KH, KW, NT, MW, KS, CPS, PD>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = ((d.Gw + TW - 1) / TW) * ((d.Gh + TH - 1) / TH) * d.N;
     hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, 1), dim3(64 * MW * KS), lds, st, d);
@@ -893,19 +898,51 @@ extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32
 extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
-    if (dp->dtype != SSR_BF16 && ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;        // digit 7 = thin-output VALU kernel
-    if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
-    if (dp->dtype == SSR_F32X3 && ssr_conv_x3r_qualifies(*dp))
-        return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 5;                              // digit 5 = register-tiled, K split over four waves (conv_x3r.hip)
-    if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
-        return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
-    if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
-    if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
-    if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
-    if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
+    // ReLU epilogues (the VGG19 layers) exist only in the pipelined kernel outside the split-bf16 mode: conv2d_impl forces it (impl = 3)
+    const bool pipelined_only = dp->dtype != SSR_F32X3 && (dp->act == SSR_ACT_RELU || dp->m_relu);
+    if (!pipelined_only) {
+        if (dp->dtype != SSR_BF16 && ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;        // digit 7 = thin-output VALU kernel
+        if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
+        if (dp->dtype == SSR_F32X3 && ssr_conv_x3r_qualifies(*dp))
+            return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 5;                              // digit 5 = register-tiled, K split over four waves (conv_x3r.hip)
+        if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
+            return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
+        if (dp->dtype != SSR_F32X3) {
+            if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
+            if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
+            if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
+            if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
+        }
+    }
     bool nt2, small;
     pick_tile(*dp, nt2, small);
     return dp->KH * 1000 + dp->stride * 100 + (nt2 ? 2 : 1) * 10 + (small ? 2 : 4);
+}
+
+void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* nt, int* ep);
+
+// The kernel symbol ssr_conv2d launches for this descriptor, as rocprofv3 prints it (without the "void (anonymous namespace)::"
+// prefix and the argument list): what bench.py files a launch under, so that roofline.kernel can be looked up in
+// profiles/*_kernel_stats*.csv, *_pmc_sq.json and traffic_*.json by the same name.  Exact for the kernels that carry the step
+// (register-tiled / ring body kernels, big-tile, thin-output); for the older pipelined / resident / weight-stationary families
+// the family name with the ssr_conv2d_variant code (their template lists depend on internal tile choices).
+extern "C" int ssr_conv2d_symbol(const ssr_conv_desc* dp, char* buf, int32_t buflen) {
+    if (!dp || !buf || buflen < 48) return SSR_EINVAL;
+    const ssr_conv_desc& d = *dp;
+    const int v = ssr_conv2d_variant(dp);
+    if (v < 0) return v;
+    const int w = v % 10, nt = (v / 10) % 10;
+    const bool f32m = d.dtype != SSR_BF16;
+    if (d.dtype == SSR_F32X3 && w == 5) {
+        int n_ = 1, ep = 3;
+        ssr_conv_x3r_instance(d, &n_, &ep);
+        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d>", n_, ep);
+    } else if (d.dtype == SSR_F32X3 && w == 6) snprintf(buf, buflen, "conv_x3q_kernel<%d>", nt);
+    else if (d.dtype == SSR_F32X3 && w == 9) snprintf(buf, buflen, "conv_bigx3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
+    else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %s>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? "true" : "false");
+    else snprintf(buf, buflen, "%s<%s,K%d,S%d,NT%d,W%d>", w == 7 ? "conv_thin_kernel" : w == 8 ? "conv_ws_kernel" : w == 9 ? "conv_big_kernel" : w == 1 ? "conv_res_kernel" : d.dtype == SSR_F32X3 ? "conv_x3_kernel" : "conv_kernel",
+                  d.dtype == SSR_BF16 ? "bf16" : d.dtype == SSR_F32 ? "fp32" : "fp32x3", v / 1000, (v / 100) % 10, nt, w);
+    return SSR_OK;
 }
 
 extern "C" int ssr_conv2d_ck(int32_t dtype, int32_t KH) {

@@ -659,20 +659,22 @@ int launch_big(const ssr_conv_desc* ds, int n, hipStream_t st) {
     const int tiles = tpi * G;
     if (n == 1) {
         auto kern = conv_big_kernel<EP, KT, CK>;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+        const int attr_dev = ssr_device_ordinal();
+        if (!attr_done[attr_dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
+            attr_done[attr_dev] = true;
         }
         hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / 64, 1), dim3(256), lds, st, d);
     } else {
         auto kern = conv_big_kernel4<EP, KT, CK>;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+        const int attr_dev = ssr_device_ordinal();
+        if (!attr_done[attr_dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
+            attr_done[attr_dev] = true;
         }
         ssr_conv_desc4b p;
         for (int k = 0; k < 4; ++k) p.d[k] = ds[k < n ? k : 0];

@@ -446,11 +446,12 @@ int launch_bigx3(const ssr_conv_desc* ds, int n, hipStream_t st) {
     }
     const int tiles = tpi * G;
     auto kern = conv_bigx3_kernel4<KT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     ssr_conv_desc4x p;
     for (int k = 0; k < 4; ++k) p.d[k] = ds[k < n ? k : 0];

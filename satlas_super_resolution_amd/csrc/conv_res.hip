@@ -196,12 +196,13 @@ int launch_res(const ssr_conv_desc& d, int nchunks, hipStream_t st) {
     constexpr int BN = 32 * NT, ROWS = RES_PROWS_PAD + 9 * BN;
     const size_t lds = (size_t)nchunks * ROWS * RES_ROWB;
     auto kern = conv_res_kernel<T, NT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = ((d.Gw + RES_TW - 1) / RES_TW) * ((d.Gh + RES_TH - 1) / RES_TH) * d.N;
     hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / BN, 1), dim3(256), lds < 24576 ? 24576 : lds, st, d);

@@ -263,11 +263,12 @@ int launch_thin_f32(const ssr_conv_desc& d, hipStream_t st) {
     constexpr int NCOP = NCO == 1 ? 1 : NCO <= 4 ? 4 : 8;
     const size_t lds = (size_t)CTF_PATCH + (size_t)9 * ((d.Cin + 15) & ~15) * NCOP * 4;     // <= 67,392 B
     auto kern = conv_thin_f32_kernel<NCO, X3>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CTF_PATCH + 9 * 64 * 8 * 4);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = d.N * ((d.Gh + CT_TH - 1) / CT_TH) * ((d.Gw + CT_TW - 1) / CT_TW);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, d);
@@ -286,12 +287,13 @@ template <int NCO>
 int launch_thin(const ssr_conv_desc& d, hipStream_t st) {
     const size_t lds = (size_t)CT_NPIX * (d.Cin * 2 + 16);
     auto kern = conv_thin_kernel<NCO>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            CT_NPIX * (64 * 2 + 16) + 9 * 8 * 64 * 2);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = d.N * ((d.Gh + CT_TH - 1) / CT_TH) * ((d.Gw + CT_TW - 1) / CT_TW);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, d);

@@ -364,12 +364,13 @@ template <int NPL, int NT, int EP>
 int launch_ws_ep(const ssr_conv_desc& d, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)NPL * WS_PIX * WS_AROW + 256 + (EP >= 0 && (EP & WS_Y1) ? 2 : 1) * 4 * 32 * (32 * NT + 8) * 2;
     auto kern = conv_ws_kernel<NPL, NT, EP>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int ntiles = d.N * ((d.Gh + WS_TH - 1) / WS_TH) * ((d.Gw + WS_TW - 1) / WS_TW);
     const int ny = d.CoutPad / (32 * NT);

@@ -45,8 +45,8 @@ constexpr int XQ_PV = XQ_NPIX * 4;                             // 16-byte vector
 constexpr int XQ_NPV = (XQ_PV + 255) / 256;                    // per producer thread: 3
 constexpr int XQ_ROT = 14;                                     // rotation of a tile's second pixel row (32 - PW)
 constexpr int XQ_OOB = 0x7ffffff0;
-constexpr int XQ_SPIN_MAX = 1 << 22;                           // polls of a flag before a wave gives up (~0.3 s; a hand-over takes ~1 us):
-                                                               // a protocol bug must fail a test, not hang the GPU
+constexpr int XQ_SPIN_MAX = 1 << 22;                           // polls of a flag before a wave TRAPS (~0.3 s; a hand-over takes ~1 us):
+                                                               // a protocol bug must fail the launch loudly - neither hang the GPU nor fall through
 // A ring STAGE holds CPS 16-channel chunks (NT = 1: two - with one, a wave had 13 MFMAs per hand-over and the per-stage work of an MFMA
 // wave - poll, release, its weight rows - cost as much as the MFMAs: 1.9 k ticks per chunk for 0.9 k of MFMAs, tools/x3q_probe.hip).
 template <int NT> struct XqT {
@@ -172,13 +172,15 @@ __global__ __launch_bounds__(XQ_NTHR) void conv_x3q_kernel(const ssr_conv_desc d
                         // here would make hipcc drain the refill loads first; "=&v": the outputs must not share a register with the
                         // address (the first read may return before the second one issues)
                         const int need = s_ - NS + 1;
-                        for (int spin = 0; spin < XQ_SPIN_MAX; ++spin) {
+                        int spin = 0;
+                        for (; spin < XQ_SPIN_MAX; ++spin) {
                             u32x4 dn, dm;
                             asm volatile("ds_read_b128 %0, %2 offset:32\n\tds_read_b128 %1, %2 offset:48\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn), "=&v"(dm) : "v"(ctl_addr) : "memory");
                             const int dmin = (int)min(min(min(dn[0], dn[1]), min(dn[2], dn[3])), min(min(dm[0], dm[1]), min(dm[2], dm[3])));
                             if (__builtin_amdgcn_readfirstlane(dmin) >= need) break;
                             __builtin_amdgcn_s_sleep(2);
                         }
+                        if (spin == XQ_SPIN_MAX) __builtin_trap();         // a stalled hand-over must be loud (a failed launch), not wrong activations
                     }
                     char* base = smem + st * STAGE;
 #pragma unroll
@@ -286,12 +288,14 @@ __global__ __launch_bounds__(XQ_NTHR) void conv_x3q_kernel(const ssr_conv_desc d
                 const int s_ = s0 + j;
                 if (s_ < nst) {
                     const int st = s_ % NS, target = (XQ_NCONS + XQ_NPROD) * (s_ / NS + 1);
-                    for (int spin = 0; spin < XQ_SPIN_MAX; ++spin) {          // all twelve waves have stored their part of the stage
+                    int spin = 0;
+                    for (; spin < XQ_SPIN_MAX; ++spin) {                      // all twelve waves have stored their part of the stage
                         int rdy;
                         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rdy) : "v"(ctl_addr + 4 * st) : "memory");
                         if (__builtin_amdgcn_readfirstlane(rdy) >= target) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    if (spin == XQ_SPIN_MAX) __builtin_trap();
                     const char* sb = smem + st * STAGE;
                     // the two k-halves take alternate (chunk, tap) pairs; with an odd number of pairs per stage (CPS = 1) the halves swap
                     // parities from stage to stage
@@ -359,11 +363,12 @@ __global__ __launch_bounds__(XQ_NTHR) void conv_x3q_kernel(const ssr_conv_desc d
 template <int NT>
 int launch_x3q(const ssr_conv_desc& d, hipStream_t st) {
     auto kern = conv_x3q_kernel<NT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XqT<NT>::LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     const int tiles = ((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N;
     hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / (32 * NT), 1), dim3(XQ_NTHR), XqT<NT>::LDS, st, d);

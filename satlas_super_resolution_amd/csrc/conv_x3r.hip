@@ -487,9 +487,8 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
 template <int NT, int EP>
 int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
     auto kern = conv_x3r_kernel<NT, EP>;
-    static bool attr_done[16] = {};                            // the attribute is per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    static bool attr_done[SSR_MAX_DEVICES] = {};               // the attribute is per DEVICE
+    const int dev = ssr_device_ordinal();
     if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XrT<NT>::LDS);
         if (e != hipSuccess) return (int)e;
@@ -527,6 +526,13 @@ int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+// NT and straight-line-epilogue index of the instantiation ssr_conv_x3r_try launches (the rocprofv3 symbol is conv_x3r_kernel<NT, EP>)
+void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* nt, int* ep) {
+    static const bool nt2_off = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return e && e[0] == '0'; }();
+    *nt = ((d.CoutPad % 64) == 0 && !nt2_off) ? 2 : 1;
+    *ep = xr_pick_epilogue(d);
+}
 
 bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d) {
     if (d.dtype != SSR_F32X3 || d.fix_list) return false;

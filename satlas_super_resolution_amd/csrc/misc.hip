@@ -968,12 +968,13 @@ extern "C" int ssr_usm_sharp(const float* src, float* dst, int32_t planes, int32
     if (!src || !dst || planes <= 0 || H <= USM_R || W <= USM_R) return SSR_EINVAL;   // reflect padding needs pad < size
     if ((long)H * W > 16384) return SSR_EUNSUP;               // plane must fit LDS twice (128 x 128 ground-truth tiles do)
     const size_t lds = ((size_t)2 * H * W + 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(usm_sharp_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 16384 + 64) * sizeof(float)));
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     hipLaunchKernelGGL(usm_sharp_kernel, dim3(planes), dim3(256), lds, ST(stream), src, dst, H, W, in_scale, weight, threshold);
     SSR_LAUNCH_CHECK();
@@ -1122,4 +1123,4 @@ extern "C" int ssr_split_bf16_multi(const ssr_split_item* items_dev, int32_t n_i
     return SSR_OK;
 }
 
-extern "C" int ssr_abi_version(void) { return 2; }
+extern "C" int ssr_abi_version(void) { return 3; }

@@ -125,12 +125,13 @@ int launch_wgrad(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((size_t)PH * PW * WG_ROW >= 4 * 16 * 64, "reduction scratch fits in the patch region");
     auto kern = wgrad_kernel<T, KH, KW, S, SPLIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_items), dim3(256), lds, st, layers, items);
     SSR_LAUNCH_CHECK();

@@ -730,12 +730,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16_k3_kernel(const ssr_wgrad_laye
 }
 
 int launch_k3(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_k3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg3::LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     hipLaunchKernelGGL(wgrad_bf16_k3_kernel, dim3(n_items), dim3(512), Wg3::LDS, st, layers, items);
     SSR_LAUNCH_CHECK();
@@ -746,12 +747,13 @@ template <int KH, int KW, int S, bool SPLIT>
 int launch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, hipStream_t st) {
     using C = WgCfg<KH, KW, S, SPLIT>;
     auto kern = wgrad_bf16_kernel<KH, KW, S, SPLIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_items), dim3(512), C::LDS, st, layers, items);
     SSR_LAUNCH_CHECK();

@@ -381,12 +381,13 @@ __global__ __launch_bounds__(512) void wgrad_x3_k3_kernel(const ssr_wgrad_layer*
 int ssr_wgrad_x3_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW, int S,
                           hipStream_t st) {
     if (!(KH == 3 && KW == 3 && S == 1)) return SSR_EUNSUP;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
+    const int attr_dev = ssr_device_ordinal();
+    if (!attr_done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_k3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wx3::LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_done[attr_dev] = true;
     }
     hipLaunchKernelGGL(wgrad_x3_k3_kernel, dim3(n_items), dim3(512), Wx3::LDS, st, layers, items);
     SSR_LAUNCH_CHECK();

@@ -13,6 +13,14 @@ MI355X-first re-design:
   * u/v stay bit-identical across ranks without any broadcast: every rank applies the same
     deterministic power iteration to the same (all-reduced) weights;
   * averaging (1/world) is folded into the fused Adam kernel's grad_scale.
+
+Exchange algorithm (SSR_DP_ALGO, read when the context is built; a one-command A/B for the first session on an 8-GPU node):
+  allreduce (default)  chunked dist.all_reduce: RCCL picks ring / tree per message size;
+  rsag                 explicit reduce_scatter_tensor + all_gather_into_tensor over the (padded) arena: each rank reduces 1/world
+                       of the arena and gathers the rest - the direct all-links form SURVEY.md section 5 prefers on point-to-point
+                       xGMI (7 links x ~153 GB/s per GPU), same sums up to the reduction order inside RCCL.
+Diagnostics (DPContext.timing = True; bench.py --gpus N switches it on): an event pair around every exchange on the comm stream ->
+comm_busy_ms(), so that a scaling result can be split into compute, exposed communication and host enqueue time from one run.
 """
 from __future__ import annotations
 
@@ -45,12 +53,18 @@ def init_distributed(backend: Optional[str] = None) -> "DPContext":
 
 
 class DPContext:
-    def __init__(self, group, rank: int, world: int, chunk_bytes: int = 32 << 20, force: bool = False):
+    def __init__(self, group, rank: int, world: int, chunk_bytes: int = 32 << 20, force: bool = False, algo: Optional[str] = None):
         self.group, self.rank, self.world = group, rank, world
         self.force = force
         self.chunk_elems = max(1, chunk_bytes // 4)
+        self.algo = (algo or os.environ.get("SSR_DP_ALGO", "allreduce")).lower()
+        if self.algo not in ("allreduce", "rsag"):
+            raise ValueError(f"SSR_DP_ALGO={self.algo!r}: expected 'allreduce' or 'rsag'")
         self._comm_stream = None
         self._pending: List = []
+        self._scratch = {}          # rsag: padded staging arenas by (numel, device)
+        self.timing = False         # event pairs around the exchanges on the comm stream (comm_busy_ms)
+        self._timed: List = []
 
     @property
     def active(self) -> bool:
@@ -77,15 +91,68 @@ class DPContext:
             cs = self._stream()
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                for off in range(0, flat.numel(), self.chunk_elems):
-                    dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group)
-                ev = torch.cuda.Event()
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(cs)
+                if self.algo == "rsag":
+                    self._rsag(flat)
+                else:
+                    for off in range(0, flat.numel(), self.chunk_elems):
+                        dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group)
+                ev = torch.cuda.Event(enable_timing=self.timing)
                 ev.record(cs)
+                if self.timing:
+                    self._timed.append((e0, ev, flat.numel() * flat.element_size()))
             return ev
+        if self.algo == "rsag":
+            self._rsag(flat)
+            return []
         works = [dist.all_reduce(flat[off:off + self.chunk_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for off in range(0, flat.numel(), self.chunk_elems)]
         self._pending.extend(works)
         return works
+
+    def _rsag(self, flat: torch.Tensor):
+        """sum-all-reduce of a flat arena as reduce-scatter + all-gather (in place; on the current stream).  The arena is used in
+        place when its length is a multiple of the world size, else through a zero-padded staging copy."""
+        n, w = flat.numel(), self.world
+        per = (n + w - 1) // w
+        if per * w == n:
+            buf = flat
+        else:
+            key = (per * w, flat.device, flat.dtype)
+            buf = self._scratch.get(key)
+            if buf is None:
+                buf = self._scratch[key] = torch.zeros(per * w, dtype=flat.dtype, device=flat.device)
+            buf[:n].copy_(flat)
+        shard = buf[self.rank * per:(self.rank + 1) * per]
+        if w == 1:
+            return
+        # in-place reduce-scatter into this rank's shard of the same buffer is not allowed by every backend: a shard-sized temporary
+        tmp = torch.empty_like(shard)
+        if hasattr(dist, "reduce_scatter_tensor") and dist.get_backend(self.group) != "gloo":
+            dist.reduce_scatter_tensor(tmp, buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(buf, tmp, group=self.group)
+        else:   # gloo (CPU tests) has no reduce_scatter: the same data movement from primitives it has - reduce each shard to its owner
+            for r in range(w):
+                dist.reduce(buf[r * per:(r + 1) * per], dst=r, op=dist.ReduceOp.SUM, group=self.group)
+            tmp.copy_(shard)
+            parts = [torch.empty_like(tmp) for _ in range(w)]
+            dist.all_gather(parts, tmp, group=self.group)
+            for r in range(w):
+                buf[r * per:(r + 1) * per].copy_(parts[r])
+        if buf is not flat:
+            flat.copy_(buf[:n])
+
+    def comm_busy_ms(self, reset: bool = True):
+        """(total ms the comm stream spent inside exchanges, bytes exchanged, exchanges) since the last reset; needs timing = True and a
+        device synchronisation by the caller"""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._timed)
+        nbytes = sum(c for _, _, c in self._timed)
+        k = len(self._timed)
+        if reset:
+            self._timed.clear()
+        return ms, nbytes, k
 
     def wait(self, handle=None):
         """Make the current stream (GPU) / the caller (CPU) wait for one exchange (`handle` from

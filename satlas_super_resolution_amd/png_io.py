@@ -151,16 +151,20 @@ def _open_map(path: str, nbytes: int):
     import mmap
     with open(path, "r+b") as f:
         mm = mmap.mmap(f.fileno(), nbytes)
-    return np.frombuffer(mm, dtype=np.uint8), mm
+    return [np.frombuffer(mm, dtype=np.uint8), mm]             # a LIST: _close_map takes the view out of it before closing
 
 
-def _close_map(entry):
-    arr, mm = entry
-    del arr
+def _close_map(entry) -> bool:
+    """unmap a block: the entry's own view is dropped first (an ndarray export keeps mmap.close() from succeeding - with the view
+    still referenced from the entry the close used to fail every time and the pages of an unlinked block stayed allocated until the
+    entry itself died).  Returns whether the mapping is closed; False = a caller still holds a view, the mapping goes with it."""
+    mm = entry[1]
+    entry[0] = None
     try:
         mm.close()                                             # gives the pages of an unlinked block back to the tmpfs
-    except (BufferError, ValueError):                          # a view is still alive somewhere: the mapping goes with it
-        pass
+    except (BufferError, ValueError):
+        return False
+    return True
 
 
 def _map(path: str, nbytes: int) -> np.ndarray:

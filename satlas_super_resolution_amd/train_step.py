@@ -164,6 +164,7 @@ class ESRGANTrainStep:
         # r02c, same box, B=32 8xS2 bf16: 13.94 -> 13.27 ms per step with the fork (two pairs, +-0.02)
         self.overlap_d = os.environ.get("SSR_OVERLAP_D", "1") == "1"
         self.dp_fork = os.environ.get("SSR_DP_FORK", "1") == "1"
+        self.dp_one_graph = os.environ.get("SSR_DP_ONE_GRAPH", "0") == "1"
         self.iter = 0
 
     # ------------------------------------------------------------------ state
@@ -314,6 +315,33 @@ class ESRGANTrainStep:
             self._graphs[name] = g
         g.replay()
 
+    def _dp_step_body(self):
+        """the forked data-parallel step as one stream program (captured whole when SSR_DP_ONE_GRAPH=1; see step())"""
+        self._phase_g(run_bwd=False)
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._phase_d()
+        segs = getattr(self.g_plan, "bwd_segments", None) or [(self.g_plan.bwd, 0, self.g_store.numel)]
+        hgs = []
+        for L, off, n in segs:
+            L.run()
+            hgs.append(self.dp.all_reduce_async(self.g_store.grad[off:off + n]))
+        with torch.cuda.stream(side):
+            hd = self.dp.all_reduce_async(self.d_store.grad)
+            self.dp.wait(hd)
+            self._phase_opt_d()
+        for hg in hgs:
+            self.dp.wait(hg)
+        self._phase_opt_g()
+        cur.wait_stream(side)
+        cs = self.dp._stream()
+        if cs is not None:
+            cur.wait_stream(cs)        # (inside a capture every forked stream must join the capturing one)
+
     def step(self, current_iter: Optional[int] = None):
         """One optimize_parameters().  Order of device work (single rank): identical to the reference.
         With DP, G's gradient exchange is issued slice by slice behind the segments of G's backward (and so overlaps it and
@@ -326,6 +354,13 @@ class ESRGANTrainStep:
             # data parallel, forked: as in the single-process step the discriminator phases run on a side stream beside G's
             # backward; each network's gradient exchange follows its own backward and each Adam its own exchange.  Collectives are
             # ISSUED in the same program order on every rank (G's slices, then D's; they execute in that order on the one comm stream).
+            if self.dp_one_graph:
+                # SSR_DP_ONE_GRAPH=1 (RCCL only: its collectives are stream operations and can be captured; gloo's are host calls):
+                # the whole data-parallel step - both phase chains, the slice exchanges on the comm stream, both Adam updates - as
+                # ONE graph launch per step instead of seven graph launches with the collectives issued from Python between them
+                # (8 ranks on 16 host cores).  Same device work, same order on every stream.
+                self._run("dp_step", self._dp_step_body)
+                return
             self._run("g_pre", lambda: self._phase_g(run_bwd=False))
             cur = torch.cuda.current_stream()
             if self._side is None:

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), f"{s} declared in include/ssr_hip.h but not exported"
     assert sorted(hip.ABI_SYMBOLS) == declared
-    assert lib.ssr_abi_version() == 2     # 2: SSR_F32X3, ssr_split_bf16, metrics
+    assert lib.ssr_abi_version() == 3     # 2: SSR_F32X3, ssr_split_bf16, metrics; 3: ssr_conv2d_symbol, impl 7 (csrc/conv_x3r.hip)
 
 
 def test_struct_layouts_match_header():

@@ -52,6 +52,18 @@ def _worker(rank, world, port, q):
         ctx.wait(h)
     assert not ctx._pending
     assert torch.equal(arena, (torch.arange(4321, dtype=torch.float32) % 97) * (world * (world + 1) // 2))
+    # (a3) SSR_DP_ALGO=rsag: the same exchange as reduce-scatter + all-gather over the (padded) arena - lengths that are / are not a
+    # multiple of the world size, shorter than the world size, and slices of a larger arena (the segmented generator exchange)
+    from satlas_super_resolution_amd.dp import DPContext
+    c2 = DPContext(ctx.group, rank, world, algo="rsag")
+    for n in (4321, 4096, 5, 8 * 17):
+        flat = (torch.arange(n, dtype=torch.float32) % 89) * (rank + 1)
+        c2.wait(c2.all_reduce_async(flat))
+        assert torch.equal(flat, (torch.arange(n, dtype=torch.float32) % 89) * (world * (world + 1) // 2)), n
+    arena = (torch.arange(4321, dtype=torch.float32) % 97) * (rank + 1)
+    for lo, hi in bounds:
+        c2.wait(c2.all_reduce_async(arena[lo:hi]))
+    assert torch.equal(arena, (torch.arange(4321, dtype=torch.float32) % 97) * (world * (world + 1) // 2))
     # (b) DP identity on a small ESRGAN step
     g_kw = dict(num_in_ch=6, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
     g0 = O.generator_init(seed=5, **g_kw)

@@ -171,7 +171,10 @@ def _rccl_worker(port, outdir):
     assert torch.distributed.get_backend() == "nccl" and ctx.active and ctx.world == 1
     g0, d0 = O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6)
     res = {}
-    for name, dp in (("dp", ctx), ("single", DPContext(None, 0, 1))):
+    # "dp_one_graph": SSR_DP_ONE_GRAPH=1 (the whole data-parallel step, RCCL collectives included, captured as ONE graph per rank) with
+    # SSR_DP_ALGO=rsag (reduce-scatter + all-gather over the padded arenas)
+    for name, dp in (("dp", ctx), ("dp_one_graph", DPContext(ctx.group, 0, 1, force=True, algo="rsag")), ("single", DPContext(None, 0, 1))):
+        os.environ["SSR_DP_ONE_GRAPH"] = "1" if name == "dp_one_graph" else "0"
         ts = ESRGANTrainStep(G_KW, D_KW, 2, 8, 8, "fp32", StepConfig(), dp=dp, use_graph=True)
         ts.load_state(g0, d0)
         if dp.active:
@@ -183,7 +186,9 @@ def _rccl_worker(port, outdir):
                 ts.step(it)
                 logs.append(dict(ts.log()))
         torch.cuda.synchronize()
-        if dp.active:
+        if name == "dp_one_graph":
+            assert set(ts._graphs) == {"dp_step"}, set(ts._graphs)
+        elif dp.active:
             assert set(ts._graphs) == {"g_pre", "g_bwd0", "g_bwd1", "g_bwd2", "d", "opt_g", "opt_d"}, set(ts._graphs)   # G's backward in 3 segments, one exchange each
             assert sum(n for _, _, n in ts.g_plan.bwd_segments) == ts.g_store.numel
         res[name] = (logs, ts.g_store.data.cpu().clone(), ts.d_store.data.cpu().clone(), ts.opt_g.ema.cpu().clone())
@@ -202,12 +207,14 @@ def test_dp_branch_over_rccl_world1_equals_single_process_step(tmp_path):
     p.join(timeout=900)
     assert p.exitcode == 0
     res = torch.load(os.path.join(str(tmp_path), "rccl.pt"), weights_only=False)
-    (la, ga, da, ea), (lb, gb, db, eb) = res["dp"], res["single"]
-    for x, y in zip(la, lb):
-        for k in x:
-            assert abs(x[k] - y[k]) <= 1e-6 * max(1.0, abs(y[k])), (k, x[k], y[k])
-    # wgrad accumulates with fp32 atomics: run-to-run differences at the 1e-7 level are expected, nothing larger
-    assert rel_err(ga, gb) < 1e-5 and rel_err(da, db) < 1e-5 and rel_err(ea, eb) < 1e-5
+    (lb, gb, db, eb) = res["single"]
+    for name in ("dp", "dp_one_graph"):
+        (la, ga, da, ea) = res[name]
+        for x, y in zip(la, lb):
+            for k in x:
+                assert abs(x[k] - y[k]) <= 1e-6 * max(1.0, abs(y[k])), (name, k, x[k], y[k])
+        # wgrad accumulates with fp32 atomics: run-to-run differences at the 1e-7 level are expected, nothing larger
+        assert rel_err(ga, gb) < 1e-5 and rel_err(da, db) < 1e-5 and rel_err(ea, eb) < 1e-5, name
 
 
 def _train_worker(rank, world, port, outdir):

@@ -108,11 +108,20 @@ def test_one_shot_blocks_are_not_retained_and_the_mapping_cache_is_bounded(tmp_p
         assert all(int(b.buf[0]) == 7 for b in blks)
         png_io._map(blks[3].path, 64)                       # a hit moves the entry to the young end
         assert list(png_io._MAPS)[-1] == blks[3].path
+        # an evicted / transient mapping is really CLOSED (mmap.closed), not merely forgotten: the entry's own view is dropped first
+        e = png_io._open_map(blks[0].path, 64)
+        mm = e[1]
+        assert png_io._close_map(e) and mm.closed and e[0] is None
+        e = png_io._open_map(blks[0].path, 64)
+        held = e[0]                                         # a caller that still holds a view: the close is refused, and reported
+        assert not png_io._close_map(e) and not e[1].closed
+        del held
+        assert png_io._close_map(e) and e[1].closed
     finally:
         for b in blks:
             e = png_io._MAPS.pop(b.path, None)
             if e is not None:
-                png_io._close_map(e)
+                assert png_io._close_map(e) and e[1].closed
             b.close()
 
 

@@ -14,10 +14,8 @@ dense-block launch, the count derived from the source).  SQ_WAVE_CYCLES / SQ_WAI
 import csv, glob, json, os, re, sys
 
 
-def short(name):
-    m = re.search(r"(rdbt_kernel<[^>]*>|rdb_kernel<\w+>|wgrad_x3_k3_kernel|wgrad_bf16_k3_kernel|wgrad_bf16_kernel|conv_x3q_kernel<\d>|conv_bigx3_kernel4<\d>|conv_x3_kernel<[^>]*>|split_bf16_multi_kernel|conv_big_kernel4?<[^>]*>|conv_ws_kernel<[^>]*>|conv_thin_kernel<[^>]*>|"
-                  r"conv_res_kernel|conv_kernel4?|wgrad_kernel)", name)
-    return m.group(1) if m else None
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ksym import hot as short       # the rocprofv3 name (family), the key bench.py's roofline.kernel uses too
 
 
 def main():

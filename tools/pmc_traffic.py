@@ -13,26 +13,8 @@ is taken as is (uncalibrated)."""
 import csv, glob, json, os, sys
 
 
-def symbol(name: str):
-    if "rdbt_kernel<16, true>" in name or "rdbt_kernelILi16ELb1" in name: return "rdbt_kernel<16, true>"
-    if "rdbt_kernel<16, false>" in name or "rdbt_kernelILi16ELb0" in name: return "rdbt_kernel<16, false>"
-    if "rdb_kernel<true>" in name or "rdb_kernelILb1" in name: return "rdb_kernel<true>"
-    if "rdb_kernel<false>" in name or "rdb_kernelILb0" in name: return "rdb_kernel<false>"
-    if "wgrad_x3_k3_kernel" in name: return "wgrad_kernel<fp32x3,K3>"
-    if "wgrad_bf16_k3_kernel" in name: return "wgrad_kernel<bf16,K3>"
-    if "wgrad_bf16_kernel" in name: return "wgrad_kernel<bf16,K4>"
-    import re
-    m = re.search(r"conv_x3_kernel<(\d), \d, (\d), (\d), \d>", name)        # <KH, KW, NT, MW, KS>: bench.py's conv_kernel<fp32x3,K..,S1,NT..,W..>
-    if m: return f"conv_kernel<fp32x3,K{m.group(1)},S1,NT{m.group(2)},W{m.group(3)}>"
-    m = re.search(r"conv_x3q_kernel<(\d)>", name)                             # the ring kernel of the fp32x3 body: <NT>
-    if m: return f"conv_kernel<fp32x3,K3,S1,NT{m.group(1)},W6>"
-    if re.search(r"conv_bigx3_kernel4<3>", name): return "conv_kernel<fp32x3,K3,S1,NT2,W9>"      # the fp32x3 big-tile kernel, 3x3 layers
-    if re.search(r"conv_bigx3_kernel4<2>", name): return "conv_bigx3_kernel4<2>"                 # (2x2: parity classes and s2d forward share it)
-    m = re.search(r"wgrad_kernel<float, (\d),", name)
-    if m: return f"wgrad_kernel<fp32,K{m.group(1)}>"
-    if "conv_big_kernel" in name: return "conv_big_kernel"
-    if "conv_ws_kernel" in name: return "conv_ws_kernel"
-    return None
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ksym import hot as symbol      # the rocprofv3 name (family), the key bench.py's roofline.kernel uses too
 
 
 def collect(d, counter):

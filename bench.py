@@ -307,6 +307,26 @@ def pmc_traffic(dom, dtype, B, frames):
         return None, f"{os.path.relpath(tp, ROOT)} unreadable: {e}"
 
 
+def unsplit_twin(ts, build):
+    """The step may run the generator as two half-batch launch chains that share the chip (train_step.py, SSR_G_SPLIT): its launches
+    are then half launches, and a half launch timed ALONE (as the instrumented step times everything) has half the chip idle.  The
+    kernel roofline is a property of the kernel at the full per-GPU batch, so it is measured on a twin of the step built without the
+    split (same weights, same data, same kernels: SSR_G_SPLIT=0), which is also what profiles/*_kernel_stats_serial.csv traces."""
+    if not hasattr(ts.g_plan, "parts"):
+        return ts, False
+    old = os.environ.get("SSR_G_SPLIT")
+    os.environ["SSR_G_SPLIT"] = "0"
+    try:
+        tw = build()
+    finally:
+        if old is None:
+            os.environ.pop("SSR_G_SPLIT", None)
+        else:
+            os.environ["SSR_G_SPLIT"] = old
+    assert not hasattr(tw.g_plan, "parts")
+    return tw, True
+
+
 def roofline_of(agg, dtype):
     """dominant MFMA kernel of an instrumented step: algorithmic FLOPs of its launches / their summed duration"""
     conv = {k: v for k, v in agg.items() if v[2] > 0}
@@ -375,8 +395,18 @@ def precision_leg(args, dtype, g_kw, d_kw, c_in, c_d, B, lr, gt, steps):
     finite = all(v == v and abs(v) < 1e30 for v in ts.log().values())
     roof, breakdown = None, None
     if not args.no_roofline:
-        agg = instrumented_step(ts, args, dtype)
+        def build():
+            tw = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, dtype, StepConfig(feed_disc_lr=args.feed_disc_lr), use_graph=False)
+            tw.load_state(g0, flops.discriminator_random_state(c_d, 64, seed=1))
+            tw.feed_data(lr, gt)
+            tw.step()
+            return tw
+        ts_r, twin = unsplit_twin(ts, build)
+        agg = instrumented_step(ts_r, args, dtype)
+        if twin:
+            del ts_r
         dom, roof = roofline_of(agg, dtype)
+        roof["measured_on"] = "unsplit twin of the step (full-batch launches)" if twin else "the step's own launch list"
         roof["traffic"], note = pmc_traffic(dom, dtype, B, args.frames)
         if note:
             roof["traffic_note"] = note
@@ -510,10 +540,24 @@ def main():
     if dp_diag is not None:
         out["dp"] = dp_diag
     # the instrumented step contains the gradient exchanges: every rank runs it (collectives must match), rank 0 reports
-    agg = instrumented_step(ts, args) if not args.no_roofline else None
+    agg, twin = None, False
+    if not args.no_roofline:
+        def build():
+            tw = ESRGANTrainStep(g_kw, d_kw, B, 32, 32, args.dtype, StepConfig(feed_disc_lr=args.feed_disc_lr, perceptual=percep), dp=ctx,
+                                 use_graph=False, vgg_state=vgg_state)
+            tw.load_state(flops.generator_random_state(seed=0, **g_kw), flops.discriminator_random_state(c_d, 64, seed=1))
+            tw.feed_data(lr, gt)
+            tw.step()
+            return tw
+        ts_r, twin = unsplit_twin(ts, build)
+        agg = instrumented_step(ts_r, args)
+        if twin:
+            del ts_r
     trace("instrumented step done")
     if ctx.rank == 0 and agg is not None:
         dom, roof0 = roofline_of(agg, args.dtype)
+        roof0["measured_on"] = ("unsplit twin of the step (full-batch launches; the step itself runs the generator as two half-batch chains that share the chip)"
+                                if twin else "the step's own launch list")
         traffic, traffic_note = pmc_traffic(dom, args.dtype, B, args.frames)
         out["roofline"] = dict(roof0, traffic=traffic)
         if traffic_note:

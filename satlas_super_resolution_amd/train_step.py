@@ -316,7 +316,11 @@ class ESRGANTrainStep:
         g.replay()
 
     def _dp_step_body(self):
-        """the forked data-parallel step as one stream program (captured whole when SSR_DP_ONE_GRAPH=1; see step())"""
+        """The forked data-parallel step as one stream program (captured whole when SSR_DP_ONE_GRAPH=1; see step()).
+        hipGraph capture on ROCm 7.2 dies (SIGSEGV in hipStreamEndCapture) when the comm stream is ENTERED from two different streams
+        (tools/graph_fork_probe.py: `full` crashes, `curonly` captures), so every exchange is forked from the main stream here: D's
+        exchange is issued after G's slices, once the main stream has taken D's backward as a dependency - all it has left to do by
+        then is G's Adam, which waits for G's exchanges anyway."""
         self._phase_g(run_bwd=False)
         cur = torch.cuda.current_stream()
         if self._side is None:
@@ -325,13 +329,16 @@ class ESRGANTrainStep:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             self._phase_d()
+            d_done = torch.cuda.Event()
+            d_done.record(side)
         segs = getattr(self.g_plan, "bwd_segments", None) or [(self.g_plan.bwd, 0, self.g_store.numel)]
         hgs = []
         for L, off, n in segs:
             L.run()
             hgs.append(self.dp.all_reduce_async(self.g_store.grad[off:off + n]))
+        cur.wait_event(d_done)
+        hd = self.dp.all_reduce_async(self.d_store.grad)          # (forked from the main stream, like G's)
         with torch.cuda.stream(side):
-            hd = self.dp.all_reduce_async(self.d_store.grad)
             self.dp.wait(hd)
             self._phase_opt_d()
         for hg in hgs:

@@ -133,6 +133,11 @@ def test_bench_n_ranks_on_one_gpu_prints_one_json_line(world):
     assert out["config"]["parallelism"] == f"dp{world}" and out["scaling"] == "weak" and out["dtype"] == "fp32x3"
     assert out["value"] == pytest.approx(2 * world * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-6)   # whole-job rate
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+    # per-rank diagnostics: a sub-linear scaling result must be attributable (compute / exposed communication / host) from this one line
+    dpd = out["dp"]
+    assert len(dpd["per_rank_ms_per_step"]) == world and len(dpd["per_rank_host_enqueue_ms_per_step"]) == world
+    assert len(dpd["per_rank_comm_stream_busy_ms_per_step"]) == world and dpd["exchanges_per_step"] == 4      # G's three slices + D's arena
+    assert dpd["algo"] == "allreduce" and dpd["exchanged_bytes_per_step"] > 0 and all(v > 0 for v in dpd["per_rank_ms_per_step"])
 
 
 @pytest.mark.gpu
@@ -171,9 +176,8 @@ def _rccl_worker(port, outdir):
     assert torch.distributed.get_backend() == "nccl" and ctx.active and ctx.world == 1
     g0, d0 = O.generator_init(seed=5, **G_KW), O.discriminator_init(3, 8, seed=6)
     res = {}
-    # "dp_one_graph": SSR_DP_ONE_GRAPH=1 (the whole data-parallel step, RCCL collectives included, captured as ONE graph per rank) with
-    # SSR_DP_ALGO=rsag (reduce-scatter + all-gather over the padded arenas)
-    for name, dp in (("dp", ctx), ("dp_one_graph", DPContext(ctx.group, 0, 1, force=True, algo="rsag")), ("single", DPContext(None, 0, 1))):
+    # "dp_one_graph": SSR_DP_ONE_GRAPH=1 (the whole data-parallel step, RCCL collectives included, captured as ONE graph per rank)
+    for name, dp in (("dp", ctx), ("dp_one_graph", DPContext(ctx.group, 0, 1, force=True, algo=os.environ.get("SSR_TEST_DP_ALGO", "allreduce"))), ("single", DPContext(None, 0, 1))):
         os.environ["SSR_DP_ONE_GRAPH"] = "1" if name == "dp_one_graph" else "0"
         ts = ESRGANTrainStep(G_KW, D_KW, 2, 8, 8, "fp32", StepConfig(), dp=dp, use_graph=True)
         ts.load_state(g0, d0)

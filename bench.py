@@ -117,6 +117,15 @@ def instrumented_step(ts, args, dtype=None):
                 sym = family(exact) + " [x%d classes]" % n if not exact.startswith("conv_bigx3_kernel4") else family(exact)
                 SYMBOLS.setdefault(sym, set()).add(exact)
                 fl = sum(conv_flops(ds[k]) for k in range(n))
+            elif name == "ssr_conv2d_chain":
+                ds, n = a[0], a[1]      # a dependent chain of body convs in one persistent launch (csrc/conv_x3c.hip)
+                exact = hip.conv_symbol(ds[0])
+                if lib.ssr_conv2d_chain_ok(ds, n):
+                    sym = "conv_x3c_kernel<%s>" % exact.rstrip(">").split(",")[-1].strip()
+                    SYMBOLS.setdefault(sym, set()).add(sym)
+                else:
+                    sym = family(exact) + " [chain run as %d launches]" % n
+                fl = sum(conv_flops(ds[k]) for k in range(n))
             elif name in ("ssr_rdb_forward", "ssr_rdb_backward"):
                 d = a[0]._obj          # five 3x3 convs of one dense block: K = 64..192 -> N = 32,32,32,32,64
                 bw = "true" if name.endswith("backward") else "false"       # the kernel symbol this launch runs (8x16- or 8x8-tile kernel)

@@ -136,6 +136,18 @@ int ssr_conv2d_impl(const ssr_conv_desc* d, void* stream, int32_t impl);
  * KH*1000 + stride*100 + NT*10 + WAVES (NT = 32-channel output tiles per wave, WAVES per workgroup);
  * used by bench.py to attribute launch durations to kernel symbols.  Negative on error. */
 int ssr_conv2d_variant(const ssr_conv_desc* d);
+/* A dependent CHAIN of n (2..4) stride-1 3x3 SSR_F32X3 convolutions over one grid in ONE persistent launch (csrc/conv_x3c.hip): the dense
+ * block's conv1..conv4 (rrdbnet_arch.py:37-41: each reads the channel prefix the earlier ones extend) or the slices 4..1 of its gather-form
+ * backward.  The workgroups of an image hand their results to each other through memory (write-through stores, per-tile flag words,
+ * bounded polls); a later descriptor may read what an earlier one writes, nothing else may alias.
+ *   state: ssr_conv2d_chain_state_bytes(N, Gh, Gw) bytes of device memory, zeroed ONCE by the host, owned by the launches of ONE stream
+ *          (consecutive launches reuse it: tickets, epoch and flags re-arm themselves; concurrent chains need one each).
+ * When the list does not qualify (ssr_conv2d_chain_ok: 32 output channels each, one of the straight-line epilogues - bias + LeakyReLU,
+ * plain, or LeakyReLU-backward mask - shared by all, <= 64 tiles per image) or state is NULL: n ssr_conv2d launches, same results
+ * (forward chains bit for bit; backward chains sum K in the opposite direction). */
+int ssr_conv2d_chain(const ssr_conv_desc* ds, int32_t n, void* state, void* stream);
+int ssr_conv2d_chain_ok(const ssr_conv_desc* ds, int32_t n);
+int64_t ssr_conv2d_chain_state_bytes(int32_t N, int32_t Gh, int32_t Gw);
 /* The kernel symbol ssr_conv2d launches for this descriptor as rocprofv3 prints it (without the "void (anonymous namespace)::" prefix and
  * the argument list), e.g. "conv_x3r_kernel<1, 0>": the key under which bench.py, tools/pmc_traffic.py, tools/pmc_sq.py and
  * tools/roofline_check.py file a launch, so that roofline.kernel can be found in profiles/ by name.  buflen >= 48. */

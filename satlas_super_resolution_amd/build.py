@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv.hip", "conv_res.hip", "conv_ws.hip", "conv_big.hip", "conv_big_x3.hip", "conv_x3q.hip", "conv_x3r.hip", "conv_thin.hip", "rdb_fwd.hip", "rdb_tile.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_x3.hip", "misc.hip", "metrics.hip", "vgg.hip"]
+SOURCES = ["conv.hip", "conv_res.hip", "conv_ws.hip", "conv_big.hip", "conv_big_x3.hip", "conv_x3q.hip", "conv_x3r.hip", "conv_x3c.hip", "conv_thin.hip", "rdb_fwd.hip", "rdb_tile.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_x3.hip", "misc.hip", "metrics.hip", "vgg.hip"]
 OUT = os.path.join(HERE, "libssr_hip.so")
 
 

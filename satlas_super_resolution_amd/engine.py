@@ -446,6 +446,7 @@ def gather_dgrad(cb: "_ConvBuilder", L: Launcher, prefix: str, k: int, x1: View,
     d.m, d.m_c0, d.m_c1 = epi.get("m", hip.NULL_VIEW), epi.get("m_c0", 0), epi.get("m_c1", 0)
     cb.keep.append(d)
     L.add(hip.lib().ssr_conv2d, C.byref(d), what=f"conv dgrad-gather {prefix}.slice{k}")
+    return d
 
 
 # split-bf16 mode (fp32x3): LeakyReLU decision fix-up (ssr_conv2d_fixup), OFF by default (SSR_X3_FIXUP=1 switches it on).
@@ -812,6 +813,16 @@ class GeneratorPlan:
         assert self.out.shape[:3] == (B, self.Ho, self.Wo)
         cb = self._cb = _ConvBuilder(store, B)
         self._cb = cb
+        # fp32x3, SSR_X3_CHAIN=1 (OFF by default): the dense block's conv1..conv4 (and slices 4..1 of its backward) as one persistent
+        # chain launch each (csrc/conv_x3c.hip); the chain's tickets / epoch / flag words live in a small device buffer owned by THIS
+        # plan's launches (one stream at a time).  Built and measured in round 6 - and slower than the four
+        # launches it replaces: 51.0 against 44 - 48 us per dense block stand-alone (tools/chain_time.py), 26.30 against 25.87 ms per step
+        # (call r06i, same box): what the removed launch boundaries save (gap + wave start + first loads) the hand-over spends again
+        # (write-through stores drained before the flag, flag visibility, the neighbours' skew) - DESIGN.md lesson 63.
+        self._chain_state = None
+        if (self.dt == hip.F32X3 and nf == 64 and gc == 32 and not X3_FIXUP[0] and os.environ.get("SSR_X3_CHAIN", "0") == "1"):
+            nbytes = int(hip.lib().ssr_conv2d_chain_state_bytes(B, H, W))
+            self._chain_state = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
         # ------------------------------------------------------------------ forward
         F = Launcher()
         buf = lambda r: self.bufs[r % n_bufs]
@@ -842,9 +853,13 @@ class GeneratorPlan:
                 self._rdb_descs.append(rd)
                 F.add(hip.lib().ssr_rdb_forward, C.byref(rd), what=f"rdb fwd {p}")
                 continue
-            for k in range(1, 5):
-                cb.conv(F, f"{p}.conv{k}", view(cur, 0), H, W, view(cur, nf + (k - 1) * gc), act=hip.ACT_LRELU,
-                        cin=nf + (k - 1) * gc)
+            # conv1..conv4: each reads the channel prefix the earlier ones extend.  fp32x3: ONE persistent launch for the four
+            # (csrc/conv_x3c.hip, ssr_conv2d_chain; falls back to four launches by itself where the chain does not qualify)
+            tmp = Launcher() if self._chain_state is not None else F
+            ds = [cb.conv(tmp, f"{p}.conv{k}", view(cur, 0), H, W, view(cur, nf + (k - 1) * gc), act=hip.ACT_LRELU,
+                          cin=nf + (k - 1) * gc) for k in range(1, 5)]
+            if tmp is not F:
+                self._add_chain(F, ds, f"conv chain fwd {p}.conv1-4")
             if j < 2:   # x5*0.2 + x                                            (rrdbnet_arch.py:44)
                 cb.conv(F, f"{p}.conv5", view(cur, 0), H, W, dst, alpha=0.2, r1=view(cur, 0), r1_nc=nf, beta1=1.0,
                         cin=cd)
@@ -991,9 +1006,11 @@ class GeneratorPlan:
                 continue
             # gather form: slice k <- one conv over [dpre_{k+1} .. dpre_4 | d_out]; every slice is written once,
             # masked by lrelu'(x_k) in the epilogue, so dgrad needs no read-modify-write
-            for k in (4, 3, 2, 1):
-                gather_dgrad(cb, Bk, p, k, view(dcur, nf + k * gc), (4 - k) * gc, d_out_r, nf, H, W,
-                             view(dcur, nf + (k - 1) * gc), gc, m=view(cur, nf + (k - 1) * gc), m_c0=0, m_c1=gc)
+            tmp = Launcher() if self._chain_state is not None else Bk
+            ds = [gather_dgrad(cb, tmp, p, k, view(dcur, nf + k * gc), (4 - k) * gc, d_out_r, nf, H, W,
+                               view(dcur, nf + (k - 1) * gc), gc, m=view(cur, nf + (k - 1) * gc), m_c0=0, m_c1=gc) for k in (4, 3, 2, 1)]
+            if tmp is not Bk:
+                self._add_chain(Bk, ds, f"conv chain dgrad-gather {p}.slice4-1")
             kw = dict(r1=d_out_r, r1_nc=nf, beta1=b5)        # the `+ x` path of this RDB         (rrdbnet_arch.py:44)
             if j == 0:                                          # d x_rrdb += d out_rrdb             (rrdbnet_arch.py:68)
                 kw.update(r2=d_rrdb, r2_nc=nf, beta2=1.0)
@@ -1023,6 +1040,14 @@ class GeneratorPlan:
             assert sum(n for _, _, n in self.bwd_segments) == st.numel and self.bwd_segments[-1][1] == 0
         else:
             self.bwd = Bk
+
+    def _add_chain(self, L: Launcher, descs, what: str):
+        """one ssr_conv2d_chain call for a list of already filled descriptors (copied into one ctypes array)"""
+        arr = (ConvDesc * len(descs))()
+        for i, d in enumerate(descs):
+            C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(ConvDesc))
+        self._cb.keep.append(arr)
+        L.add(hip.lib().ssr_conv2d_chain, arr, len(descs), self._chain_state.data_ptr(), what=what)
 
     # ---- boundary: NCHW fp32 tensors of the reference API ----
     def load_input(self, x_nchw: torch.Tensor, scale: float = 1.0):

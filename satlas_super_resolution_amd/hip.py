@@ -119,7 +119,7 @@ class AdamArgs(C.Structure):
 
 # every symbol include/ssr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ssr_conv2d", "ssr_conv2d_fixup", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_symbol", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
+    "ssr_conv2d", "ssr_conv2d_fixup", "ssr_conv2d_batch", "ssr_conv2d_impl", "ssr_conv2d_variant", "ssr_conv2d_symbol", "ssr_conv2d_chain", "ssr_conv2d_chain_ok", "ssr_conv2d_chain_state_bytes", "ssr_conv2d_ck", "ssr_conv2d_s2d_ok", "ssr_rdb_forward", "ssr_rdb_backward", "ssr_rdb_tile_of", "ssr_conv2d_wgrad", "ssr_wgrad_reduce", "ssr_wgrad_tiles", "ssr_wgrad_ci_tile", "ssr_wgrad_co_tile", "ssr_pack_weights", "ssr_pack_dgrad_gather", "ssr_add_views", "ssr_nchw_to_nhwc", "ssr_nhwc_to_nchw",
     "ssr_fill", "ssr_bilinear2x_fwd", "ssr_bilinear2x_bwd", "ssr_nearest2x_bwd", "ssr_spectral_norm",
     "ssr_spectral_norm_bwd", "ssr_usm_sharp", "ssr_l1_loss", "ssr_bce_logits_loss", "ssr_adam_step", "ssr_axpby_f32",
     "ssr_quantize_u8", "ssr_metric_shift_sums", "ssr_metric_ssim_sums", "ssr_split_bf16", "ssr_split_bf16_multi", "ssr_channel_affine", "ssr_relu_maxpool2_fwd", "ssr_relu_maxpool2_bwd",
@@ -150,6 +150,9 @@ def lib() -> C.CDLL:
     l.ssr_conv2d_batch.argtypes = [C.POINTER(ConvDesc), i32, vp]
     l.ssr_conv2d_variant.argtypes = [C.POINTER(ConvDesc)]
     l.ssr_conv2d_symbol.argtypes = [C.POINTER(ConvDesc), C.c_char_p, i32]
+    l.ssr_conv2d_chain.argtypes = [C.POINTER(ConvDesc), i32, vp, vp]
+    l.ssr_conv2d_chain_ok.argtypes = [C.POINTER(ConvDesc), i32]
+    l.ssr_conv2d_chain_state_bytes.argtypes = [i32, i32, i32]
     l.ssr_conv2d_ck.argtypes = [i32, i32]
     l.ssr_conv2d_s2d_ok.argtypes = [i32, i32, i32, i32]
     l.ssr_rdb_forward.argtypes = [C.POINTER(RdbDesc), vp]
@@ -187,7 +190,7 @@ def lib() -> C.CDLL:
     l.ssr_device_info.argtypes = [C.c_char_p, i32]
     l.ssr_abi_version.argtypes = []
     for s in ABI_SYMBOLS:
-        getattr(l, s).restype = i32
+        getattr(l, s).restype = i64 if s == "ssr_conv2d_chain_state_bytes" else i32
     _lib = l
     return l
 

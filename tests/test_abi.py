@@ -10,7 +10,7 @@ from conftest import ROOT
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "ssr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int32_t)\s+(ssr_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int32_t|int64_t)\s+(ssr_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

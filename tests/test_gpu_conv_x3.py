@@ -236,6 +236,117 @@ def test_regtile_x3_linear_epilogue_with_two_residuals():
     assert float(nxt[..., cout:].abs().max()) == 0.0           # the other channels of the destination buffer are untouched
 
 
+# ---- the dense block's conv1..conv4 / backward slices 4..1 as ONE persistent chain launch (csrc/conv_x3c.hip, ssr_conv2d_chain) ----
+def _dense_block_fixture(B, H, W, seed):
+    engine, hip = _mods()
+    torch.manual_seed(seed)
+    nf, gc = 64, 32
+    specs = [engine.ConvSpec(f"c{k}", gc, nf + (k - 1) * gc, 3, 1, True, False) for k in range(1, 5)]
+    st = engine.ParamStore(specs, hip.F32X3)
+    sd = {}
+    for k in range(1, 5):
+        cin = nf + (k - 1) * gc
+        sd[f"c{k}.weight"] = torch.randn(gc, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+        sd[f"c{k}.bias"] = torch.randn(gc) * 0.1
+    st.load_state_dict(sd)
+    st.pack()
+    return engine, hip, st, sd
+
+
+def _chain_call(hip, descs, state):
+    arr = (hip.ConvDesc * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(hip.ConvDesc))
+    assert hip.lib().ssr_conv2d_chain_ok(arr, len(descs)) == 1
+    hip.check(hip.lib().ssr_conv2d_chain(arr, len(descs), state.data_ptr(), hip.stream_ptr()), "ssr_conv2d_chain")
+    return arr
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 21, 37), (32, 32, 32), (1, 8, 16), (2, 64, 64)])
+def test_chain_x3_forward_is_bit_identical_to_four_launches(B, H, W):
+    """conv1..conv4 of a dense block (rrdbnet_arch.py:37-41: conv k reads the prefix [x | x1 .. x(k-1)] of the block buffer and appends
+    x_k) in one persistent launch: same bytes as four launches of the register-tiled kernel, and right against float64 torch.
+    Shapes: the body's (also at the benchmarked batch: 256 workgroups, every CU waits on its neighbours), ragged tiles, a single
+    tile per image (no neighbour), 32 tiles per image; run TWICE on the same state (tickets / epoch re-arm themselves)"""
+    engine, hip, st, sd = _dense_block_fixture(B, H, W, 11 + H)
+    nf, gc = 64, 32
+    x0 = (torch.randn(B, H, W, nf, device="cuda") * 0.5).contiguous()
+    bufs = []
+    state = torch.zeros(int(hip.lib().ssr_conv2d_chain_state_bytes(B, H, W) + 3) // 4, dtype=torch.int32, device="cuda")
+    for mode in ("four", "chain", "chain_again"):
+        buf = torch.zeros(B, H, W, nf + 4 * gc, device="cuda")
+        buf[..., :nf] = x0
+        cb = engine._ConvBuilder(st, B)
+        descs = [cb.conv(engine.Launcher(), f"c{k}", hip.view(buf, 0), H, W, hip.view(buf, nf + (k - 1) * gc), act=hip.ACT_LRELU,
+                         cin=nf + (k - 1) * gc) for k in range(1, 5)]
+        if mode == "four":
+            for d in descs:
+                hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), 7), "impl 7")
+        else:
+            _chain_call(hip, descs, state)
+        torch.cuda.synchronize()
+        bufs.append(buf)
+    assert torch.equal(bufs[0].view(torch.int32), bufs[1].view(torch.int32)), int((bufs[0] != bufs[1]).sum())
+    assert torch.equal(bufs[0].view(torch.int32), bufs[2].view(torch.int32))
+    cur = _nchw(x0, nf)
+    for k in range(1, 5):
+        y = F.leaky_relu(F.conv2d(cur, sd[f"c{k}.weight"].double(), sd[f"c{k}.bias"].double(), padding=1), 0.2)
+        e = rel_err(_nchw(bufs[1], nf + 4 * gc)[:, nf + (k - 1) * gc:nf + k * gc], y)
+        assert e < TOL, (k, e)
+        cur = torch.cat([cur, y], 1)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (32, 32, 32), (1, 24, 40)])
+def test_chain_x3_backward_gather_slices(B, H, W):
+    """slices 4..1 of the gather-form dense-block backward (engine.gather_dgrad: slice k <- conv over [dpre_(k+1) .. dpre_4 | d_out], masked
+    by lrelu'(x_k)): the newest slice comes FIRST in K, the chain walks K last to first.  Against four launches (same products, other
+    summation order) and against float64 torch."""
+    engine, hip = _mods()
+    nf, gc = 64, 32
+    torch.manual_seed(5 + H)
+    # "later conv" weights W_j [gc or nf][cin_j] of a dense block; only their gathered (rotated, transposed) packing is needed
+    names = [f"body.0.rdb1.conv{k}" for k in range(1, 6)]
+    specs = [engine.ConvSpec(names[k - 1], gc if k < 5 else nf, nf + (k - 1) * gc, 3, 1, True, False, dgrad_packed=False) for k in range(1, 6)]
+    st = engine.ParamStore(specs, hip.F32X3)
+    sd = {}
+    for k in range(1, 6):
+        cin = nf + (k - 1) * gc
+        sd[names[k - 1] + ".weight"] = torch.randn(gc if k < 5 else nf, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+        sd[names[k - 1] + ".bias"] = torch.zeros(gc if k < 5 else nf)
+    st.load_state_dict(sd)
+    st.add_rdb_gather("body.0.rdb1", nf, gc, 0.2)
+    st.pack()
+    cur = (torch.randn(B, H, W, nf + 4 * gc, device="cuda") * 0.5).contiguous()          # forward activations: the masks
+    d_out = (torch.randn(B, H, W, nf, device="cuda") * 0.5).contiguous()
+    state = torch.zeros(int(hip.lib().ssr_conv2d_chain_state_bytes(B, H, W) + 3) // 4, dtype=torch.int32, device="cuda")
+    outs = []
+    for mode in ("four", "chain"):
+        dcur = torch.zeros(B, H, W, nf + 4 * gc, device="cuda")
+        cb = engine._ConvBuilder(st, B)
+        descs = [engine.gather_dgrad(cb, engine.Launcher(), "body.0.rdb1", k, hip.view(dcur, nf + k * gc), (4 - k) * gc, hip.view(d_out), nf, H, W,
+                                     hip.view(dcur, nf + (k - 1) * gc), gc, m=hip.view(cur, nf + (k - 1) * gc), m_c0=0, m_c1=gc) for k in (4, 3, 2, 1)]
+        if mode == "four":
+            for d in descs:
+                hip.check(hip.lib().ssr_conv2d_impl(C.byref(d), hip.stream_ptr(), 7), "impl 7")
+        else:
+            _chain_call(hip, descs, state)
+        torch.cuda.synchronize()
+        outs.append(dcur)
+    assert rel_err(outs[1].double().cpu(), outs[0].double().cpu()) < 1e-5
+    # float64: dpre_k = lrelu'(x_k) * sum_{j > k} conv_transpose(dpre_j, W_j[:, slice k]) with dpre_5 = 0.2 * d_out (conv5's scale folded in)
+    g = {5: 0.2 * _nchw(d_out, nf)}
+    for k in (4, 3, 2, 1):
+        lo, hi = nf + (k - 1) * gc, nf + k * gc
+        tot = 0
+        for j in range(k + 1, 6):
+            wj = sd[names[j - 1] + ".weight"].double()[:, lo:hi]
+            tot = tot + F.conv_transpose2d(g[j], wj, padding=1)
+        xk = _nchw(cur, nf + 4 * gc)[:, lo:hi]
+        g[k] = tot * torch.where(xk > 0, torch.ones_like(xk), torch.full_like(xk, 0.2))
+        e = rel_err(_nchw(outs[1], nf + 4 * gc)[:, lo:hi], g[k])
+        assert e < TOL, (k, e)
+
+
 # ---- the thin-output VALU kernel of the fp32 modes (csrc/conv_thin.hip, conv_thin_f32_kernel), forced through ssr_conv2d_impl(impl = 5) ----
 @pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
 @pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "mask_acc", "generic"])

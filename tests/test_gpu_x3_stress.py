@@ -122,3 +122,63 @@ def test_hundreds_of_one_pass_weight_gradient_launches_reproduce_the_first(loade
     torch.cuda.synchronize()
     nb = bad.cpu().tolist()
     assert nb[1] == n and nb[0] == 0, f"{nb[0]} differing words in {n} launches"
+
+
+@pytest.mark.parametrize("loaded", [False, True], ids=["alone", "second_stream_busy"])
+def test_hundreds_of_chain_launches_reproduce_four_launches(loaded):
+    """the persistent dense-block chain (csrc/conv_x3c.hip, opt-in SSR_X3_CHAIN=1): conv1..conv4 in one launch of 256 workgroups that hand
+    their results to each other through memory (write-through stores, per-tile flag bytes, ticketed tiles, self re-arming epoch).  Every
+    launch must give the bytes of four register-tiled launches - also while a second stream takes CUs away (workgroups of an image
+    then start at different times: the case the ticket order exists for)."""
+    from satlas_super_resolution_amd import engine, hip
+    lib = hip.lib()
+    nf, gc = 64, 32
+    torch.manual_seed(3 + int(loaded))
+    specs = [engine.ConvSpec(f"c{k}", gc, nf + (k - 1) * gc, 3, 1, True, False) for k in range(1, 5)]
+    st = engine.ParamStore(specs, hip.F32X3)
+    sd = {}
+    for k in range(1, 5):
+        cin = nf + (k - 1) * gc
+        sd[f"c{k}.weight"] = torch.randn(gc, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+        sd[f"c{k}.bias"] = torch.randn(gc) * 0.1
+    st.load_state_dict(sd)
+    st.pack()
+    x0 = (torch.randn(B, H, W, nf, device="cuda") * 0.5).contiguous()
+    state = torch.zeros(int(lib.ssr_conv2d_chain_state_bytes(B, H, W) + 3) // 4, dtype=torch.int32, device="cuda")
+    cb = engine._ConvBuilder(st, B)
+
+    def descs_on(buf):
+        ds = [cb.conv(engine.Launcher(), f"c{k}", hip.view(buf, 0), H, W, hip.view(buf, nf + (k - 1) * gc), act=hip.ACT_LRELU, cin=nf + (k - 1) * gc)
+              for k in range(1, 5)]
+        arr = (hip.ConvDesc * 4)()
+        for i, d in enumerate(ds):
+            C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(hip.ConvDesc))
+        return arr
+
+    ref = torch.zeros(B, H, W, nf + 4 * gc, device="cuda")
+    ref[..., :nf] = x0
+    aref = descs_on(ref)
+    for k in range(4):
+        assert lib.ssr_conv2d_impl(C.byref(aref[k]), None, 7) == 0
+    torch.cuda.synchronize()
+    ref_i = ref.view(torch.int32)
+    NSET = 3
+    bufs = [torch.zeros_like(ref) for _ in range(NSET)]
+    arrs = [descs_on(b) for b in bufs]
+    assert lib.ssr_conv2d_chain_ok(arrs[0], 4) == 1
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    more = _side_load(side) if loaded else None
+    bad = torch.zeros(2, device="cuda", dtype=torch.int64)
+    n = max(100, LAUNCHES // 4)
+    for it in range(n):
+        k = it % NSET
+        if loaded and it % 4 == 0:
+            more()
+        bufs[k].zero_()
+        bufs[k][..., :nf] = x0
+        assert lib.ssr_conv2d_chain(arrs[k], 4, state.data_ptr(), main.cuda_stream) == 0
+        bad[0] += (bufs[k].view(torch.int32) != ref_i).sum()
+        bad[1] += 1
+    torch.cuda.synchronize()
+    nb = bad.cpu().tolist()
+    assert nb[1] == n and nb[0] == 0, f"{nb[0]} differing words in {n} chain launches"

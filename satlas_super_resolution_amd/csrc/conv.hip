@@ -919,7 +919,7 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     return dp->KH * 1000 + dp->stride * 100 + (nt2 ? 2 : 1) * 10 + (small ? 2 : 4);
 }
 
-void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* nt, int* ep);
+void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep);
 
 // The kernel symbol ssr_conv2d launches for this descriptor, as rocprofv3 prints it (without the "void (anonymous namespace)::"
 // prefix and the argument list): what bench.py files a launch under, so that roofline.kernel can be looked up in
@@ -934,9 +934,9 @@ extern "C" int ssr_conv2d_symbol(const ssr_conv_desc* dp, char* buf, int32_t buf
     const int w = v % 10, nt = (v / 10) % 10;
     const bool f32m = d.dtype != SSR_BF16;
     if (d.dtype == SSR_F32X3 && w == 5) {
-        int n_ = 1, ep = 3;
-        ssr_conv_x3r_instance(d, &n_, &ep);
-        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d>", n_, ep);
+        int ntw = 1, nu = 1, ep = 3;
+        ssr_conv_x3r_instance(d, &ntw, &nu, &ep);
+        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d>", ntw, nu, ep);
     } else if (d.dtype == SSR_F32X3 && w == 6) snprintf(buf, buflen, "conv_x3q_kernel<%d>", nt);
     else if (d.dtype == SSR_F32X3 && w == 9) snprintf(buf, buflen, "conv_bigx3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
     else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %s>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? "true" : "false");

@@ -57,7 +57,7 @@ typedef __attribute__((address_space(1))) unsigned char gu8;
 
 template <int EP>
 __global__ __launch_bounds__(XR_NTHR) void conv_x3c_kernel(const ssr_chain_args a) {
-    using T = XrT<1>;
+    using T = XrT<1, 1>;
     constexpr int WR = T::WR, TPS = T::TPS, SPT = 4 / TPS, NSUB = 3 * SPT, NSETS = T::NSETS, PD = NSETS - 1;
     static_assert(WR == 6 && NSUB * 2 % NSETS == 0, "item-parity unrolling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -411,7 +411,7 @@ bool overlap(const ssr_view& a, int na, const ssr_view& b, int nb) {
 }  // namespace
 
 bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d);
-void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* nt, int* ep);
+void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep);
 
 extern "C" int64_t ssr_conv2d_chain_state_bytes(int32_t N, int32_t Gh, int32_t Gw) {
     return XC_STATE_HDR + (int64_t)N * ((Gw + 15) / 16) * ((Gh + 7) / 8) * 16;
@@ -427,8 +427,8 @@ extern "C" int ssr_conv2d_chain_ok(const ssr_conv_desc* ds, int32_t n) {
         if (!ssr_conv_x3r_shape_ok(d) || d.CoutPad != 32 || d.Cout > 32) return 0;
         if (d.N != ds[0].N || d.Hi != ds[0].Hi || d.Wi != ds[0].Wi || d.Gh != ds[0].Gh || d.Gw != ds[0].Gw) return 0;
         if ((d.Cin % 16) != 0 || (d.x2.p && (d.Cin2 % 16) != 0) || (d.Cin + d.Cin2) / 16 > XC_MAXCH || d.Cin + d.Cin2 < 16) return 0;
-        int nt = 0, ep = 3;
-        ssr_conv_x3r_instance(d, &nt, &ep);
+        int nt = 0, nu = 0, ep = 3;
+        ssr_conv_x3r_instance(d, &nt, &nu, &ep);
         if (ep == XR_EP_GENERIC || (ep0 >= 0 && ep != ep0)) return 0;
         ep0 = ep;
         // no later conv of the chain may overwrite what an earlier one reads or writes (a workgroup runs ahead of its neighbours)
@@ -492,7 +492,7 @@ extern "C" int ssr_conv2d_chain(const ssr_conv_desc* ds, int32_t n, void* state,
     a.tiles_x = (ds[0].Gw + 15) / 16;
     a.tiles_y = (ds[0].Gh + 7) / 8;
     a.state = reinterpret_cast<uint32_t*>(state);
-    int ep = 3, nt = 0;
+    int ep = 3, nt = 0, nu = 0;
     for (int k = 0; k < n; ++k) {
         a.d[k] = ds[k];
         const ssr_conv_desc& d = ds[k];
@@ -511,7 +511,7 @@ extern "C" int ssr_conv2d_chain(const ssr_conv_desc* ds, int32_t n, void* state,
         }
         // dependent chunks must be walked LAST: ascending when the producers grow with the chunk index, else descending
         a.rev[k] = (int8_t)((nch > 1 && firstd > a.dep[k][nch - 1]) ? 1 : 0);
-        ssr_conv_x3r_instance(d, &nt, &ep);
+        ssr_conv_x3r_instance(d, &nt, &nu, &ep);
     }
     const int blocks = a.tiles_x * a.tiles_y * ds[0].N;
     switch (ep) {

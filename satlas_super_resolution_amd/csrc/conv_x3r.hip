@@ -39,12 +39,12 @@
 
 namespace {
 
-template <int NT, int EP>
-__global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d) {
-    using T = XrT<NT>;
-    constexpr int BN = T::BN, WR = T::WR;
+template <int NTW, int NU, int EP>
+__global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ssr_conv_desc d) {
+    using T = XrT<NTW, NU>;
+    constexpr int NT = NTW, NTT = T::NTT, NMF = T::NMF, BN = T::BN, WR = T::WR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* ctl = reinterpret_cast<int*>(smem + T::CTL);          // [0..3] pdone, [4..7] cdone
+    int* ctl = reinterpret_cast<int*>(smem + T::CTL);          // [0..3] pdone, [4 .. 4 + NMF) cdone
     const int ctl_addr = (int)(size_t)(__attribute__((address_space(3))) char*)(smem + T::CTL);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (d.Gw + 15) / 16, tiles_y = (d.Gh + 7) / 8;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
     const int cout_pad = d.CoutPad;
     const int tapstride = cout_pad * 64, wchunk = 9 * tapstride;      // packed bytes per tap / per 16-channel chunk
     RPROBE(tid == 0, 0);
-    if (tid < 8) ctl[tid] = 0;
+    if (tid < 4 + NMF) ctl[tid] = 0;
     __syncthreads();                                           // the only barrier before the reduce
 
     f32x16 acc[4][NT];
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
-    if (wave >= XR_NMFMA) {
+    if (wave >= NMF) {
         // =============================== producer waves: the patch ===============================
-        const int pw = wave - XR_NMFMA;
-        const int pt = tid - 64 * XR_NMFMA;                    // 0..255
+        const int pw = wave - NMF;
+        const int pt = tid - 64 * NMF;                         // 0..255
         const int part = pt & 3, p4 = pt >> 2;
         // vector q of a thread = slot pt + 256 q: patch pixel p4 + 64 q, 16-byte part pt & 3
         int ppix[XR_NPV];                                      // global pixel index of the patch vectors (-1: zeros)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                         // the place is free once every MFMA wave has finished chunk c - NS
                         int spin = 0;
                         for (; spin < XR_SPIN_MAX; ++spin) {
-                            cfree = xr_min4(ctl_addr + 16) + XR_NS;
+                            cfree = xr_minN<NMF>(ctl_addr + 16) + XR_NS;
                             if (c < cfree) break;
                             __builtin_amdgcn_s_sleep(2);
                         }
@@ -156,16 +156,16 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
         RPROBE(pt == 0, 9);
     } else {
         // =============================== MFMA waves: all four pixel tiles, a quarter of K ===============================
-        const int w = wave;
+        const int w = wave & 3, ug = wave >> 2;                             // K quarter, channel-tile group
         const int i = lane & 31, gq = lane >> 5;
         const int a_lane = ((i >> 4) * XR_PW + epi_col<XR_ROT>(i)) * XR_ROWB + gq * 16;     // lane (i, g): channels 8 g .. 8 g + 7 of pixel slot i of tile 0
         const __amdgpu_buffer_rsrc_t rsw = xr_rsrc(d.w, (long)nchunks * wchunk);
-        const int w_lane = (co0 + i) * 64 + gq * 16;
+        const int w_lane = (co0 + 32 * NTW * ug + i) * 64 + gq * 16;
         const int nitems = 3 * nchunks;
         const int nj = nitems > w ? (nitems - w + 3) / 4 : 0;              // this wave's items g = w, w + 4, ...
         const int glast = w + 4 * (nj - 1);
         if (nj == 0) {
-            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = 0x3fffffff;
+            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * wave) = 0x3fffffff;
         } else {
             bf16x8 wf[WR][NT][2];                                          // weight fragments of WR (chunk, tap) steps: [hi | lo]
             constexpr int TPS = T::TPS, SPT = 4 / TPS, NSUB = 3 * SPT, NSETS = T::NSETS, PD = NSETS - 1;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                         // every fragment read of this item has been issued: the chunks below the next item's are finished
                         if (c_next > c_cur) {
                             asm volatile("" ::: "memory");
-                            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = c_next;
+                            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * wave) = c_next;
                             asm volatile("" ::: "memory");
                         }
                         ensure(c_next);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                 if (j < 5) RPROBE(tid == 0, 3 + j);
 #endif
             };
-            if constexpr (WR == 6) {
+            if constexpr (WR == 6 || (NSUB % NSETS) != 0) {                // the register sets of an item depend on its parity
                 for (int j = 0; j < nj; j += 2) {
                     body(j, std::integral_constant<int, 0>{});
                     if (j + 1 < nj) body(j + 1, std::integral_constant<int, 1>{});
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                 for (int j = 0; j < nj; ++j) body(j, std::integral_constant<int, 0>{});
             }
             asm volatile("" ::: "memory");
-            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * w) = 0x3fffffff;
+            if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * wave) = 0x3fffffff;
         }
     }
     __syncthreads();                                           // every wave is out of the ring: it becomes the partial-sum slots
@@ -307,15 +307,16 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
 
     // ---- sum the four K-quarters in wave order through LDS: slot [source wave][pixel tile][channel tile] = 16 registers x 64 lanes,
     //      as four 16-byte vectors per lane ([q][lane][4]: contiguous, conflict-free); wave m keeps tile (m, 0) in registers ----
-    const bool is_mfma = wave < XR_NMFMA;
-    const int me = is_mfma ? wave : wave - XR_NMFMA;           // the pixel tile this wave finishes
+    const bool is_mfma = wave < NMF;
+    const int me = is_mfma ? (wave & 3) : wave - NMF;          // the pixel tile this wave finishes
+    const int ut = is_mfma ? NTW * (wave >> 2) : 1;            // ... and the channel tile (producers: the second tile of the one group, NTW = 2)
     if (is_mfma) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int u = 0; u < NT; ++u)
                 if (!(t == me && u == 0)) {
-                    char* sp = smem + ((wave * 4 + t) * NT + u) * XR_SLOT + lane * 16;
+                    char* sp = smem + ((me * 4 + t) * NTT + ut + u) * XR_SLOT + lane * 16;       // source K quarter = wave & 3 = me
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]};
@@ -324,8 +325,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                 }
     }
     __syncthreads();
-    const int ut = is_mfma ? 0 : 1;                            // channel tile this wave finishes
-    if (is_mfma || NT == 2) {
+    if (is_mfma || NTW == 2) {
         f32x16 own;
 #pragma unroll
         for (int r = 0; r < 16; ++r) own[r] = 0.f;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x16 part;
-            const char* sp = smem + ((s * 4 + me) * NT + ut) * XR_SLOT + lane * 16;
+            const char* sp = smem + ((s * 4 + me) * NTT + ut) * XR_SLOT + lane * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sp + q * 1024);
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
                 sum[r] = s == 0 ? p : sum[r] + p;
             }
         }
-        // the transpose slab: a slot no other wave reads (an MFMA wave's own, never written, slot of its tile; a producer's: source wave 0's)
-        char* slab = smem + (((is_mfma ? me : 0) * 4 + me) * NT + ut) * XR_SLOT;
+        // the transpose slab: a slot no other wave reads (an MFMA wave's own, never written, slot of its tile; a producer's: source quarter 0's)
+        char* slab = smem + (((is_mfma ? me : 0) * 4 + me) * NTT + ut) * XR_SLOT;
         const int cb = co0 + 32 * ut;
         if constexpr (EP == XR_EP_GENERIC) conv_epilogue<float, XR_ROT>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
         else xr_epilogue<EP>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
@@ -360,18 +360,19 @@ __global__ __launch_bounds__(XR_NTHR) void conv_x3r_kernel(const ssr_conv_desc d
     RPROBE(tid == 0, 11);
 }
 
-template <int NT, int EP>
+template <int NTW, int NU, int EP>
 int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
-    auto kern = conv_x3r_kernel<NT, EP>;
+    using T = XrT<NTW, NU>;
+    auto kern = conv_x3r_kernel<NTW, NU, EP>;
     static bool attr_done[SSR_MAX_DEVICES] = {};               // the attribute is per DEVICE
     const int dev = ssr_device_ordinal();
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XrT<NT>::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS);
         if (e != hipSuccess) return (int)e;
         attr_done[dev] = true;
     }
     const int tiles = ((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N;
-    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / (32 * NT), 1), dim3(XR_NTHR), XrT<NT>::LDS, st, d);
+    hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / T::BN, 1), dim3(T::NTHR), T::LDS, st, d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }
@@ -391,22 +392,35 @@ int xr_pick_epilogue(const ssr_conv_desc& d) {
     return XR_EP_GENERIC;
 }
 
-template <int NT>
+template <int NTW, int NU>
 int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
     switch (xr_pick_epilogue(d)) {
-        case XR_EP_LRELU: return launch_x3r<NT, XR_EP_LRELU>(d, st);
-        case XR_EP_LIN: return launch_x3r<NT, XR_EP_LIN>(d, st);
-        case XR_EP_MASK: return launch_x3r<NT, XR_EP_MASK>(d, st);
-        default: return launch_x3r<NT, XR_EP_GENERIC>(d, st);
+        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU>(d, st);
+        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN>(d, st);
+        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK>(d, st);
+        default: return launch_x3r<NTW, NU, XR_EP_GENERIC>(d, st);
     }
+}
+
+// the form of the 64-channel layers: 1 = four MFMA waves with two channel tiles each (default); 2 = eight MFMA waves, one channel tile each
+// (SSR_X3_REGTILE_NT2=8: 21.6 against 22.4 us per launch alone - the K-quarter sum + epilogue falls from 5.7 k to 3.7 k ticks - but 27.38
+// against 27.24 ms per step, call r06j: twelve-wave workgroups share the chip worse with the second chain and the discriminator stream);
+// 0 = as two 32-channel workgroups (SSR_X3_REGTILE_NT2=0)
+int xr_wide_form(const ssr_conv_desc& d) {
+    static const int f = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return !e ? 1 : e[0] == '0' ? 0 : e[0] == '8' ? 2 : 1; }();
+    if ((d.CoutPad % 64) != 0) return 0;
+    // the generic epilogue does not fit the 168 registers of a twelve-wave workgroup (77 spilled): those (rare) layers keep the four-wave form
+    return (f == 2 && xr_pick_epilogue(d) == XR_EP_GENERIC) ? 1 : f;
 }
 
 }  // namespace
 
-// NT and straight-line-epilogue index of the instantiation ssr_conv_x3r_try launches (the rocprofv3 symbol is conv_x3r_kernel<NT, EP>)
-void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* nt, int* ep) {
-    static const bool nt2_off = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return e && e[0] == '0'; }();
-    *nt = ((d.CoutPad % 64) == 0 && !nt2_off) ? 2 : 1;
+// channel tiles per workgroup, MFMA waves and straight-line-epilogue index of the instantiation ssr_conv_x3r_try launches (the rocprofv3
+// symbol is conv_x3r_kernel<NTW, NU, EP>)
+void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep) {
+    const int f = xr_wide_form(d);
+    *ntw = f == 1 ? 2 : 1;
+    *nu = f == 2 ? 2 : 1;
     *ep = xr_pick_epilogue(d);
 }
 
@@ -430,7 +444,7 @@ bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d) {
 
 bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_x3r_shape_ok(d) : !ssr_conv_x3r_qualifies(d)) return false;
-    static const bool nt2_off = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return e && e[0] == '0'; }();
-    *rc = ((d.CoutPad % 64) == 0 && !nt2_off) ? launch_x3r_ep<2>(d, st) : launch_x3r_ep<1>(d, st);
+    const int f = xr_wide_form(d);
+    *rc = f == 2 ? launch_x3r_ep<1, 2>(d, st) : f == 1 ? launch_x3r_ep<2, 1>(d, st) : launch_x3r_ep<1, 1>(d, st);
     return true;
 }

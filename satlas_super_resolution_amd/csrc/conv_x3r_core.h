@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int XR_NMFMA = 4, XR_NPROD = 4, XR_NTHR = 64 * (XR_NMFMA + XR_NPROD);
+constexpr int XR_NMFMA = 4, XR_NPROD = 4, XR_NTHR = 64 * (XR_NMFMA + XR_NPROD);      // (the 32-channel form; XrT<NTW, NU>::NMF / NTHR in general)
 constexpr int XR_ROWB = 80, XR_PH = 10, XR_PW = 18, XR_NPIX = XR_PH * XR_PW;       // 8 x 16 tile + halo, rows [16 hi | 16 lo | pad]
 constexpr int XR_SUB = XR_NPIX * XR_ROWB;                      // one 16-channel chunk of the patch: 14,400 B
 constexpr int XR_NS = 8;                                       // ring stages (one chunk each)
@@ -24,17 +24,24 @@ constexpr int XR_SPIN_MAX = 1 << 22;                           // polls of a fla
 constexpr int XR_TILEB = 2 * XR_PW * XR_ROWB;                  // LDS bytes between the pixel tiles of a wave (two patch rows): 2,880
 constexpr int XR_SLOT = 32 * 32 * 4;                           // one 32 x 32 fp32 partial tile / one transpose slab
 
-template <int NT> struct XrT {
-    static constexpr int BN = 32 * NT;
-    static constexpr int WR = NT == 1 ? 6 : 3;                 // (chunk, tap) steps of weight fragments in flight per wave (8 / 16 registers each)
+// NTW = 32-channel output tiles per MFMA wave, NU = groups of such waves: NU * 4 MFMA waves (K quarter = wave & 3, group = wave >> 2) + 4
+// producer waves, NTW * NU * 32 output channels per workgroup.  Instantiated: <1, 1> the 32-channel layers; <2, 1> the 64-channel layers on
+// four waves with two channel tiles each (default); <1, 2> the 64-channel layers on EIGHT MFMA waves (two per SIMD; every wave one channel
+// tile: SSR_X3_REGTILE_NT2=8, faster alone, not in the step - conv_x3r.hip, xr_wide_form).
+template <int NTW, int NU = 1> struct XrT {
+    static constexpr int NTT = NTW * NU;                       // channel tiles of the workgroup
+    static constexpr int BN = 32 * NTT;
+    static constexpr int NMF = 4 * NU;                         // MFMA waves
+    static constexpr int NTHR = 64 * (NMF + 4);
+    static constexpr int WR = (NTW == 1 && NU == 1) ? 6 : 3;   // (chunk, tap) steps of weight fragments in flight per wave (8 NTW registers each)
 #ifndef XR_TPS1
 #define XR_TPS1 4
 #endif
-    static constexpr int TPS = NT == 1 ? XR_TPS1 : 2;          // pixel tiles per fragment set: a sub-step's MFMAs rotate over TPS NT = 4 accumulators
+    static constexpr int TPS = NTW == 1 ? XR_TPS1 : 2;         // pixel tiles per fragment set: a sub-step's MFMAs rotate over TPS NTW = 4 accumulators
     static constexpr int NSETS = TPS == 4 ? 2 : 3;             // fragment sets in registers (32 / 16 registers each); reads run NSETS - 1 sub-steps ahead
-    static constexpr int SLOTS = 4 * 4 * NT;                   // [source wave][pixel tile][channel tile] partial tiles of the K-quarter sum
+    static constexpr int SLOTS = 4 * 4 * NTT;                  // [source K quarter][pixel tile][channel tile] partial tiles of the K-quarter sum
     static constexpr int RED = SLOTS * XR_SLOT;                // 64 / 128 KB (the ring is dead by then)
-    static constexpr int CTL = RED > XR_RING ? RED : XR_RING;  // control words behind both: pdone[4] | cdone[4]
+    static constexpr int CTL = RED > XR_RING ? RED : XR_RING;  // control words behind both: pdone[4] | cdone[NMF]
     static constexpr int LDS = CTL + 256;
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -55,12 +62,22 @@ __device__ __forceinline__ void xr_split4(const u32x4& v, uint2& hi, uint2& lo) 
 }
 typedef __attribute__((address_space(3))) int* xr_lds_int;
 
-// min of the four counters at LDS address `a` (one ds_read_b128).  Inline asm: a compiler-visible LDS read would make hipcc drain
+// min of the four counters at LDS address `a` (one ds_read_b128; xr_minN<8>: eight counters, two reads).  Inline asm: a compiler-visible LDS read would make hipcc drain
 // the wave's global loads first (vmcnt(0)); "=&v": the output must not share registers with the address
 __device__ __forceinline__ int xr_min4(int a) {
     u32x4 v;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     return __builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
+}
+
+template <int N> __device__ __forceinline__ int xr_minN(int a) {
+    if constexpr (N == 4) return xr_min4(a);
+    else {
+        u32x4 v, w;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v), "=&v"(w) : "v"(a) : "memory");
+        const unsigned m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(w[0], w[1]), min(w[2], w[3])));
+        return __builtin_amdgcn_readfirstlane((int)m);
+    }
 }
 
 enum { XR_EP_LRELU = 0, XR_EP_LIN = 1, XR_EP_MASK = 2, XR_EP_GENERIC = 3 };

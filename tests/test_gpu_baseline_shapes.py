@@ -422,7 +422,8 @@ def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
         assert e_dev <= 0.1 and m_dev <= 1e-2, (what, f_dev, e_dev, m_dev)      # sanity bound only: see the docstring
 
 
-@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24), ("fp32x3-fix", "full_g24", 24)])   # full_g96 pins the oracle (CPU test)
+@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24),
+                                            pytest.param("fp32x3-fix", "full_g24", 24, marks=pytest.mark.slow)])   # full_g96 pins the oracle (CPU test)
 def test_generator_vs_reference_class_at_full_size(mode, name, c_in, monkeypatch):
     """SSR_RRDBNet(nf=64, gc=32, nb=23) forward + backward on the device against what the UNMODIFIED reference class produced for
     the same parameters and inputs (oracle/make_golden_fullsize.py; the reference, not the oracle, is the comparison target)."""
@@ -497,7 +498,7 @@ def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
     print(f"[{mode} masked] worst parameter / input gradient deviation from the mask-conditioned float64 oracle: {worst_err:.2e} of max|ref| (asserted <= {tol:.0e})")
 
 
-@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), ("fp32x3-fix", "full_d3")])                    # full_d27 pins the oracle (CPU test)
+@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), pytest.param("fp32x3-fix", "full_d3", marks=pytest.mark.slow)])                    # full_d27 pins the oracle (CPU test)
 def test_discriminator_vs_reference_class_at_full_size(mode, name, monkeypatch):
     """SSR_UNetDiscriminatorSN(nf=64) on 128x128 (3- and 27-channel input) against the unmodified reference class: logits, input
     gradient, parameter gradients through the spectral norm, u / v after the power iteration."""

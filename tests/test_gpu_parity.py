@@ -615,9 +615,10 @@ def _assert_one_ulp(got_nhwc, ref_nchw, what):
 
 @pytest.mark.parametrize("cin,cout,H,W,B,up", [(64, 64, 16, 32, 2, 1), (8, 64, 9, 21, 1, 1), (32, 8, 16, 16, 1, 1),
                                               (64, 128, 8, 16, 1, 1), (24, 32, 5, 7, 2, 2)])
-def test_weight_stationary_conv_matches_pipelined_kernel(cin, cout, H, W, B, up):
-    """csrc/conv_ws.hip forced through ssr_conv2d_impl(impl=1) against the pipelined kernel (impl=3) on the same
-    descriptor, with the whole epilogue contract switched on: bias, LeakyReLU, alpha, both residuals, dual
+def test_weight_stationary_conv_vs_float64_contract_reference(cin, cout, H, W, B, up):
+    """csrc/conv_ws.hip forced through ssr_conv2d_impl(impl=1) AND the pipelined kernel (impl=3) on the same descriptor, each held
+    to an independent float64 torch evaluation of the descriptor contract (_desc_reference) within one bf16 ulp - not to each other -
+    with the whole epilogue contract switched on: bias, LeakyReLU, alpha, both residuals, dual
     outputs, in-place accumulate, LReLU-backward mask, nearest x2 read."""
     import ctypes as C
     engine, hip = _mods()
@@ -690,7 +691,7 @@ def test_weight_stationary_conv_lean_epilogues(variant, cin, cout, H, W, B):
 
 @pytest.mark.parametrize("variant", ["lrelu", "lrelu_r1", "lrelu_r1_y0", "mask", "mask_acc", "mask_r1", "plain", "generic"])
 @pytest.mark.parametrize("cin,cout,H,W,B", [(128, 64, 32, 32, 2), (96, 128, 37, 21, 1), (256, 64, 16, 48, 1)])
-def test_big_tile_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
+def test_big_tile_conv_vs_float64_contract_reference(variant, cin, cout, H, W, B):
     """csrc/conv_big.hip (32x16-pixel x 64-channel workgroup tiles, 4x2 register tiling, rotated lane->pixel map)
     forced through ssr_conv2d_impl(impl=4) against the pipelined kernel (impl=3) on the same descriptor: every
     branch-free epilogue instantiation plus the generic one (alpha, both residuals, dual outputs), ragged sizes."""
@@ -776,7 +777,7 @@ def test_train_step_feeds_usm_sharpened_l1_target():
 
 @pytest.mark.parametrize("variant", ["bias", "lrelu_r1", "mask_acc", "dual"])
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 1, 16, 40, 2), (64, 3, 9, 33, 1), (24, 3, 8, 32, 1), (64, 8, 16, 32, 1)])
-def test_thin_output_conv_matches_pipelined_kernel(variant, cin, cout, H, W, B):
+def test_thin_output_conv_vs_float64_contract_reference(variant, cin, cout, H, W, B):
     """csrc/conv_thin.hip (v_dot2c_f32_bf16 dot products, one pixel per thread; the conv9 / conv_last / conv0-dgrad shapes)
     forced through ssr_conv2d_impl(impl=5) against the pipelined MFMA kernel (impl=3), epilogue features included."""
     import ctypes as C
@@ -892,8 +893,8 @@ def test_big_tile_workgroups_persistent_over_images(groups, monkeypatch):
     2x2 parity classes of the stride-2 dgrad and the space-to-depth forward."""
     monkeypatch.setenv("SSR_CONV_BIG_G", groups)
     for variant in ("plain", "lrelu", "lrelu_r1_y0", "mask_acc", "mask_r1", "generic"):
-        test_big_tile_conv_matches_pipelined_kernel(variant, 128, 64, 32, 32, 3)
-    test_big_tile_conv_matches_pipelined_kernel("lrelu", 32, 64, 37, 21, 3)        # a single chunk per image
+        test_big_tile_conv_vs_float64_contract_reference(variant, 128, 64, 32, 32, 3)
+    test_big_tile_conv_vs_float64_contract_reference("lrelu", 32, 64, 37, 21, 3)        # a single chunk per image
     test_stride2_dgrad_big_tile_parity_classes(128, 64, 32, 32, 3, monkeypatch)
     test_stride2_forward_space_to_depth(64, 128, 32, 32, 3)
     test_stride2_forward_space_to_depth(32, 64, 66, 34, 3)                         # nchunks = 4 (one per parity class)

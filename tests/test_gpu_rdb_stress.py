@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 CS = 192
 N, H, W = 32, 32, 32
-LAUNCHES = int(os.environ.get("SSR_STRESS_LAUNCHES", "2500"))      # per direction and per load condition: 4 x 2500 = 10 000
+LAUNCHES = int(os.environ.get("SSR_STRESS_LAUNCHES", "800"))       # per direction and per load condition (round 4 ran 4 x 2500 = 10 000: SSR_STRESS_LAUNCHES=2500, tools/gpu_round.sh)
 
 
 def _desc(hip, b, bwd, r2, cur, out, dcur, tile):

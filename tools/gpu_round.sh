@@ -12,10 +12,17 @@ export TMPDIR=/tmp
 PYT="python -m pytest -q -p no:cacheprovider"
 PMC_BENCH="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs"
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  # the driver's run: default depth (slow variants skipped); then the slow variants and the deep stress loops on their own
   timeout 1800 $PYT tests -m gpu --durations=12 -s ${PYTEST_ARGS:-} > $O/${TAG}_tests.log 2>&1
   echo "pytest rc=$?" >> $O/${TAG}_tests.log
   grep -E "passed|failed|rc=" $O/${TAG}_tests.log | tail -5
   grep -E "^(FAILED|ERROR)" $O/${TAG}_tests.log | head -40
+  if [ "${SKIP_SLOW:-0}" != "1" ]; then
+    SSR_RUN_SLOW=1 timeout 900 $PYT tests -m "gpu and slow" -s > $O/${TAG}_tests_slow.log 2>&1
+    SSR_STRESS_LAUNCHES=2500 SSR_STRESS_LAUNCHES_X3=4000 timeout 900 $PYT tests/test_gpu_rdb_stress.py tests/test_gpu_x3_stress.py -m gpu -s >> $O/${TAG}_tests_slow.log 2>&1
+    echo "pytest (slow + deep stress) rc=$?" >> $O/${TAG}_tests_slow.log
+    grep -E "passed|failed|rc=" $O/${TAG}_tests_slow.log | tail -3
+  fi
 fi
 if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then      # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one), --kernel-trace only
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)

@@ -72,10 +72,10 @@ def conv_flops(d) -> float:
 
 def family(sym: str) -> str:
     """Kernel FAMILY of a rocprofv3 symbol: launches of one kernel template that differ only in the straight-line epilogue variant
-    (conv_x3r_kernel<NTW, NU, EP>) are one row of the roofline; the exact symbols are listed beside it (roofline.rocprof_symbols)."""
+    (conv_x3r_kernel<NTW, NU, EP, TH>) are one row of the roofline; the exact symbols are listed beside it (roofline.rocprof_symbols)."""
     import re
-    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d>", sym)          # <channel tiles per wave, wave groups, epilogue>
-    return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}>" if m else sym
+    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d)>", sym)          # <channel tiles per wave, wave groups, epilogue, tile height>
+    return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}>" if m else sym
 
 
 WGRAD_FLOPS = {}   # layer-table device pointer -> algorithmic FLOPs of that batched launch
@@ -121,7 +121,7 @@ def instrumented_step(ts, args, dtype=None):
                 ds, n = a[0], a[1]      # a dependent chain of body convs in one persistent launch (csrc/conv_x3c.hip)
                 exact = hip.conv_symbol(ds[0])
                 if lib.ssr_conv2d_chain_ok(ds, n):
-                    sym = "conv_x3c_kernel<%s>" % exact.rstrip(">").split(",")[-1].strip()
+                    sym = "conv_x3c_kernel<%s>" % exact.rstrip(">").split(",")[2].strip()
                     SYMBOLS.setdefault(sym, set()).add(sym)
                 else:
                     sym = family(exact) + " [chain run as %d launches]" % n

@@ -920,6 +920,7 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
 }
 
 void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep);
+int ssr_conv_x3r_tile_height(const ssr_conv_desc& d);
 
 // The kernel symbol ssr_conv2d launches for this descriptor, as rocprofv3 prints it (without the "void (anonymous namespace)::"
 // prefix and the argument list): what bench.py files a launch under, so that roofline.kernel can be looked up in
@@ -936,7 +937,7 @@ extern "C" int ssr_conv2d_symbol(const ssr_conv_desc* dp, char* buf, int32_t buf
     if (d.dtype == SSR_F32X3 && w == 5) {
         int ntw = 1, nu = 1, ep = 3;
         ssr_conv_x3r_instance(d, &ntw, &nu, &ep);
-        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d>", ntw, nu, ep);
+        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d, %d>", ntw, nu, ep, ssr_conv_x3r_tile_height(d));
     } else if (d.dtype == SSR_F32X3 && w == 6) snprintf(buf, buflen, "conv_x3q_kernel<%d>", nt);
     else if (d.dtype == SSR_F32X3 && w == 9) snprintf(buf, buflen, "conv_bigx3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
     else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %s>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? "true" : "false");

@@ -39,20 +39,21 @@
 
 namespace {
 
-template <int NTW, int NU, int EP>
-__global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ssr_conv_desc d) {
-    using T = XrT<NTW, NU>;
-    constexpr int NT = NTW, NTT = T::NTT, NMF = T::NMF, BN = T::BN, WR = T::WR;
+template <int NTW, int NU, int EP, int TH = 8>
+__global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(const ssr_conv_desc d) {
+    using T = XrT<NTW, NU, TH>;
+    constexpr int NT = NTW, NTT = T::NTT, NMF = T::NMF, BN = T::BN, WR = T::WR, MT = T::MT;
+    constexpr int G_NPIX = T::NPIX, G_SUB = T::SUB, G_PV = T::PV, G_NPV = T::NPV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* ctl = reinterpret_cast<int*>(smem + T::CTL);          // [0..3] pdone, [4 .. 4 + NMF) cdone
     const int ctl_addr = (int)(size_t)(__attribute__((address_space(3))) char*)(smem + T::CTL);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (d.Gw + 15) / 16, tiles_y = (d.Gh + 7) / 8;
+    const int tiles_x = (d.Gw + 15) / 16, tiles_y = (d.Gh + TH - 1) / TH;
     int b = blockIdx.x;
     const int tx_i = b % tiles_x; b /= tiles_x;
     const int ty_i = b % tiles_y;
     const int n = b / tiles_y;
-    const int gy0 = ty_i * 8, gx0 = tx_i * 16;
+    const int gy0 = ty_i * TH, gx0 = tx_i * 16;
     const int co0 = blockIdx.y * BN;
     const int Cin = d.Cin, Cin2 = d.Cin2;
     const int nchunks = (Cin + Cin2 + 15) / 16;
@@ -62,9 +63,9 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
     if (tid < 4 + NMF) ctl[tid] = 0;
     __syncthreads();                                           // the only barrier before the reduce
 
-    f32x16 acc[4][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -76,13 +77,13 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
         const int pt = tid - 64 * NMF;                         // 0..255
         const int part = pt & 3, p4 = pt >> 2;
         // vector q of a thread = slot pt + 256 q: patch pixel p4 + 64 q, 16-byte part pt & 3
-        int ppix[XR_NPV];                                      // global pixel index of the patch vectors (-1: zeros)
+        int ppix[G_NPV];                                      // global pixel index of the patch vectors (-1: zeros)
 #pragma unroll
-        for (int q = 0; q < XR_NPV; ++q) {
+        for (int q = 0; q < G_NPV; ++q) {
             const int pix = p4 + 64 * q;
             const int py = pix / XR_PW, px = pix - py * XR_PW;
             const int ly = gy0 + py - d.pad_y, lx = gx0 + px - d.pad_x;
-            const bool okp = pix < XR_NPIX && ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi;
+            const bool okp = pix < G_NPIX && ly >= 0 && ly < d.Hi && lx >= 0 && lx < d.Wi;
             ppix[q] = okp ? (n * d.Hi + ly) * d.Wi + lx : -1;
         }
         const int plo0 = p4 * XR_ROWB + part * 8;              // hi half of the row; the lo half lies 32 bytes further
@@ -90,7 +91,7 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
         const void* xp = d.x.p;
         const void* x2p = d.x2.p ? d.x2.p : d.x.p;
         const int x_cs = d.x.cs, x_coff = d.x.coff, x2_cs = d.x2.p ? d.x2.cs : d.x.cs, x2_coff = d.x2.p ? d.x2.coff : d.x.coff;
-        u32x4 rq[XR_PQ][XR_NPV];
+        u32x4 rq[XR_PQ][G_NPV];
         auto load_chunk = [&](int c, auto jc) {                // chunk c -> register set j; past the end: zeros, no memory access
             constexpr int j = decltype(jc)::value;
             const bool live = c < nchunks;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
             const __amdgpu_buffer_rsrc_t rs = xr_rsrc(in_x ? xp : x2p, xbytes * cs);
             const int k = cb + part * 4;
 #pragma unroll
-            for (int q = 0; q < XR_NPV; ++q) {
+            for (int q = 0; q < G_NPV; ++q) {
                 const int off = (ppix[q] * cs + coff + k) * 4;             // computed unconditionally, selected below: no branch around a load
                 const bool okl = (k < clim) & (ppix[q] >= 0);
 #ifdef XR_X_NOXLOAD   // (probe switch: the producers publish without loading)
@@ -131,12 +132,12 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
                         }
                         if (spin == XR_SPIN_MAX) __builtin_trap();         // a protocol bug must be loud, not wrong activations
                     }
-                    char* base = smem + (c % XR_NS) * XR_SUB;
+                    char* base = smem + (c % XR_NS) * G_SUB;
 #pragma unroll
-                    for (int q = 0; q < XR_NPV; ++q) {
+                    for (int q = 0; q < G_NPV; ++q) {
                         uint2 hi, lo;
                         xr_split4(rq[j][q], hi, lo);
-                        if (q < XR_NPV - 1 || pt < XR_PV - (XR_NPV - 1) * 256) {
+                        if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256) {
                             *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB) = hi;
                             *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB + 32) = lo;
                         }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
             if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 16 + 4 * wave) = 0x3fffffff;
         } else {
             bf16x8 wf[WR][NT][2];                                          // weight fragments of WR (chunk, tap) steps: [hi | lo]
-            constexpr int TPS = T::TPS, SPT = 4 / TPS, NSUB = 3 * SPT, NSETS = T::NSETS, PD = NSETS - 1;
+            constexpr int TPS = T::TPS, SPT = T::SPT, NSUB = 3 * SPT, NSETS = T::NSETS, PD = NSETS - 1;
             bf16x8 af[NSETS][TPS][2];                                      // pixel fragments of NSETS sub-steps (TPS tiles each): [hi | lo]
             auto load_w = [&](int g_, auto kxc, auto sc) {                 // step (item g, tap kx) -> register set s
                 constexpr int kx = decltype(kxc)::value, s = decltype(sc)::value;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
                 }
                 if (spin == XR_SPIN_MAX) __builtin_trap();
             };
-            auto base_of = [&](int g_) { const int c = g_ / 3, ky = g_ - 3 * c; return (c % XR_NS) * XR_SUB + ky * XR_PW * XR_ROWB + a_lane; };
+            auto base_of = [&](int g_) { const int c = g_ / 3, ky = g_ - 3 * c; return (c % XR_NS) * G_SUB + ky * XR_PW * XR_ROWB + a_lane; };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             // weights of the first WR steps (they depend on nobody), then the first chunk
@@ -308,15 +309,15 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
     // ---- sum the four K-quarters in wave order through LDS: slot [source wave][pixel tile][channel tile] = 16 registers x 64 lanes,
     //      as four 16-byte vectors per lane ([q][lane][4]: contiguous, conflict-free); wave m keeps tile (m, 0) in registers ----
     const bool is_mfma = wave < NMF;
-    const int me = is_mfma ? (wave & 3) : wave - NMF;          // the pixel tile this wave finishes
+    const int me = is_mfma ? (wave & 3) : wave - NMF;          // the pixel tile this wave finishes (if it is one of the MT tiles) = its K quarter
     const int ut = is_mfma ? NTW * (wave >> 2) : 1;            // ... and the channel tile (producers: the second tile of the one group, NTW = 2)
     if (is_mfma) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int u = 0; u < NT; ++u)
                 if (!(t == me && u == 0)) {
-                    char* sp = smem + ((me * 4 + t) * NTT + ut + u) * XR_SLOT + lane * 16;       // source K quarter = wave & 3 = me
+                    char* sp = smem + ((me * MT + t) * NTT + ut + u) * XR_SLOT + lane * 16;      // source K quarter = wave & 3 = me
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]};
@@ -325,20 +326,20 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
                 }
     }
     __syncthreads();
-    if (is_mfma || NTW == 2) {
+    if ((is_mfma || NTW == 2) && me < MT) {
         f32x16 own;
 #pragma unroll
         for (int r = 0; r < 16; ++r) own[r] = 0.f;
         if (is_mfma) {                                         // runtime tile index -> static register selection
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < MT; ++t)
                 if (t == me) own = acc[t][0];
         }
         f32x16 sum;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x16 part;
-            const char* sp = smem + ((s * 4 + me) * NTT + ut) * XR_SLOT + lane * 16;
+            const char* sp = smem + ((s * MT + me) * NTT + ut) * XR_SLOT + lane * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sp + q * 1024);
@@ -352,7 +353,7 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
             }
         }
         // the transpose slab: a slot no other wave reads (an MFMA wave's own, never written, slot of its tile; a producer's: source quarter 0's)
-        char* slab = smem + (((is_mfma ? me : 0) * 4 + me) * NTT + ut) * XR_SLOT;
+        char* slab = smem + (((is_mfma ? me : 0) * MT + me) * NTT + ut) * XR_SLOT;
         const int cb = co0 + 32 * ut;
         if constexpr (EP == XR_EP_GENERIC) conv_epilogue<float, XR_ROT>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
         else xr_epilogue<EP>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
@@ -360,10 +361,10 @@ __global__ __launch_bounds__((XrT<NTW, NU>::NTHR)) void conv_x3r_kernel(const ss
     RPROBE(tid == 0, 11);
 }
 
-template <int NTW, int NU, int EP>
+template <int NTW, int NU, int EP, int TH = 8>
 int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
-    using T = XrT<NTW, NU>;
-    auto kern = conv_x3r_kernel<NTW, NU, EP>;
+    using T = XrT<NTW, NU, TH>;
+    auto kern = conv_x3r_kernel<NTW, NU, EP, TH>;
     static bool attr_done[SSR_MAX_DEVICES] = {};               // the attribute is per DEVICE
     const int dev = ssr_device_ordinal();
     if (!attr_done[dev]) {
@@ -371,7 +372,7 @@ int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done[dev] = true;
     }
-    const int tiles = ((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N;
+    const int tiles = ((d.Gw + 15) / 16) * ((d.Gh + TH - 1) / TH) * d.N;
     hipLaunchKernelGGL(kern, dim3(tiles, d.CoutPad / T::BN, 1), dim3(T::NTHR), T::LDS, st, d);
     SSR_LAUNCH_CHECK();
     return SSR_OK;
@@ -392,14 +393,24 @@ int xr_pick_epilogue(const ssr_conv_desc& d) {
     return XR_EP_GENERIC;
 }
 
-template <int NTW, int NU>
+template <int NTW, int NU, int TH = 8>
 int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
     switch (xr_pick_epilogue(d)) {
-        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU>(d, st);
-        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN>(d, st);
-        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK>(d, st);
-        default: return launch_x3r<NTW, NU, XR_EP_GENERIC>(d, st);
+        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU, TH>(d, st);
+        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN, TH>(d, st);
+        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK, TH>(d, st);
+        default: return launch_x3r<NTW, NU, XR_EP_GENERIC, TH>(d, st);
     }
+}
+
+// half-height tiles (4 x 16 pixels, <1, 1> form only): when the 8 x 16 tiling of a 32-channel layer would leave more than 3/8 of the
+// CUs without a workgroup (per-GPU batch 16 on the 32 x 32 body: 128 tiles).  SSR_X3_REGTILE_TH=8 | 4 forces one
+int xr_tile_height(const ssr_conv_desc& d, int form) {
+    static const int forced = [] { const char* e = getenv("SSR_X3_REGTILE_TH"); return e ? atoi(e) : 0; }();
+    if (form != 0) return 8;
+    if (forced == 4 || forced == 8) return forced;
+    const long tiles8 = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / 32);
+    return (tiles8 <= 160 && d.Gh > 4) ? 4 : 8;
 }
 
 // the form of the 64-channel layers: 1 = four MFMA waves with two channel tiles each (default); 2 = eight MFMA waves, one channel tile each
@@ -409,6 +420,12 @@ int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
 int xr_wide_form(const ssr_conv_desc& d) {
     static const int f = [] { const char* e = getenv("SSR_X3_REGTILE_NT2"); return !e ? 1 : e[0] == '0' ? 0 : e[0] == '8' ? 2 : 1; }();
     if ((d.CoutPad % 64) != 0) return 0;
+    // a launch that leaves half the chip idle (per-GPU batch 16 on the 32 x 32 body: 128 tiles) runs its 64-channel layers as two
+    // 32-channel workgroups per tile: twice the workgroups, the same products in the same order (an image's bytes do not depend on
+    // the form: every form sums the four K quarters of a (pixel tile, channel tile) in wave order)
+    static const bool split_off = [] { const char* e = getenv("SSR_X3_REGTILE_SPLIT"); return e && e[0] == '0'; }();
+    const long tiles = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N;
+    if (!split_off && tiles * (d.CoutPad / 64) <= 160) return 0;
     // the generic epilogue does not fit the 168 registers of a twelve-wave workgroup (77 spilled): those (rare) layers keep the four-wave form
     return (f == 2 && xr_pick_epilogue(d) == XR_EP_GENERIC) ? 1 : f;
 }
@@ -423,6 +440,7 @@ void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep) {
     *nu = f == 2 ? 2 : 1;
     *ep = xr_pick_epilogue(d);
 }
+int ssr_conv_x3r_tile_height(const ssr_conv_desc& d) { return xr_tile_height(d, xr_wide_form(d)); }
 
 bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d) {
     if (d.dtype != SSR_F32X3 || d.fix_list) return false;
@@ -445,6 +463,8 @@ bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d) {
 bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_x3r_shape_ok(d) : !ssr_conv_x3r_qualifies(d)) return false;
     const int f = xr_wide_form(d);
-    *rc = f == 2 ? launch_x3r_ep<1, 2>(d, st) : f == 1 ? launch_x3r_ep<2, 1>(d, st) : launch_x3r_ep<1, 1>(d, st);
+    if (f == 2) *rc = launch_x3r_ep<1, 2>(d, st);
+    else if (f == 1) *rc = launch_x3r_ep<2, 1>(d, st);
+    else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4>(d, st) : launch_x3r_ep<1, 1, 8>(d, st);
     return true;
 }

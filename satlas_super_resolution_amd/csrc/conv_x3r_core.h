@@ -28,7 +28,15 @@ constexpr int XR_SLOT = 32 * 32 * 4;                           // one 32 x 32 fp
 // producer waves, NTW * NU * 32 output channels per workgroup.  Instantiated: <1, 1> the 32-channel layers; <2, 1> the 64-channel layers on
 // four waves with two channel tiles each (default); <1, 2> the 64-channel layers on EIGHT MFMA waves (two per SIMD; every wave one channel
 // tile: SSR_X3_REGTILE_NT2=8, faster alone, not in the step - conv_x3r.hip, xr_wide_form).
-template <int NTW, int NU = 1> struct XrT {
+template <int NTW, int NU = 1, int TH = 8> struct XrT {
+    static_assert(TH == 8 || TH == 4, "tile height");
+    // tile geometry: TH x 16 pixels = MT 32-pixel MFMA tiles per wave (TH = 4: the half-height tiles of launches that would leave half
+    // the chip idle - per-GPU batch 16 on the 32 x 32 body; the same products in the same order per pixel, tests/test_gpu_conv_x3.py)
+    static constexpr int MT = TH / 2;
+    static constexpr int PH = TH + 2, NPIX = PH * XR_PW;       // tile + halo
+    static constexpr int SUB = NPIX * XR_ROWB;                 // one 16-channel chunk of the patch: 14,400 / 8,640 B
+    static constexpr int RING = XR_NS * SUB;
+    static constexpr int PV = NPIX * 4, NPV = (PV + 255) / 256;         // 16-byte vectors of a chunk's patch; per producer thread: 3 / 2
     static constexpr int NTT = NTW * NU;                       // channel tiles of the workgroup
     static constexpr int BN = 32 * NTT;
     static constexpr int NMF = 4 * NU;                         // MFMA waves
@@ -37,11 +45,12 @@ template <int NTW, int NU = 1> struct XrT {
 #ifndef XR_TPS1
 #define XR_TPS1 4
 #endif
-    static constexpr int TPS = NTW == 1 ? XR_TPS1 : 2;         // pixel tiles per fragment set: a sub-step's MFMAs rotate over TPS NTW = 4 accumulators
-    static constexpr int NSETS = TPS == 4 ? 2 : 3;             // fragment sets in registers (32 / 16 registers each); reads run NSETS - 1 sub-steps ahead
-    static constexpr int SLOTS = 4 * 4 * NTT;                  // [source K quarter][pixel tile][channel tile] partial tiles of the K-quarter sum
+    static constexpr int TPS = (NTW == 1 ? XR_TPS1 : 2) < MT ? (NTW == 1 ? XR_TPS1 : 2) : MT;      // pixel tiles per fragment set
+    static constexpr int SPT = MT / TPS;                       // sub-steps per tap
+    static constexpr int NSETS = SPT == 1 ? 2 : 3;             // fragment sets in registers; reads run NSETS - 1 sub-steps ahead
+    static constexpr int SLOTS = 4 * MT * NTT;                 // [source K quarter][pixel tile][channel tile] partial tiles of the K-quarter sum
     static constexpr int RED = SLOTS * XR_SLOT;                // 64 / 128 KB (the ring is dead by then)
-    static constexpr int CTL = RED > XR_RING ? RED : XR_RING;  // control words behind both: pdone[4] | cdone[NMF]
+    static constexpr int CTL = RED > RING ? RED : RING;        // control words behind both: pdone[4] | cdone[NMF]
     static constexpr int LDS = CTL + 256;
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };

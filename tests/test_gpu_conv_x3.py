@@ -214,6 +214,37 @@ def test_regtile_x3_conv(variant, cin, cout, H, W, B):
     _run_3x3(variant, cin, cout, H, W, B, impl=7)
 
 
+@pytest.mark.parametrize("cin,cout,variant", [(128, 32, "lrelu"), (192, 64, "plain"), (96, 32, "mask")])
+def test_regtile_x3_bytes_of_an_image_do_not_depend_on_the_batch(cin, cout, variant):
+    """the launch shape picks the tiling (8 x 16-pixel tiles when they fill the chip, 4 x 16 at small launches; 64-channel layers as one
+    workgroup per tile or two): every form adds the same products in the same order per output, so an image computed alone (B = 1),
+    in a small batch (B = 4: half-height tiles) and inside the benchmarked batch (B = 32: full tiles) has the same bytes"""
+    engine, hip = _mods()
+    H = W = 32
+    torch.manual_seed(cin)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], hip.F32X3)
+    st.load_state_dict({"c.weight": torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5), "c.bias": torch.randn(cout) * 0.1})
+    st.pack()
+    xall = (torch.randn(32, H, W, cin, device="cuda") * 0.5).contiguous()
+    mall = (torch.randn(32, H, W, cout, device="cuda") * 0.5).contiguous()
+    outs = {}
+    for B in (1, 4, 32):
+        x, m = xall[:B].contiguous(), mall[:B].contiguous()
+        y = torch.zeros(B, H, W, cout, device="cuda")
+        cb = engine._ConvBuilder(st, B)
+        d = cb.conv(engine.Launcher(), "c", hip.view(x), H, W, hip.view(y), act=hip.ACT_LRELU if variant == "lrelu" else hip.ACT_NONE, cin=cin)
+        if variant == "mask":
+            d.m, d.m_c0, d.m_c1 = hip.view(m), 0, cout
+        assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5
+        hip.check(hip.lib().ssr_conv2d(C.byref(d), hip.stream_ptr()), "ssr_conv2d")
+        torch.cuda.synchronize()
+        outs[B] = (y, hip.conv_symbol(d))
+    print({B: v[1] for B, v in outs.items()})
+    assert len({v[1] for v in outs.values()}) >= 2               # the launch shapes really took different instantiations
+    for B in (1, 4):
+        assert torch.equal(outs[B][0].view(torch.int32), outs[32][0][:B].view(torch.int32)), (B, outs[B][1], outs[32][1])
+
+
 def test_regtile_x3_linear_epilogue_with_two_residuals():
     """conv5 of the third dense block of an RRDB: 0.04 (acc + b) + 0.2 x + x_rrdb (rrdbnet_arch.py:44,68) on the straight-line path"""
     engine, hip = _mods()

@@ -60,8 +60,10 @@ def _gen_state(c_in, nb, seed=11):
 # (mode, C_in, B): bf16 at every input width; fp32x3 - the arithmetic bench.py's headline line runs - at the benchmarked
 # configuration exactly (C_in 24, B = 32: big-tile / ring kernels are picked by the grid size); the fp32 modes run the same kernels
 # for any C_in beyond conv_first (C_in 3 / 96 end to end further down)
-@pytest.mark.parametrize("mode,c_in,B", [("bf16", 24, 32), ("bf16", 24, 16), ("bf16", 3, 4), ("bf16", 96, 4), ("fp32", 24, 4),
-                                         ("fp32x3", 24, 32)])
+# (bf16 at C_in 3 / 96 differs from C_in 24 in conv_first only: those two run with SSR_RUN_SLOW=1, tools/gpu_round.sh - the suite must
+#  fit the driver's time budget; the odd input widths keep their kernel-level cases in tests/test_gpu_parity.py)
+@pytest.mark.parametrize("mode,c_in,B", [("bf16", 24, 32), ("bf16", 24, 16), pytest.param("bf16", 3, 4, marks=pytest.mark.slow),
+                                         pytest.param("bf16", 96, 4, marks=pytest.mark.slow), ("fp32", 24, 4), ("fp32x3", 24, 32)])
 def test_generator_every_layer_at_baseline_shape(mode, c_in, B):
     """SSR_RRDBNet(nf=64, nb=23, gc=32) forward + backward, 32x32 tiles: 351 convs forward, their dgrads, 351 weight and
     bias gradients, layer by layer.  (24, 32) is the benchmarked configuration exactly, (24, 16) the launch size of its two

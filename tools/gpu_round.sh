@@ -25,8 +25,9 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
   fi
 fi
 if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then      # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one), --kernel-trace only
-  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
-  (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
+  # (SSR_G_SPLIT=0: full-batch launches, the launch shape roofline.kernel is measured at - bench.py unsplit_twin - and the serial trace uses)
+  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
+  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
   SSR_PMC_DTYPE=fp32x3 python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic_fp32x3.json > /dev/null && cp $O/${TAG}_traffic_fp32x3.json profiles/traffic_fp32x3.json && python -c "
 import json; d=json.load(open('$O/${TAG}_traffic_fp32x3.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
 fi
@@ -45,9 +46,22 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   F=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp $F $O/${TAG}_kernel_stats.csv && head -8 $F | cut -c1-160
   (cd /tmp && SSR_OVERLAP_D=0 SSR_G_SPLIT=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o k -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --blocks-timed 0 --no-legs > /tmp/profs_$TAG.log 2>&1)
   F=$(find /tmp/profs_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp $F $O/${TAG}_kernel_stats_serial.csv
-  (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY \
+  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY \
       --kernel-trace --output-format csv -d /tmp/pmc_$TAG -- python $R/bench.py $PMC_BENCH > /tmp/pmc_$TAG.log 2>&1)
   python tools/pmc_sq.py /tmp/pmc_$TAG $O/${TAG}_pmc_sq.json > /dev/null || tail -20 /tmp/pmc_$TAG.log
+fi
+# roofline.frac recomputed from the serial kernel trace by name (tools/roofline_check.py): profiles/<tag>_roofline_check.txt
+[ -f $O/${TAG}_kernel_stats_serial.csv ] && python tools/roofline_check.py $O/${TAG}_bench.json $O/${TAG}_kernel_stats_serial.csv > $O/${TAG}_roofline_check.txt 2>&1 && head -12 $O/${TAG}_roofline_check.txt
+if [ "${SKIP_DP:-0}" != "1" ]; then           # the data-parallel branch over RCCL at world size 1: per-rank diagnostics of both launch forms
+  : > $O/${TAG}_dp_world1.jsonl
+  for OG in 0 1; do for ALGO in allreduce rsag; do
+    SSR_DP_FORCE=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((29500 + OG * 2 + ${#ALGO})) SSR_DP_ONE_GRAPH=$OG SSR_DP_ALGO=$ALGO \
+      python bench.py --no-cpu-baseline --no-legs --no-roofline --blocks-timed 2 2>/dev/null | tail -1 >> $O/${TAG}_dp_world1.jsonl
+  done; done
+  python -c "
+import json
+for ln in open('$O/${TAG}_dp_world1.jsonl'):
+    d = json.loads(ln); p = d['dp']; print('one_graph', p['one_graph'], p['algo'], round(d['ms_per_step'], 3), 'ms/step; host enqueue', p['per_rank_host_enqueue_ms_per_step'], 'comm busy', p['per_rank_comm_stream_busy_ms_per_step'])"
 fi
 if [ "${SKIP_CONFIGS:-0}" != "1" ]; then      # the other BASELINE.json configurations on this build, one JSON line each
   : > $O/${TAG}_bench_configs.jsonl

@@ -505,6 +505,23 @@ def main():
                    "note": "comm_stream_busy = sum over the step's gradient exchanges of (end - start) on the comm stream: it overlaps the backward "
                            "and the discriminator phases by design; exposed communication = ms_per_step minus the single-GPU step time"}
     dt = float(tmax.item())
+    if dp_diag is not None:
+        # host cost of ONE step with an empty queue (inside the timed loop the host runs ahead until the launch queue pushes back: the
+        # loop's enqueue time then measures the DEVICE): sync, enqueue one step, read the clock - median of five
+        one = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            ts.step()
+            one.append(1e3 * (time.perf_counter() - th))
+        torch.cuda.synchronize()
+        hm = torch.tensor([sorted(one)[2]], device="cuda", dtype=torch.float64)
+        allh = [torch.zeros_like(hm) for _ in range(ctx.world)]
+        torch.distributed.all_gather(allh, hm)
+        dp_diag["per_rank_host_ms_to_enqueue_one_step"] = [round(float(a[0]), 4) for a in allh]
+        dp_diag["note_host"] = ("per_rank_host_ms_to_enqueue_one_step: host wall time of one step() call on an idle stream (graph launches + "
+                                "collectives issued from Python) - what must stay below ms_per_step for the host not to be the bound; "
+                                "per_rank_host_enqueue_ms_per_step is the same inside the timed loop, where a full launch queue blocks the host")
     # beside the contract's single timed region: further blocks of the same K steps, median reported (boxes differ by a few %
     # and a 0.3 s region sees clock ramps)
     blocks = []

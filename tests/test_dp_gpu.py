@@ -138,6 +138,7 @@ def test_bench_n_ranks_on_one_gpu_prints_one_json_line(world):
     assert len(dpd["per_rank_ms_per_step"]) == world and len(dpd["per_rank_host_enqueue_ms_per_step"]) == world
     assert len(dpd["per_rank_comm_stream_busy_ms_per_step"]) == world and dpd["exchanges_per_step"] == 4      # G's three slices + D's arena
     assert dpd["algo"] == "allreduce" and dpd["exchanged_bytes_per_step"] > 0 and all(v > 0 for v in dpd["per_rank_ms_per_step"])
+    assert len(dpd["per_rank_host_ms_to_enqueue_one_step"]) == world and all(v > 0 for v in dpd["per_rank_host_ms_to_enqueue_one_step"])
 
 
 @pytest.mark.gpu

@@ -74,8 +74,8 @@ def family(sym: str) -> str:
     """Kernel FAMILY of a rocprofv3 symbol: launches of one kernel template that differ only in the straight-line epilogue variant
     (conv_x3r_kernel<NTW, NU, EP, TH>) are one row of the roofline; the exact symbols are listed beside it (roofline.rocprof_symbols)."""
     import re
-    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d)>", sym)          # <channel tiles per wave, wave groups, epilogue, tile height>
-    return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}>" if m else sym
+    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d), (\w+)>", sym)          # <channel tiles per wave, wave groups, epilogue, tile height>
+    return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}, {m.group(4)}>" if m else sym
 
 
 WGRAD_FLOPS = {}   # layer-table device pointer -> algorithmic FLOPs of that batched launch

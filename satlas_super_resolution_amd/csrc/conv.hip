@@ -911,6 +911,8 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
             if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
             if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
             if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
+            if (dp->dtype == SSR_F32 && ssr_conv_x3r_qualifies(*dp))
+                return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 5;   // digit 5 = register-tiled (exact fp32 form)
             if (ssr_conv_res_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 1;   // WAVES digit 1 = resident
         }
     }
@@ -934,10 +936,10 @@ extern "C" int ssr_conv2d_symbol(const ssr_conv_desc* dp, char* buf, int32_t buf
     if (v < 0) return v;
     const int w = v % 10, nt = (v / 10) % 10;
     const bool f32m = d.dtype != SSR_BF16;
-    if (d.dtype == SSR_F32X3 && w == 5) {
+    if (d.dtype != SSR_BF16 && w == 5) {
         int ntw = 1, nu = 1, ep = 3;
         ssr_conv_x3r_instance(d, &ntw, &nu, &ep);
-        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d, %d>", ntw, nu, ep, ssr_conv_x3r_tile_height(d));
+        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d, %d, %s>", ntw, nu, ep, ssr_conv_x3r_tile_height(d), d.dtype == SSR_F32 ? "true" : "false");
     } else if (d.dtype == SSR_F32X3 && w == 6) snprintf(buf, buflen, "conv_x3q_kernel<%d>", nt);
     else if (d.dtype == SSR_F32X3 && w == 9) snprintf(buf, buflen, "conv_bigx3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
     else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %s>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? "true" : "false");
@@ -995,6 +997,8 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
     if (impl == 0 && ssr_conv_thin_try(d, st, &rc, false)) return rc;
     if (impl == 0 && ssr_conv_ws_try(d, st, &rc, false)) return rc;
     if (impl == 0 && ssr_conv_big_try(d, st, &rc, false)) return rc;
+    if (d.dtype == SSR_F32 && impl == 7) return ssr_conv_x3r_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+    if (d.dtype == SSR_F32 && impl == 0 && ssr_conv_x3r_try(d, st, &rc, false)) return rc;     // exact fp32 on the register-tiled body kernel (round 6)
     if (impl != 3 && ssr_conv_res_try(d, st, &rc)) return rc;
     if (d.dtype == SSR_F32) return dispatch_geom<float>(d, st);
     if (d.dtype == SSR_BF16) return dispatch_geom<__bf16>(d, st);

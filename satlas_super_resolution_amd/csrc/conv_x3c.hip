@@ -424,7 +424,7 @@ extern "C" int ssr_conv2d_chain_ok(const ssr_conv_desc* ds, int32_t n) {
     int ep0 = -1;
     for (int k = 0; k < n; ++k) {
         const ssr_conv_desc& d = ds[k];
-        if (!ssr_conv_x3r_shape_ok(d) || d.CoutPad != 32 || d.Cout > 32) return 0;
+        if (d.dtype != SSR_F32X3 || !ssr_conv_x3r_shape_ok(d) || d.CoutPad != 32 || d.Cout > 32) return 0;
         if (d.N != ds[0].N || d.Hi != ds[0].Hi || d.Wi != ds[0].Wi || d.Gh != ds[0].Gh || d.Gw != ds[0].Gw) return 0;
         if ((d.Cin % 16) != 0 || (d.x2.p && (d.Cin2 % 16) != 0) || (d.Cin + d.Cin2) / 16 > XC_MAXCH || d.Cin + d.Cin2 < 16) return 0;
         int nt = 0, nu = 0, ep = 3;

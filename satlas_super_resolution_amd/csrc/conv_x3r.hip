@@ -39,7 +39,12 @@
 
 namespace {
 
-template <int NTW, int NU, int EP, int TH = 8>
+// EX: the EXACT fp32 arithmetic mode (SSR_F32) on the same data path - the staged rows hold the 16 fp32 channels of a pixel as they are
+// (64 bytes: the same pitch and the same two 16-byte fragment reads per lane as [16 hi | 16 lo]), the packed fp32 weight rows likewise,
+// and a (tile, tap, chunk) step is eight v_mfma_f32_32x32x2_f32 (lane (i, g) multiplies channels 4 g + s and 8 + 4 g + s, s = 0 .. 3)
+// instead of three bf16 MFMAs.  At 64 cycles per MFMA the step is 5.3 x longer than the split step while every byte moves as before:
+// the mode that every gate of the reference holds in (outputs AND gradients) runs MFMA-bound here.
+template <int NTW, int NU, int EP, int TH = 8, bool EX = false>
 __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(const ssr_conv_desc d) {
     using T = XrT<NTW, NU, TH>;
     constexpr int NT = NTW, NTT = T::NTT, NMF = T::NMF, BN = T::BN, WR = T::WR, MT = T::MT;
@@ -135,11 +140,16 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                     char* base = smem + (c % XR_NS) * G_SUB;
 #pragma unroll
                     for (int q = 0; q < G_NPV; ++q) {
-                        uint2 hi, lo;
-                        xr_split4(rq[j][q], hi, lo);
-                        if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256) {
-                            *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB) = hi;
-                            *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB + 32) = lo;
+                        if constexpr (EX) {                                 // exact mode: the four fp32 channels as they are
+                            if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256)
+                                *reinterpret_cast<u32x4*>(base + p4 * XR_ROWB + part * 16 + q * 64 * XR_ROWB) = rq[j][q];
+                        } else {
+                            uint2 hi, lo;
+                            xr_split4(rq[j][q], hi, lo);
+                            if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256) {
+                                *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB) = hi;
+                                *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB + 32) = lo;
+                            }
                         }
                     }
                     // LDS operations of a wave execute in order: the count follows the data
@@ -236,12 +246,26 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                     constexpr int ws = (JP * 3 + kx) % WR, as = (JP * NSUB + q) % NSETS, asn = (JP * NSUB + qn) % NSETS;
                     auto group = [&](auto pc) {
                         constexpr int P = decltype(pc)::value;             // 0: a_lo w_hi, 1: a_hi w_lo, 2: a_hi w_hi
+                        if constexpr (EX) {
+                            // exact mode: group 0 = channels 8 .. 15 (the fragments read first), groups 1 / 2 = channels 0 .. 7 in two halves
+                            constexpr int H = P == 0 ? 1 : 0, S0 = P == 2 ? 2 : 0, S1 = P == 1 ? 2 : 4;
 #pragma unroll
-                        for (int t2 = 0; t2 < TPS; ++t2)
+                            for (int sidx = S0; sidx < S1; ++sidx)
 #pragma unroll
-                            for (int u = 0; u < NT; ++u)
-                                acc[part * TPS + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[as][t2][P == 0 ? 1 : 0], wf[ws][u][P == 1 ? 1 : 0],
-                                                                                                 acc[part * TPS + t2][u], 0, 0, 0);
+                                for (int t2 = 0; t2 < TPS; ++t2)
+#pragma unroll
+                                    for (int u = 0; u < NT; ++u) {
+                                        const f32x4 av = __builtin_bit_cast(f32x4, af[as][t2][H]), bv = __builtin_bit_cast(f32x4, wf[ws][u][H]);
+                                        acc[part * TPS + t2][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx], acc[part * TPS + t2][u], 0, 0, 0);
+                                    }
+                        } else {
+#pragma unroll
+                            for (int t2 = 0; t2 < TPS; ++t2)
+#pragma unroll
+                                for (int u = 0; u < NT; ++u)
+                                    acc[part * TPS + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[as][t2][P == 0 ? 1 : 0], wf[ws][u][P == 1 ? 1 : 0],
+                                                                                                     acc[part * TPS + t2][u], 0, 0, 0);
+                        }
                     };
                     auto reads = [&](auto hc) {
 #ifndef XR_X_NOA      // (tools/x3r_probe.hip switch: the fragment reads of the prologue are reused)
@@ -361,10 +385,10 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
     RPROBE(tid == 0, 11);
 }
 
-template <int NTW, int NU, int EP, int TH = 8>
+template <int NTW, int NU, int EP, int TH = 8, bool EX = false>
 int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
     using T = XrT<NTW, NU, TH>;
-    auto kern = conv_x3r_kernel<NTW, NU, EP, TH>;
+    auto kern = conv_x3r_kernel<NTW, NU, EP, TH, EX>;
     static bool attr_done[SSR_MAX_DEVICES] = {};               // the attribute is per DEVICE
     const int dev = ssr_device_ordinal();
     if (!attr_done[dev]) {
@@ -393,13 +417,13 @@ int xr_pick_epilogue(const ssr_conv_desc& d) {
     return XR_EP_GENERIC;
 }
 
-template <int NTW, int NU, int TH = 8>
+template <int NTW, int NU, int TH = 8, bool EX = false>
 int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
     switch (xr_pick_epilogue(d)) {
-        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU, TH>(d, st);
-        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN, TH>(d, st);
-        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK, TH>(d, st);
-        default: return launch_x3r<NTW, NU, XR_EP_GENERIC, TH>(d, st);
+        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU, TH, EX>(d, st);
+        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN, TH, EX>(d, st);
+        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK, TH, EX>(d, st);
+        default: return launch_x3r<NTW, NU, XR_EP_GENERIC, TH, EX>(d, st);
     }
 }
 
@@ -435,7 +459,8 @@ int xr_wide_form(const ssr_conv_desc& d) {
 // channel tiles per workgroup, MFMA waves and straight-line-epilogue index of the instantiation ssr_conv_x3r_try launches (the rocprofv3
 // symbol is conv_x3r_kernel<NTW, NU, EP>)
 void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep) {
-    const int f = xr_wide_form(d);
+    int f = xr_wide_form(d);
+    if (d.dtype == SSR_F32 && f == 2) f = 1;
     *ntw = f == 1 ? 2 : 1;
     *nu = f == 2 ? 2 : 1;
     *ep = xr_pick_epilogue(d);
@@ -443,7 +468,9 @@ void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep) {
 int ssr_conv_x3r_tile_height(const ssr_conv_desc& d) { return xr_tile_height(d, xr_wide_form(d)); }
 
 bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d) {
-    if (d.dtype != SSR_F32X3 || d.fix_list) return false;
+    static const bool ex_off = [] { const char* e = getenv("SSR_F32_REGTILE"); return e && e[0] == '0'; }();
+    if (!(d.dtype == SSR_F32X3 || (d.dtype == SSR_F32 && !ex_off)) || d.fix_list) return false;
+    if (d.dtype == SSR_F32 && (d.act == SSR_ACT_RELU || d.m_relu)) return false;      // (the VGG19 layers keep the pipelined kernel: conv2d_impl)
     if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.up == 1 && !d.s2d)) return false;
     if (d.Gh != d.Hi || d.Gw != d.Wi || (d.CoutPad % 32) != 0) return false;
     if (d.x2.p && (d.Cin % 16) != 0) return false;            // a 16-channel chunk comes from ONE view
@@ -463,6 +490,11 @@ bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d) {
 bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_x3r_shape_ok(d) : !ssr_conv_x3r_qualifies(d)) return false;
     const int f = xr_wide_form(d);
+    if (d.dtype == SSR_F32) {                                  // exact fp32 arithmetic: four-wave forms only
+        if (f != 0) *rc = launch_x3r_ep<2, 1, 8, true>(d, st);
+        else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4, true>(d, st) : launch_x3r_ep<1, 1, 8, true>(d, st);
+        return true;
+    }
     if (f == 2) *rc = launch_x3r_ep<1, 2>(d, st);
     else if (f == 1) *rc = launch_x3r_ep<2, 1>(d, st);
     else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4>(d, st) : launch_x3r_ep<1, 1, 8>(d, st);

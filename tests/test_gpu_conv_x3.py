@@ -51,7 +51,7 @@ def _reference(d, w, bias, xb, y_init, r1, r2, m, up=1, cin=None):
 VARIANTS = ["plain", "lrelu", "lrelu_r1_y0", "mask", "mask_acc", "mask_r1", "generic"]
 
 
-def _run_3x3(variant, cin, cout, H, W, B, up=1, impl=4, mode="fp32x3"):
+def _run_3x3(variant, cin, cout, H, W, B, up=1, impl=4, mode="fp32x3", TOL=TOL):
     engine, hip = _mods()
     dt = hip.dtype_code(mode)
     torch.manual_seed(cin + cout + H + len(variant))
@@ -243,6 +243,25 @@ def test_regtile_x3_bytes_of_an_image_do_not_depend_on_the_batch(cin, cout, vari
     assert len({v[1] for v in outs.values()}) >= 2               # the launch shapes really took different instantiations
     for B in (1, 4):
         assert torch.equal(outs[B][0].view(torch.int32), outs[32][0][:B].view(torch.int32)), (B, outs[B][1], outs[32][1])
+
+
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 32, 32, 2), (192, 64, 32, 32, 2), (160, 32, 32, 32, 32), (96, 32, 21, 37, 1), (24, 64, 9, 7, 1),
+                                            (320, 64, 16, 16, 1)])
+def test_regtile_exact_fp32_conv(variant, cin, cout, H, W, B):
+    """the EXACT fp32 arithmetic mode on the register-tiled kernel (csrc/conv_x3r.hip, template flag EX: fp32 rows in the patch ring,
+    v_mfma_f32_32x32x2_f32 - the mode every gate of the reference holds in): the same launch shapes as the split mode, held to the float64
+    contract reference at fp32 accuracy (2e-6 of max|ref|: only the summation order differs from an fp32 evaluation)"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=7, mode="fp32", TOL=2e-6)
+
+
+def test_regtile_exact_fp32_is_the_automatic_choice_for_the_body():
+    engine, hip = _mods()
+    st = engine.ParamStore([engine.ConvSpec("b", 32, 160, 3, 1, True, False)], hip.F32)
+    cb = engine._ConvBuilder(st, 32)
+    buf = torch.zeros(32, 32, 32, 192, device="cuda")
+    d = cb.conv(engine.Launcher(), "b", hip.view(buf, 0), 32, 32, hip.view(buf, 160), act=hip.ACT_LRELU, cin=160)
+    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5 and hip.conv_symbol(d) == "conv_x3r_kernel<1, 1, 0, 8, true>"
 
 
 def test_regtile_x3_linear_epilogue_with_two_residuals():

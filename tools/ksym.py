@@ -23,9 +23,9 @@ def bare(name: str) -> str:
 
 def family(name: str) -> str:
     s = bare(name)
-    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d)>", s)      # <channel tiles per wave, wave groups, epilogue, tile height>
+    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d), (\w+)>", s)      # <channel tiles per wave, wave groups, epilogue, tile height>
     if m:
-        return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}>"
+        return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}, {m.group(4)}>"
     return s
 
 

@@ -32,7 +32,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL ac
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3}   # split operands: three bf16 MFMAs per product   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3, "fp32f": 157.3}   # fp32f: exact fp32 forward (its dominant kernels), split-bf16 backward   # split operands: three bf16 MFMAs per product   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
 
 
 def parse():
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="fp32x3", choices=["bf16", "fp32", "fp32x3"],
+    ap.add_argument("--dtype", default="fp32x3", choices=["bf16", "fp32", "fp32x3", "fp32f"],
                     help="arithmetic mode of the headline line.  Default fp32x3: the fastest mode whose outputs pass the reference's "
                          "1e-3 gate (the reference computes in fp32); bf16 (throughput mode, outside the gate) and exact fp32 are "
                          "reported as `legs` of the same run, timed the same way")
@@ -132,8 +132,9 @@ def instrumented_step(ts, args, dtype=None):
                 sym = ("rdbt_kernel<16, %s>" % bw) if lib.ssr_rdb_tile_of(C.byref(d)) == 16 else ("rdb_kernel<%s>" % bw)
                 fl = 2.0 * RDB_MACS * d.N * d.H * d.W
             elif name == "ssr_conv2d_wgrad":
+                wdt = "fp32x3" if dtype == "fp32f" else dtype          # fp32f: the backward is the split-bf16 mode's
                 sym = {("fp32x3", 3): "wgrad_x3_k3_kernel", ("bf16", 3): "wgrad_bf16_k3_kernel", ("fp32x3", 4): "wgrad_bf16_kernel<4, 4, 2, true> x3 (split passes)",
-                       ("bf16", 4): "wgrad_bf16_kernel<4, 4, 2, false>"}.get((dtype, a[4]), f"wgrad_kernel<{dtype},K{a[4]}>")
+                       ("bf16", 4): "wgrad_bf16_kernel<4, 4, 2, false>"}.get((wdt, a[4]), f"wgrad_kernel<{wdt},K{a[4]}>")
                 fl = WGRAD_FLOPS.get(a[0], 0.0)
             # one event pair per RUN of consecutive launches of the same kernel symbol (the 69 dense blocks of the forward chain are
             # one run): an event record is a barrier packet with a cache release of its own - around every single launch it added
@@ -286,6 +287,11 @@ GATE = {
                           "<= 2e-4 layer-locally (tests/test_gpu_baseline_shapes.py::test_generator_vs_reference_class_at_full_size, "
                           "::test_discriminator_vs_reference_class_at_full_size); against the float64 truth with ITS OWN decisions the first-layer "
                           "gradients leave the 1e-3 gate through flipped LeakyReLU decisions (counted and printed by the same tests)"},
+    "fp32f": {"outputs_1e-3": True, "gradients_1e-3": True,
+              "held_to": "exact fp32 forward (the LeakyReLU decisions are an fp32 evaluation's; outputs 2e-6), split-bf16 backward (gradients 2e-5 "
+                         "given the decisions): every parameter / input gradient inside the gate against the float64 truth, asserted unconditionally "
+                         "like the exact mode's (tests/test_gpu_baseline_shapes.py::test_generator_vs_reference_class_at_full_size[fp32f-...], "
+                         "::test_discriminator_vs_reference_class_at_full_size[fp32f-...])"},
     "fp32": {"outputs_1e-3": True, "gradients_1e-3": True,
              "held_to": "outputs 2e-6; every parameter / input gradient inside the gate against the float64 truth (<= 0.1 % of the elements of a "
                         "tensor outside, asserted), same tests"},
@@ -336,13 +342,23 @@ def unsplit_twin(ts, build):
     return tw, True
 
 
+def peak_for(sym, dtype):
+    """dense MFMA peak the kernel `sym` is priced against: by the arithmetic the KERNEL runs (mode fp32f mixes exact fp32 forward kernels
+    - conv_x3r_kernel<.., true>, conv_kernel<fp32,..> - with split-bf16 backward kernels)"""
+    if dtype != "fp32f":
+        return PEAK_TFLOPS[dtype]
+    exact = sym.endswith(", true>") or "<fp32," in sym or sym.startswith("conv_thin_f32_kernel")
+    return PEAK_TFLOPS["fp32"] if exact else PEAK_TFLOPS["fp32x3"]
+
+
 def roofline_of(agg, dtype):
     """dominant MFMA kernel of an instrumented step: algorithmic FLOPs of its launches / their summed duration"""
     conv = {k: v for k, v in agg.items() if v[2] > 0}
     dom = max(conv, key=lambda k: conv[k][1])
     n, secs, fl = conv[dom]
+    PEAK = {dtype: peak_for(dom, dtype)}
     return dom, {"bound": "mfma", "kernel": dom, "rocprof_symbols": sorted(SYMBOLS.get(dom, {dom})), "launches_per_step": n, "avg_launch_us": 1e6 * secs / n, "flops_per_launch": fl / n,
-                 "achieved": fl / secs / 1e12, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": fl / secs / 1e12 / PEAK_TFLOPS[dtype],
+                 "achieved": fl / secs / 1e12, "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": fl / secs / 1e12 / PEAK[dtype],
                  "traffic": None}
 
 
@@ -370,6 +386,8 @@ ERR_DEFINITION = ("max over outputs of |y - ref| / (max|ref| + |ref|): <= 1e-3 i
 ARITH = {"bf16": "bf16 tensors in HBM; v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput mode: outside the 1e-3 gate by the "
                  "mode's own rounding, BASELINE.json configs[1] names it)",
          "fp32x3": "fp32 tensors in HBM; bf16 MFMA on split operands (hi+lo, 3 MFMAs per product), fp32 accumulate",
+         "fp32f": "fp32 tensors in HBM; forward convolutions v_mfma_f32_32x32x2_f32 (exact fp32), backward convolutions and weight gradients "
+                  "bf16 MFMA on split operands (3 MFMAs per product)",
          "fp32": "fp32 tensors in HBM; v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the bf16 matrix rate)"}
 
 
@@ -629,7 +647,7 @@ def main():
         # the other arithmetic modes of the same step, same configuration, same run, timed like the headline: each with its own
         # roofline and the part of the 1e-3 gate it meets.  `parity_mode` (readers of earlier rounds' lines) names the fp32x3 record.
         legs = {}
-        for leg_dtype in ("fp32x3", "bf16", "fp32"):
+        for leg_dtype in ("fp32x3", "bf16", "fp32f", "fp32"):
             if leg_dtype == args.dtype:
                 continue
             legs[leg_dtype] = precision_leg(args, leg_dtype, g_kw, d_kw, c_in, c_d, B, lr, gt, args.leg_steps or args.steps)

@@ -54,6 +54,12 @@ class ParamStore:
 
     def __init__(self, specs: List[ConvSpec], dtype: int, device="cuda"):
         self.specs = OrderedDict((s.name, s) for s in specs)
+        # mode hip.F32F: forward convolutions exact fp32, everything else (storage, backward convolutions, weight gradients) as fp32x3;
+        # `dtype` is what the C ABI sees for tensors and backward launches, `fwd_dtype` what forward conv descriptors and the forward
+        # packing carry
+        self.mode = dtype
+        self.fwd_dtype = hip.forward_code(dtype)
+        dtype = hip.storage_code(dtype)
         self.dtype = dtype
         self.device = torch.device(device)
         self.offsets: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
@@ -93,16 +99,17 @@ class ParamStore:
         self.pad: Dict[str, Tuple[int, int, int, int]] = {}
         self.s2d: Dict[str, bool] = {}
         items = []
+        fdt = self.fwd_dtype
         for i, s in enumerate(specs):
             kk = s.k * s.k
-            ck_f = L.ssr_conv2d_ck(dtype, s.k)                       # kernel consuming the forward weights
+            ck_f = L.ssr_conv2d_ck(fdt, s.k)                         # kernel consuming the forward weights
             ck_d = L.ssr_conv2d_ck(dtype, s.k if s.stride == 1 else 2)   # dgrad kernel (2x2 parity classes for s2)
             # 4x4 stride-2 layers (discriminator_arch.py:31-35) run as 2x2 layers over a space-to-depth view of their
             # input when the shape allows (ssr_conv_desc.s2d): the forward weights are packed in that order
-            s2d = bool(s.k == 4 and s.stride == 2 and s.s2d is not False and L.ssr_conv2d_s2d_ok(dtype, s.cin, s.cout, rup(s.cout, 32)))
+            s2d = bool(s.k == 4 and s.stride == 2 and s.s2d is not False and L.ssr_conv2d_s2d_ok(fdt, s.cin, s.cout, rup(s.cout, 32)))
             self.s2d[s.name] = s2d
             if s2d:
-                ck_f = 32 if dtype == hip.BF16 else 16     # (split-bf16 mode: 16-channel chunks, csrc/conv_big_x3.hip)
+                ck_f = 32 if fdt == hip.BF16 else 16       # (split-bf16 mode: 16-channel chunks, csrc/conv_big_x3.hip)
             cout_pad, cin_pad = rup(s.cout, 32), rup(rup(s.cin, 8), ck_f)
             cin_pad_o, cout_pad_i = rup(s.cin, 32), rup(rup(s.cout, 8), ck_d)
             self.pad[s.name] = (cout_pad, cin_pad, cin_pad_o, cout_pad_i)
@@ -117,6 +124,21 @@ class ParamStore:
                                   s.cout, s.cin, s.k, s.k, s.stride, cout_pad, cin_pad, cin_pad_o, cout_pad_i, ck_f, ck_d,
                                   1 if s2d else 0))
         self._pack_items = items
+        # mixed mode: the forward packing in the forward kernels' layout (one launch), the backward packing in the backward kernels' (a second)
+        self._pack_items_bwd = None
+        if fdt != dtype:
+            fw, bw = [], []
+            for it in items:
+                a, b = PackItem(), PackItem()
+                C.memmove(C.byref(a), C.byref(it), C.sizeof(PackItem))
+                C.memmove(C.byref(b), C.byref(it), C.sizeof(PackItem))
+                a.dst_dgrad = None
+                b.dst_fwd = None
+                fw.append(a)
+                bw.append(b)
+            self._pack_items, self._pack_items_bwd = fw, bw
+            items = fw
+            self.pack_table_bwd = hip.device_table(bw)
         self.repacked: Dict[Tuple[str, int], torch.Tensor] = {}
         # gathered dense-block dgrad weights (filled by add_rdb_gather)
         self.gather: Dict[Tuple[str, int], torch.Tensor] = {}
@@ -184,8 +206,11 @@ class ParamStore:
 
     # ---- device ops ----
     def pack(self):
-        hip.check(hip.lib().ssr_pack_weights(self.pack_table.data_ptr(), len(self._pack_items), self.dtype,
+        hip.check(hip.lib().ssr_pack_weights(self.pack_table.data_ptr(), len(self._pack_items), self.fwd_dtype,
                                              hip.stream_ptr()), "ssr_pack_weights")
+        if self._pack_items_bwd is not None:
+            hip.check(hip.lib().ssr_pack_weights(self.pack_table_bwd.data_ptr(), len(self._pack_items_bwd), self.dtype,
+                                                 hip.stream_ptr()), "ssr_pack_weights (backward layouts)")
         if self._seg_items:
             if self.seg_table is None:
                 self.seg_table = hip.device_table(self._seg_items)
@@ -323,7 +348,7 @@ class _ConvBuilder:
         s = self.store.specs[name]
         cout_pad, _, _, _ = self.store.pad[name]
         d = ConvDesc()
-        d.dtype = self.dt
+        d.dtype = self.store.fwd_dtype                          # (mode fp32f: forward convolutions exact, hip.F32F)
         d.x, d.N, d.Hi, d.Wi, d.up = x, self.N, hi, wi, up
         d.Cin = rup(s.cin, 8) if cin is None else cin
         d.w = self.packed_fwd[name].data_ptr()
@@ -344,7 +369,7 @@ class _ConvBuilder:
         d.m, d.m_c0, d.m_c1 = hip.NULL_VIEW, 0, 0
         d.s2d = 1 if self.store.s2d.get(name) else 0
         self.keep.append(d)
-        fix = (self.dt == hip.F32X3 and act == hip.ACT_LRELU and s.stride == 1 and s.k == 3 and alpha == 1.0 and not y0.p
+        fix = (self.store.fwd_dtype == hip.F32X3 and act == hip.ACT_LRELU and s.stride == 1 and s.k == 3 and alpha == 1.0 and not y0.p
                and not r1.p and not r2.p and X3_FIXUP[0])
         if fix:
             # split-bf16 mode: the LeakyReLU decisions of this layer are those of an exact evaluation - outputs whose pre-activation

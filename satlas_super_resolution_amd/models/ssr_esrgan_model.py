@@ -221,7 +221,7 @@ class SSRESRGANModel:
         ts = self.ts
         B, _, h, w = self.lr.shape
         key = (B, h, w)
-        dt = ts.dt if ts is not None else hip.dtype_code(self.compute_dtype)
+        dt = ts.mode if ts is not None else hip.dtype_code(self.compute_dtype)      # the arithmetic MODE (fp32f: this forward is exact fp32)
         if self._infer is None or self._infer[0] != key:
             st = self._infer[1] if self._infer is not None else engine.ParamStore(engine.generator_specs(**self.g_kwargs), dt)
             if self._infer is None and ts is None:

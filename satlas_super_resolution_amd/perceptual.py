@@ -97,10 +97,12 @@ class PerceptualPlan:
             # a tapped layer is stored before its ReLU; the fused ReLU+pool pass needs a pooling behind it
             if n in self.layer_weights and not nxt[4]:
                 raise NotImplementedError(f"perceptual layer {n!r}: taps are supported in front of a pooling layer (and at the last layer)")
+        mode = dtype                          # (hip.F32F: the VGG forward in exact fp32 too - its ReLU decisions shape the image gradient)
+        dtype = hip.storage_code(mode)
         self.dt, self.B, self.H, self.W = dtype, B, H, W
         tdt = hip.torch_dtype(dtype)
         dev = x_buf.device
-        self.store = engine.ParamStore(vgg19_specs(last), dtype, device=dev)
+        self.store = engine.ParamStore(vgg19_specs(last), mode, device=dev)
         sd = state
         self.random_weights = False
         if sd is None:

@@ -78,7 +78,8 @@ class ESRGANTrainStep:
                  vgg_state: Optional[Dict[str, torch.Tensor]] = None):
         assert g_kwargs.get("scale", 4) == 4, "the train step is defined for scale 4 (all shipped configs)"
         self.cfg, self.B, self.h, self.w = cfg, B, h, w
-        self.dt = hip.dtype_code(dtype)
+        self.mode = hip.dtype_code(dtype)          # arithmetic mode of the launch plans (hip.F32F: exact fp32 forward, split-bf16 backward)
+        self.dt = hip.storage_code(self.mode)      # what the C ABI sees for tensors, losses, backward launches
         self.dp = dp if dp is not None else DPContext(None, 0, 1)
         self.use_graph = use_graph
         self.g_kwargs, self.d_kwargs = dict(g_kwargs), dict(d_kwargs)
@@ -87,9 +88,9 @@ class ESRGANTrainStep:
         assert cd == cout + (cin if cfg.feed_disc_lr else 0) + (cout if cfg.old_hr else 0), \
             f"network_d.num_in_ch={cd} must be {cout} (+{cin} with feed_disc_lr, +{cout} with old_hr): ssr_esrgan_model.py:171-178"
         self.cin, self.cout, self.cd = cin, cout, cd
-        self.g_store = g_store or engine.ParamStore(engine.generator_specs(**g_kwargs), self.dt)
+        self.g_store = g_store or engine.ParamStore(engine.generator_specs(**g_kwargs), self.mode)
         self.d_store = d_store or engine.ParamStore(
-            engine.discriminator_specs(cd, d_kwargs.get("num_feat", 64), in_hw=(4 * h, 4 * w), dtype=self.dt), self.dt)
+            engine.discriminator_specs(cd, d_kwargs.get("num_feat", 64), in_hw=(4 * h, 4 * w), dtype=hip.forward_code(self.mode)), self.mode)
         tdt, dev = hip.torch_dtype(self.dt), self.g_store.device
         H, W = 4 * h, 4 * w
         self.H, self.W = H, W
@@ -151,7 +152,7 @@ class ESRGANTrainStep:
             self.p_plan = None
             if cfg.perceptual:      # VGG19 feature L1 (ssr_esrgan_model.py:153-160); its image gradient joins the L1 gradient buffer
                 from .perceptual import PerceptualPlan
-                self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.dt, self.fake_in, self.percep_tgt, self.grad_l1,
+                self.p_plan = PerceptualPlan(cfg.perceptual, B, H, W, self.mode, self.fake_in, self.percep_tgt, self.grad_l1,
                                              self.losses.data_ptr() + 4 * 6 * self.loss_stride, num_ch=cout, state=vgg_state,
                                              loss_flags=self.loss_dt & hip.DETERMINISTIC)
                 self.p_plan.pack()

@@ -247,7 +247,7 @@ def test_regtile_x3_bytes_of_an_image_do_not_depend_on_the_batch(cin, cout, vari
 
 @pytest.mark.parametrize("variant", ["plain", "lrelu", "mask", "generic"])
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 32, 32, 2), (192, 64, 32, 32, 2), (160, 32, 32, 32, 32), (96, 32, 21, 37, 1), (24, 64, 9, 7, 1),
-                                            (320, 64, 16, 16, 1)])
+                                            (320, 64, 16, 16, 1), (40, 8, 16, 16, 2), (16, 8, 16, 16, 2)])
 def test_regtile_exact_fp32_conv(variant, cin, cout, H, W, B):
     """the EXACT fp32 arithmetic mode on the register-tiled kernel (csrc/conv_x3r.hip, template flag EX: fp32 rows in the patch ring,
     v_mfma_f32_32x32x2_f32 - the mode every gate of the reference holds in): the same launch shapes as the split mode, held to the float64

@@ -237,8 +237,12 @@ def _grad_close(got, ref, what, split=False):
     assert float(err.mean()) <= m_max * scale, (what, float(err.mean()) / scale)
 
 
-@pytest.mark.parametrize("mode,c_in,feed_disc_lr", [(m, c, f) for m in ("bf16", "fp32x3") for c, f in ((3, False), (24, False), (24, True), (96, False))]
-                         + [("fp32", 24, False), ("fp32f", 24, False), ("fp32f", 24, True)])
+# (bf16 at C_in 3 / 96 and fp32f with feed_disc_lr run with SSR_RUN_SLOW=1, tools/gpu_round.sh: they repeat the step around a different first
+#  layer, and the suite must fit the driver's time budget)
+@pytest.mark.parametrize("mode,c_in,feed_disc_lr", [("bf16", 24, False), ("bf16", 24, True), pytest.param("bf16", 3, False, marks=pytest.mark.slow),
+                                                    pytest.param("bf16", 96, False, marks=pytest.mark.slow)]
+                         + [("fp32x3", c, f) for c, f in ((3, False), (24, False), (24, True), (96, False))]
+                         + [("fp32", 24, False), ("fp32f", 24, False), pytest.param("fp32f", 24, True, marks=pytest.mark.slow)])
 def test_train_step_full_depth_vs_oracle(mode, c_in, feed_disc_lr):
     """One optimize_parameters() at nf=64/gc=32/nb=23, B=4, against the oracle in the same precision model: the six logged
     scalars, every generator and discriminator parameter gradient, the generator output.  (24, True) feeds the 27-channel
@@ -395,6 +399,9 @@ def _seeded(fx, shape):
     return x, g
 
 
+_TRUTH64 = {}      # fixture name -> (float64 parameters with .grad, float64 input with .grad) of the full-size reference-class tests
+
+
 def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
     """A gradient that passed through hundreds of LeakyReLU kinks, judged on the yardstick of the TRUE (fp64) gradient; the
     reference's own fp32 evaluation sits 1e-6 .. 1e-4 from it (printed beside the device's).
@@ -456,9 +463,13 @@ def test_generator_vs_reference_class_at_full_size(mode, name, c_in, monkeypatch
     st.grad.zero_()
     plan.bwd.run()
     # the true gradients: the oracle (pinned to this very golden at 2e-5 / 1e-4 by tests/test_oracle_golden.py) in float64
-    sd64 = OrderedDict((k, v.double().requires_grad_(True)) for k, v in sd.items())
-    x64 = x.double().requires_grad_(True)
-    (O.generator_forward(sd64, x64, 4) * r.double()).sum().backward()
+    # (~40 s of CPU work, the same for every arithmetic mode: computed once per session)
+    if name not in _TRUTH64:
+        sd64 = OrderedDict((k, v.double().requires_grad_(True)) for k, v in sd.items())
+        x64 = x.double().requires_grad_(True)
+        (O.generator_forward(sd64, x64, 4) * r.double()).sum().backward()
+        _TRUTH64[name] = (sd64, x64)
+    sd64, x64 = _TRUTH64[name]
     _vs_truth(plan.read_input_grad(), fx["dx"], x64.grad, "dx", mode, is_input_grad=True)
     for k, gr in fx["grads"].items():
         _vs_truth(st.tensor(k, st.grad), gr, sd64[k].grad, k, mode)
@@ -535,9 +546,12 @@ def test_discriminator_vs_reference_class_at_full_size(mode, name, monkeypatch):
     plan.backward_plan(xb, param_grads=True, input_grad=True).run()
     st.spectral_norm_backward()
     dx = _nchw(plan.g_in, 0, c_d)
-    sd64 = OrderedDict((k, (v.double().requires_grad_(True) if k in O.D_PARAM_KEYS else v.double())) for k, v in sd.items())
-    x64 = x.double().requires_grad_(True)
-    (O.discriminator_forward(sd64, x64, train=True) * r.double()).sum().backward()
+    if name not in _TRUTH64:       # (float64 truth: once per session, as for the generator)
+        sd64 = OrderedDict((k, (v.double().requires_grad_(True) if k in O.D_PARAM_KEYS else v.double())) for k, v in sd.items())
+        x64 = x.double().requires_grad_(True)
+        (O.discriminator_forward(sd64, x64, train=True) * r.double()).sum().backward()
+        _TRUTH64[name] = (sd64, x64)
+    sd64, x64 = _TRUTH64[name]
     _vs_truth(dx[:, :3], fx["dx_first3"], x64.grad[:, :3], "dx[:3]", mode, is_input_grad=True)
     _vs_truth(dx[:, -3:], fx["dx_last3"], x64.grad[:, -3:], "dx[-3:]", mode, is_input_grad=True)
     for k, gr in fx["grads"].items():

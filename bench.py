@@ -32,7 +32,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL ac
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3, "fp32f": 157.3}   # fp32f: exact fp32 forward (its dominant kernels), split-bf16 backward   # split operands: three bf16 MFMAs per product   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3, "fp32h": 2500.0 / 3, "fp32f": 157.3}   # fp32h: three fp16 MFMAs per forward product (the fp16 dense peak = the bf16 one), three bf16 MFMAs per backward product   # fp32f: exact fp32 forward (its dominant kernels), split-bf16 backward   # split operands: three bf16 MFMAs per product   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
 
 
 def parse():
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="fp32x3", choices=["bf16", "fp32", "fp32x3", "fp32f"],
+    ap.add_argument("--dtype", default="fp32x3", choices=["bf16", "fp32", "fp32x3", "fp32f", "fp32h"],
                     help="arithmetic mode of the headline line.  Default fp32x3: the fastest mode whose outputs pass the reference's "
                          "1e-3 gate (the reference computes in fp32); bf16 (throughput mode, outside the gate) and exact fp32 are "
                          "reported as `legs` of the same run, timed the same way")
@@ -132,7 +132,7 @@ def instrumented_step(ts, args, dtype=None):
                 sym = ("rdbt_kernel<16, %s>" % bw) if lib.ssr_rdb_tile_of(C.byref(d)) == 16 else ("rdb_kernel<%s>" % bw)
                 fl = 2.0 * RDB_MACS * d.N * d.H * d.W
             elif name == "ssr_conv2d_wgrad":
-                wdt = "fp32x3" if dtype == "fp32f" else dtype          # fp32f: the backward is the split-bf16 mode's
+                wdt = "fp32x3" if dtype in ("fp32f", "fp32h") else dtype          # fp32f / fp32h: the backward is the split-bf16 mode's
                 sym = {("fp32x3", 3): "wgrad_x3_k3_kernel", ("bf16", 3): "wgrad_bf16_k3_kernel", ("fp32x3", 4): "wgrad_bf16_kernel<4, 4, 2, true> x3 (split passes)",
                        ("bf16", 4): "wgrad_bf16_kernel<4, 4, 2, false>"}.get((wdt, a[4]), f"wgrad_kernel<{wdt},K{a[4]}>")
                 fl = WGRAD_FLOPS.get(a[0], 0.0)
@@ -292,6 +292,12 @@ GATE = {
                          "given the decisions): every parameter / input gradient inside the gate against the float64 truth, asserted unconditionally "
                          "like the exact mode's (tests/test_gpu_baseline_shapes.py::test_generator_vs_reference_class_at_full_size[fp32f-...], "
                          "::test_discriminator_vs_reference_class_at_full_size[fp32f-...])"},
+    "fp32h": {"outputs_1e-3": True, "gradients_1e-3": True,
+              "held_to": "fp16-split forward (two 11-bit pieces per operand = 22 bits, weights pre-scaled by 2^10: pre-activations as close to the fp32 "
+                         "values as another fp32 summation order, so the LeakyReLU decisions are an fp32 evaluation's), split-bf16 backward: every parameter / "
+                         "input gradient inside the gate against the float64 truth, asserted unconditionally like the exact mode's "
+                         "(tests/test_gpu_baseline_shapes.py::test_generator_vs_reference_class_at_full_size[fp32h-...], "
+                         "::test_discriminator_vs_reference_class_at_full_size[fp32h-...]); activations must stay below fp16's 65504 (beyond: NaN, loudly)"},
     "fp32": {"outputs_1e-3": True, "gradients_1e-3": True,
              "held_to": "outputs 2e-6; every parameter / input gradient inside the gate against the float64 truth (<= 0.1 % of the elements of a "
                         "tensor outside, asserted), same tests"},
@@ -344,10 +350,10 @@ def unsplit_twin(ts, build):
 
 def peak_for(sym, dtype):
     """dense MFMA peak the kernel `sym` is priced against: by the arithmetic the KERNEL runs (mode fp32f mixes exact fp32 forward kernels
-    - conv_x3r_kernel<.., true>, conv_kernel<fp32,..> - with split-bf16 backward kernels)"""
+    - conv_x3r_kernel<.., 1>, conv_kernel<fp32,..> - with split-bf16 backward kernels)"""
     if dtype != "fp32f":
         return PEAK_TFLOPS[dtype]
-    exact = sym.endswith(", true>") or "<fp32," in sym or sym.startswith("conv_thin_f32_kernel")
+    exact = (sym.startswith("conv_x3r_kernel") and sym.endswith(", 1>")) or "<fp32," in sym or sym.startswith("conv_thin_f32_kernel")
     return PEAK_TFLOPS["fp32"] if exact else PEAK_TFLOPS["fp32x3"]
 
 
@@ -388,6 +394,8 @@ ARITH = {"bf16": "bf16 tensors in HBM; v_mfma_f32_32x32x16_bf16, fp32 accumulate
          "fp32x3": "fp32 tensors in HBM; bf16 MFMA on split operands (hi+lo, 3 MFMAs per product), fp32 accumulate",
          "fp32f": "fp32 tensors in HBM; forward convolutions v_mfma_f32_32x32x2_f32 (exact fp32), backward convolutions and weight gradients "
                   "bf16 MFMA on split operands (3 MFMAs per product)",
+         "fp32h": "fp32 tensors in HBM; forward convolutions fp16 MFMA on split operands (hi+lo fp16 pieces = 22 bits, 3 x v_mfma_f32_32x32x16_f16 per "
+                  "product, weights x 2^10), backward convolutions and weight gradients bf16 MFMA on split operands (3 MFMAs per product), fp32 accumulate",
          "fp32": "fp32 tensors in HBM; v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the bf16 matrix rate)"}
 
 
@@ -647,7 +655,7 @@ def main():
         # the other arithmetic modes of the same step, same configuration, same run, timed like the headline: each with its own
         # roofline and the part of the 1e-3 gate it meets.  `parity_mode` (readers of earlier rounds' lines) names the fp32x3 record.
         legs = {}
-        for leg_dtype in ("fp32x3", "bf16", "fp32f", "fp32"):
+        for leg_dtype in ("fp32h", "fp32x3", "bf16", "fp32f", "fp32"):
             if leg_dtype == args.dtype:
                 continue
             legs[leg_dtype] = precision_leg(args, leg_dtype, g_kw, d_kw, c_in, c_d, B, lr, gt, args.leg_steps or args.steps)

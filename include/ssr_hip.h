@@ -32,6 +32,19 @@ extern "C" {
  * arithmetic mode that meets the 1e-3 parity gate at matrix-core speed.  Storage, packing and every non-MFMA entry point
  * treat it exactly as SSR_F32. */
 #define SSR_F32X3 2
+/* FORWARD convolutions only (ssr_conv2d, ssr_conv2d_batch; the forward table of ssr_pack_weights), round 6: fp32 tensors in HBM,
+ * fp16 matrix cores on split operands - an activation is staged as hi = f16(x), lo = f16(x - hi); the packed weights hold
+ * hi = f16(2^SSR_F32H_WSHIFT w), lo = f16(2^SSR_F32H_WSHIFT w - hi) in the SSR_F32X3 row layout ([16 hi | 16 lo], 64 bytes); a product
+ * is a_lo w_hi + a_hi w_lo + a_hi w_hi (three v_mfma_f32_32x32x16_f16, fp32 accumulation) and the accumulators are multiplied by
+ * 2^-SSR_F32H_WSHIFT before the epilogue.  Two 11-bit pieces carry 22 bits of an operand (bf16 pieces: 16), so a pre-activation is
+ * as close to the fp32 value as another fp32 summation order is, and its LeakyReLU decision is an fp32 evaluation's - at the split-bf16
+ * mode's speed.  The weight shift keeps the lo pieces of ordinary convolution weights (|w| down to 2^-17 x 2^-SHIFT) in fp16's
+ * normal range; activations are staged unscaled: an element below 2^-3 keeps an ABSOLUTE error of 2^-25 (its lo piece is an fp16
+ * subnormal, which gfx950's matrix cores and converters keep), and |x| must stay below 65504 (beyond: inf -> NaN outputs, loudly).
+ * Gradients (1e-7 .. 1e-4 in this model) do not fit fp16's range without a per-tensor scale: backward convolutions and weight
+ * gradients of the mode that uses this code (hip.F32H in the Python layer) stay SSR_F32X3. */
+#define SSR_F32H 3
+#define SSR_F32H_WSHIFT 10
 
 #define SSR_OK 0
 #define SSR_EINVAL (-1)   /* bad descriptor (unsupported geometry / alignment) */

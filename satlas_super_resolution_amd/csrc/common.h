@@ -18,6 +18,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- split-operand matrix math (SSR_F32X3: bf16 pieces; SSR_F32H: fp16 pieces, include/ssr_hip.h) ----
+// The kernels keep the pieces in bf16x8 / uint2 containers whatever the encoding; H selects the conversion and the MFMA.
+template <bool H> __device__ __forceinline__ f32x16 split_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// four fp32 values -> four hi pieces, four lo pieces (x = hi + lo + O(2^-17 x) in bf16, O(2^-22 x) in fp16 above its subnormal range)
+template <bool H> __device__ __forceinline__ void split_f32x4(const u32x4& v, uint2& hi, uint2& lo) {
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    if constexpr (H) {
+        f16x4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (_Float16)f[k];
+            l[k] = (_Float16)(f[k] - (float)h[k]);
+        }
+        hi = __builtin_bit_cast(uint2, h);
+        lo = __builtin_bit_cast(uint2, l);
+    } else {
+        bf16x4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (__bf16)f[k];
+            l[k] = (__bf16)(f[k] - (float)h[k]);
+        }
+        hi = __builtin_bit_cast(uint2, h);
+        lo = __builtin_bit_cast(uint2, l);
+    }
+}
+constexpr float SSR_F32H_WSCALE = (float)(1 << SSR_F32H_WSHIFT), SSR_F32H_UNSCALE = 1.0f / (float)(1 << SSR_F32H_WSHIFT);
 
 #define LRELU_SLOPE 0.2f
 

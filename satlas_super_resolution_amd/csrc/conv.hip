@@ -333,7 +333,9 @@ __device__ __forceinline__ void split4(const u32x4& v, uint2& hi, uint2& lo) {
     lo = __builtin_bit_cast(uint2, l);
 }
 
-template <int KH, int KW, int NT, int MW, int KS>
+// H: the fp16-split forward arithmetic (SSR_F32H, include/ssr_hip.h) on the same data path - fp16 pieces, v_mfma_f32_32x32x16_f16,
+// accumulators x 2^-SSR_F32H_WSHIFT before the epilogue
+template <int KH, int KW, int NT, int MW, int KS, bool H = false>
 __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
     constexpr int VEC = 4, CK = 16, VPR = 4, ROWB = 80, BN = 32 * NT, S = 1;
     constexpr int TH = 2 * MW, TW = 16;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
 #pragma unroll
         for (int q = 0; q < NPV; ++q)
             if (plo[q] >= 0) {
-                split4(rp[q], hi, lo);
+                split_f32x4<H>(rp[q], hi, lo);
                 *reinterpret_cast<uint2*>(base + plo[q]) = hi;
                 *reinterpret_cast<uint2*>(base + plo[q] + 32) = lo;
             }
@@ -447,9 +449,9 @@ __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
             for (int t = 0; t < NT; ++t) {
                 const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(bb + (tap * BN + t * 32) * ROWB);
                 const bf16x8 blo = *reinterpret_cast<const bf16x8*>(bb + (tap * BN + t * 32) * ROWB + 32);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[t], 0, 0, 0);
+                acc[t] = split_mfma<H>(alo, bhi, acc[t]);
+                acc[t] = split_mfma<H>(ahi, blo, acc[t]);
+                acc[t] = split_mfma<H>(ahi, bhi, acc[t]);
             }
         }
         if (has_next) store_chunk((c + 1) & 1);
@@ -458,7 +460,14 @@ __device__ __forceinline__ void conv_body_x3(const ssr_conv_desc& d) {
 
     char* slab = smem + (size_t)MW * 16 * 64 * sizeof(float) + (size_t)wave * EPI_STAGE_BYTES;
     auto epilogue = [&](const f32x16& a, int t) {
-        conv_epilogue<float>(d, a, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+        if constexpr (H) {
+            f32x16 b;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b[r] = a[r] * SSR_F32H_UNSCALE;
+            conv_epilogue<float>(d, b, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+        } else {
+            conv_epilogue<float>(d, a, co0 + t * 32, n, gy0 + 2 * wm, gx0, lane, slab);
+        }
     };
     if (KS == 1) {
 #pragma unroll
@@ -509,15 +518,19 @@ template <int KH, int KW, int NT, int MW, int KS>
 __global__ __launch_bounds__(64 * MW * KS) void conv_x3_kernel(const ssr_conv_desc d) {
     conv_body_x3<KH, KW, NT, MW, KS>(d);
 }
-
 template <int KH, int KW, int NT, int MW, int KS>
+__global__ __launch_bounds__(64 * MW * KS) void conv_h3_kernel(const ssr_conv_desc d) {      // the fp16-split form (SSR_F32H)
+    conv_body_x3<KH, KW, NT, MW, KS, true>(d);
+}
+
+template <int KH, int KW, int NT, int MW, int KS, bool H = false>
 int launch_conv_x3(const ssr_conv_desc& d, hipStream_t st) {
     constexpr int BN = 32 * NT, TH = 2 * MW, TW = 16, PH = TH - 1 + KH, PW = TW - 1 + KW;
     constexpr size_t stage = (size_t)(PH * PW + KH * KW * BN) * 80;
     constexpr size_t red = (size_t)MW * 16 * 64 * sizeof(float) + (size_t)MW * KS * EPI_STAGE_BYTES;
     constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_x3_kernel<KH, KW, NT, MW, KS>;
+    auto kern = H ? conv_h3_kernel<KH, KW, NT, MW, KS> : conv_x3_kernel<KH, KW, NT, MW, KS>;
     static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
     const int attr_dev = ssr_device_ordinal();
     if (!attr_done[attr_dev]) {
@@ -834,7 +847,7 @@ bool x3p_ok(const ssr_conv_desc& d, int cps) {
     return true;
 }
 
-template <int KH, int KW>
+template <int KH, int KW, bool H = false>
 int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
     bool nt2, small;
     pick_tile(d, nt2, small);
@@ -844,13 +857,13 @@ int dispatch_tile_x3(const ssr_conv_desc& d, hipStream_t st) {
     // 38.1 ms without small tiles, 60.0 ms with small tiles everywhere.  SSR_X3_SMALL = threshold in 8x16 tiles (tuning hook).
     static const long thr = [] { const char* e = getenv("SSR_X3_SMALL"); return e ? atol(e) : 0L; }();
     small = (long)((d.Gw + 15) / 16) * ((d.Gh + 7) / 8) * d.N * (d.CoutPad / (nt2 ? 64 : 32)) < thr;
-    if (!small) {      // round 5: deep load pipeline (two chunks per stage at 32 output channels, three register stages at 64)
+    if (!small && !H) {      // round 5: deep load pipeline (two chunks per stage at 32 output channels, three register stages at 64)
         static const bool p2 = [] { const char* e = getenv("SSR_X3_PIPE2"); return e && e[0] == '1'; }();   // 64 output channels: measured slower than the plain pipeline (r05b: 10.4 vs 9.6 ms per step), opt-in
         if (nt2 && p2 && x3p_ok(d, 1)) return launch_conv_x3p<KH, KW, 2, 4, 2, 1, 3>(d, st);
         if (!nt2 && x3p_ok(d, 2)) return launch_conv_x3p<KH, KW, 1, 4, 2, 2, 2>(d, st);
     }
-    if (nt2) return small ? launch_conv_x3<KH, KW, 2, 2, 2>(d, st) : launch_conv_x3<KH, KW, 2, 4, 2>(d, st);
-    return small ? launch_conv_x3<KH, KW, 1, 2, 2>(d, st) : launch_conv_x3<KH, KW, 1, 4, 2>(d, st);
+    if (nt2) return small ? launch_conv_x3<KH, KW, 2, 2, 2, H>(d, st) : launch_conv_x3<KH, KW, 2, 4, 2, H>(d, st);
+    return small ? launch_conv_x3<KH, KW, 1, 2, 2, H>(d, st) : launch_conv_x3<KH, KW, 1, 4, 2, H>(d, st);
 }
 
 bool view_ok(const ssr_view& v, bool required) {
@@ -886,7 +899,7 @@ bool ssr_conv_x3r_qualifies(const ssr_conv_desc& d);
 
 extern "C" int ssr_conv2d_s2d_ok(int32_t dtype, int32_t Cin, int32_t Cout, int32_t CoutPad) {
     static const bool off = [] { const char* e = getenv("SSR_CONV_S2D"); return e && e[0] == '0'; }();
-    if (dtype == SSR_F32X3) {   // split-bf16 mode: 16-channel chunks (conv_big_x3.hip)
+    if (dtype == SSR_F32X3 || dtype == SSR_F32H) {   // split modes: 16-channel chunks (conv_big_x3.hip)
         static const bool offx = [] { const char* e = getenv("SSR_X3_BIGTILE"); return e && e[0] == '0'; }();
         const int cpx = Cin / 16;
         return !off && !offx && Cin >= 16 && (Cin % 16) == 0 && (cpx & (cpx - 1)) == 0 && (CoutPad % 64) == 0 && (Cout % 8) == 0;
@@ -899,15 +912,16 @@ extern "C" int ssr_conv2d_variant(const ssr_conv_desc* dp) {
     if (!dp) return SSR_EINVAL;
     if (dp->s2d) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;
     // ReLU epilogues (the VGG19 layers) exist only in the pipelined kernel outside the split-bf16 mode: conv2d_impl forces it (impl = 3)
-    const bool pipelined_only = dp->dtype != SSR_F32X3 && (dp->act == SSR_ACT_RELU || dp->m_relu);
+    const bool split = dp->dtype == SSR_F32X3 || dp->dtype == SSR_F32H;
+    const bool pipelined_only = !split && (dp->act == SSR_ACT_RELU || dp->m_relu);
     if (!pipelined_only) {
         if (dp->dtype != SSR_BF16 && ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;        // digit 7 = thin-output VALU kernel
-        if (dp->dtype == SSR_F32X3 && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
-        if (dp->dtype == SSR_F32X3 && ssr_conv_x3r_qualifies(*dp))
+        if (split && ssr_conv_bigx3_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
+        if (split && ssr_conv_x3r_qualifies(*dp))
             return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 5;                              // digit 5 = register-tiled, K split over four waves (conv_x3r.hip)
         if (dp->dtype == SSR_F32X3 && ssr_conv_x3q_qualifies(*dp))
             return dp->KH * 1000 + dp->stride * 100 + ((dp->CoutPad % 64) == 0 ? 2 : 1) * 10 + 6;                              // digit 6 = twelve-wave ring (conv_x3q.hip)
-        if (dp->dtype != SSR_F32X3) {
+        if (!split) {
             if (ssr_conv_thin_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 7;  // digit 7 = thin-output VALU kernel
             if (ssr_conv_ws_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 1 * 10 + 8;    // digit 8 = weight-stationary
             if (ssr_conv_big_qualifies(*dp)) return dp->KH * 1000 + dp->stride * 100 + 2 * 10 + 9;   // digit 9 = big tile
@@ -939,12 +953,13 @@ extern "C" int ssr_conv2d_symbol(const ssr_conv_desc* dp, char* buf, int32_t buf
     if (d.dtype != SSR_BF16 && w == 5) {
         int ntw = 1, nu = 1, ep = 3;
         ssr_conv_x3r_instance(d, &ntw, &nu, &ep);
-        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d, %d, %s>", ntw, nu, ep, ssr_conv_x3r_tile_height(d), d.dtype == SSR_F32 ? "true" : "false");
+        snprintf(buf, buflen, "conv_x3r_kernel<%d, %d, %d, %d, %d>", ntw, nu, ep, ssr_conv_x3r_tile_height(d), d.dtype == SSR_F32 ? 1 : d.dtype == SSR_F32H ? 2 : 0);
     } else if (d.dtype == SSR_F32X3 && w == 6) snprintf(buf, buflen, "conv_x3q_kernel<%d>", nt);
     else if (d.dtype == SSR_F32X3 && w == 9) snprintf(buf, buflen, "conv_bigx3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
-    else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %s>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? "true" : "false");
-    else snprintf(buf, buflen, "%s<%s,K%d,S%d,NT%d,W%d>", w == 7 ? "conv_thin_kernel" : w == 8 ? "conv_ws_kernel" : w == 9 ? "conv_big_kernel" : w == 1 ? "conv_res_kernel" : d.dtype == SSR_F32X3 ? "conv_x3_kernel" : "conv_kernel",
-                  d.dtype == SSR_BF16 ? "bf16" : d.dtype == SSR_F32 ? "fp32" : "fp32x3", v / 1000, (v / 100) % 10, nt, w);
+    else if (d.dtype == SSR_F32H && w == 9) snprintf(buf, buflen, "conv_bigh3_kernel4<%d>", (d.s2d || d.KH == 2) ? 2 : 3);
+    else if (f32m && w == 7) snprintf(buf, buflen, "conv_thin_f32_kernel<%d, %d>", d.Cout == 1 ? 1 : d.Cout <= 3 ? 3 : d.Cout == 4 ? 4 : 8, d.dtype == SSR_F32X3 ? 1 : d.dtype == SSR_F32H ? 2 : 0);
+    else snprintf(buf, buflen, "%s<%s,K%d,S%d,NT%d,W%d>", w == 7 ? "conv_thin_kernel" : w == 8 ? "conv_ws_kernel" : w == 9 ? "conv_big_kernel" : w == 1 ? "conv_res_kernel" : d.dtype == SSR_F32X3 ? "conv_x3_kernel" : d.dtype == SSR_F32H ? "conv_h3_kernel" : "conv_kernel",
+                  d.dtype == SSR_BF16 ? "bf16" : d.dtype == SSR_F32 ? "fp32" : d.dtype == SSR_F32H ? "fp32h" : "fp32x3", v / 1000, (v / 100) % 10, nt, w);
     return SSR_OK;
 }
 
@@ -972,8 +987,22 @@ static int conv2d_impl(const ssr_conv_desc* dp, void* stream, int impl) {
             return SSR_EINVAL;
         ssr_conv_desc e = d;
         e.KH = e.KW = 2; e.stride = 1; e.pad_y = e.pad_x = 0; e.Cin = 4 * d.Cin;
-        if (d.dtype == SSR_F32X3) return ssr_conv_bigx3_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (d.dtype == SSR_F32X3 || d.dtype == SSR_F32H) return ssr_conv_bigx3_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
         return ssr_conv_big_try(e, st, &rc, true) ? rc : SSR_EUNSUP;
+    }
+    if (d.dtype == SSR_F32H) {    // fp16-split FORWARD arithmetic (include/ssr_hip.h): the split-bf16 mode's kernels with the H flag
+        if (d.fix_list) return SSR_EUNSUP;
+        if (impl == 4) return ssr_conv_bigx3_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 5) return ssr_conv_thin_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 7) return ssr_conv_x3r_try(d, st, &rc, true) ? rc : SSR_EUNSUP;
+        if (impl == 0 && ssr_conv_thin_try(d, st, &rc, false)) return rc;
+        if (impl == 0 && ssr_conv_bigx3_try(d, st, &rc, false)) return rc;
+        if (impl == 0 && ssr_conv_x3r_try(d, st, &rc, false)) return rc;
+        if (d.KH == 3 && d.KW == 3 && d.stride == 1) return dispatch_tile_x3<3, 3, true>(d, st);
+        if (d.KH == 2 && d.KW == 2 && d.stride == 1) return dispatch_tile_x3<2, 2, true>(d, st);
+        ssr_conv_desc e = d;      // 4x4 stride 2 without the space-to-depth view: rows of 8 are plain fp32 (misc.hip put_packed), the exact kernel
+        e.dtype = SSR_F32;
+        return dispatch_geom<float>(e, st);
     }
     if (d.dtype == SSR_F32X3) {   // fp32 storage, split-bf16 matrix math (stride-1 2x2 / 3x3); 4x4 stride 2 without s2d: the exact fp32 kernel
         if (impl == 4) return ssr_conv_bigx3_try(d, st, &rc, true) ? rc : SSR_EUNSUP;

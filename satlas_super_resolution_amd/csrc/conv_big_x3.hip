@@ -83,7 +83,9 @@ __device__ __forceinline__ void xb_split4(const u32x4& v, uint2& hi, uint2& lo) 
     lo = __builtin_bit_cast(uint2, l);
 }
 
-template <int KT>
+// H: the fp16-split FORWARD arithmetic (SSR_F32H, include/ssr_hip.h) on the same data path: fp16 pieces, v_mfma_f32_32x32x16_f16; the
+// accumulators start at 2^SSR_F32H_WSHIFT x bias and leave through the epilogue multiplied by 2^-SSR_F32H_WSHIFT (both exact)
+template <int KT, bool H = false>
 __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
     using T = XbT<KT>;
     constexpr int AROW = T::AROW, VPP = T::VPP, PW = T::PW, NPIX = T::NPIX, PATCH = T::PATCH, NPV = T::NPV, NWV = T::NWV, NSTEP = T::NSTEP;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
     const unsigned long long xb_start = xb_t0;
     (void)xb_t; (void)xb_start;
     float* bias_lds = reinterpret_cast<float*>(smem + T::BIAS);
-    if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] : 0.f;
+    if (tid < 64) bias_lds[tid] = (d.bias && co0 + tid < d.Cout) ? d.bias[co0 + tid] * (H ? SSR_F32H_WSCALE : 1.f) : 0.f;
 
     // ---- staging descriptors (independent of the chunk) ----
     // space-to-depth view (ssr_conv_desc.s2d, the 4x4 stride-2 forward layers as 2x2 layers over 4 x C channels): chunk c is parity
@@ -187,7 +189,7 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
         static_for<0, NPV>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             uint2 hi, lo;
-            xb_split4(rp[j], hi, lo);
+            split_f32x4<H>(rp[j], hi, lo);
             if (j + 1 < NPV || tid < PTAIL) {
                 *reinterpret_cast<uint2*>(smem + plo0 + j * 64 * AROW) = hi;
                 *reinterpret_cast<uint2*>(smem + plo0 + j * 64 * AROW + 32) = lo;
@@ -292,7 +294,8 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
 #pragma unroll
                 for (int h4 = 0; h4 < 4; ++h4) {
                     const int h = 4 * hh + h4;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (4 * h + hp) * XB_SLAB_PITCH + (lane & 15) * 16);
+                    f32x4 a = *reinterpret_cast<const f32x4*>(slab + (4 * h + hp) * XB_SLAB_PITCH + (lane & 15) * 16);
+                    if constexpr (H) a *= SSR_F32H_UNSCALE;
                     const bool ok = po[h] >= 0;
                     const int pp = po[h] & 0x7fffffff;
                     f32x4 v, s0, s1;
@@ -361,7 +364,7 @@ __device__ __forceinline__ void conv_bigx3_body(const ssr_conv_desc& d) {
             static_for<0, 24>([&](auto kc) {
                 constexpr int k = decltype(kc)::value, m = k / 6, t = (k % 6) / 3, p = k % 3;
                 // w_lo p_hi, w_hi p_lo, w_hi p_hi (the order of conv_x3_kernel: small terms first)
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s_ & 1][t][p == 0 ? 1 : 0], pq[s_ & 1][m][p == 1 ? 1 : 0], acc[m][t], 0, 0, 0);
+                acc[m][t] = split_mfma<H>(wq[s_ & 1][t][p == 0 ? 1 : 0], pq[s_ & 1][m][p == 1 ? 1 : 0], acc[m][t]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (k < 12) {
                     if constexpr (s_ + 1 < NSTEP) issue1(std::integral_constant<int, s_ + 1>{}, kc);
@@ -422,8 +425,12 @@ template <int KT>
 __global__ __launch_bounds__(256, 1) void conv_bigx3_kernel4(const ssr_conv_desc4x p) {
     conv_bigx3_body<KT>(p.d[blockIdx.z]);
 }
-
 template <int KT>
+__global__ __launch_bounds__(256, 1) void conv_bigh3_kernel4(const ssr_conv_desc4x p) {      // the fp16-split form (SSR_F32H)
+    conv_bigx3_body<KT, true>(p.d[blockIdx.z]);
+}
+
+template <int KT, bool H = false>
 int launch_bigx3(const ssr_conv_desc* ds, int n, hipStream_t st) {
     constexpr int lds = XbT<KT>::LDS;
     const ssr_conv_desc& d = ds[0];
@@ -445,7 +452,7 @@ int launch_bigx3(const ssr_conv_desc* ds, int n, hipStream_t st) {
         if (g >= 1) G = g < d.N ? g : d.N;
     }
     const int tiles = tpi * G;
-    auto kern = conv_bigx3_kernel4<KT>;
+    auto kern = H ? conv_bigh3_kernel4<KT> : conv_bigx3_kernel4<KT>;
     static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
     const int attr_dev = ssr_device_ordinal();
     if (!attr_done[attr_dev]) {
@@ -464,7 +471,7 @@ int launch_bigx3(const ssr_conv_desc* ds, int n, hipStream_t st) {
 
 // everything except the grid-size heuristic
 bool ssr_conv_bigx3_shape_ok(const ssr_conv_desc& d) {
-    if (d.dtype != SSR_F32X3 || d.fix_list) return false;
+    if ((d.dtype != SSR_F32X3 && d.dtype != SSR_F32H) || d.fix_list) return false;
     const bool k3 = d.KH == 3 && d.KW == 3 && d.pad_y == 1 && d.pad_x == 1;
     const bool k2 = d.KH == 2 && d.KW == 2 && (d.pad_y == 0 || d.pad_y == 1) && (d.pad_x == 0 || d.pad_x == 1);
     if (!(k3 || k2) || d.stride != 1 || d.x2.p) return false;
@@ -501,7 +508,8 @@ bool ssr_conv_bigx3_qualifies(const ssr_conv_desc& d) {
 
 bool ssr_conv_bigx3_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_bigx3_shape_ok(d) : !ssr_conv_bigx3_qualifies(d)) return false;
-    *rc = d.KH == 3 ? launch_bigx3<3>(&d, 1, st) : launch_bigx3<2>(&d, 1, st);
+    if (d.dtype == SSR_F32H) *rc = d.KH == 3 ? launch_bigx3<3, true>(&d, 1, st) : launch_bigx3<2, true>(&d, 1, st);
+    else *rc = d.KH == 3 ? launch_bigx3<3>(&d, 1, st) : launch_bigx3<2>(&d, 1, st);
     return true;
 }
 
@@ -511,7 +519,7 @@ bool ssr_conv_bigx3_batch_try(const ssr_conv_desc* ds, int n, hipStream_t st, in
     const bool off = e && e[0] == '0', always = e && e[0] == '2';
     if (off || n < 1 || n > 4) return false;
     for (int k = 0; k < n; ++k)
-        if (!ssr_conv_bigx3_shape_ok(ds[k]) || ds[k].KH != 2 || ds[k].s2d) return false;
+        if (!ssr_conv_bigx3_shape_ok(ds[k]) || ds[k].dtype != SSR_F32X3 || ds[k].KH != 2 || ds[k].s2d) return false;
     const ssr_conv_desc& d = ds[0];
     for (int k = 1; k < n; ++k)
         if (ds[k].N != d.N || ds[k].Gh != d.Gh || ds[k].Gw != d.Gw || ds[k].CoutPad != d.CoutPad || ds[k].Cin != d.Cin || ds[k].Hi != d.Hi || ds[k].Wi != d.Wi ||

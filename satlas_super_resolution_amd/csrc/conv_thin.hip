@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ssr_conv_desc d) {
 constexpr int CTF_CB = 32, CTF_ROWB = CTF_CB * 4 + 16;        // channels staged per pass, bytes per LDS row
 constexpr int CTF_PATCH = CT_NPIX * CTF_ROWB;                 // 48,960 B
 
-template <int NCO, bool X3>
+// X3: 0 = plain fp32 rows (SSR_F32), 1 = [16 hi | 16 lo] bf16 rows (SSR_F32X3), 2 = fp16 rows of 2^SSR_F32H_WSHIFT w (SSR_F32H)
+template <int NCO, int X3>
 __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc d) {
     constexpr int NCOP = NCO == 1 ? 1 : NCO <= 4 ? 4 : 8;     // weight-table columns (a 16-byte vector holds 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc 
         float w = 0.f;
         if (c < NCO) {
             const char* row = wg + ((size_t)((ci >> 4) * 9 + tap) * d.CoutPad + c) * 64;
-            if (X3) {
+            if (X3 == 2) {
+                const _Float16 h = reinterpret_cast<const _Float16*>(row)[ci & 15], l = reinterpret_cast<const _Float16*>(row)[16 + (ci & 15)];
+                w = ((float)h + (float)l) * SSR_F32H_UNSCALE;
+            } else if (X3 == 1) {
                 const unsigned short h = reinterpret_cast<const unsigned short*>(row)[ci & 15], l = reinterpret_cast<const unsigned short*>(row)[16 + (ci & 15)];
                 w = __builtin_bit_cast(float, (unsigned)h << 16) + __builtin_bit_cast(float, (unsigned)l << 16);
             } else {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_thin_f32_kernel(const ssr_conv_desc 
     }
 }
 
-template <int NCO, bool X3>
+template <int NCO, int X3>
 int launch_thin_f32(const ssr_conv_desc& d, hipStream_t st) {
     constexpr int NCOP = NCO == 1 ? 1 : NCO <= 4 ? 4 : 8;
     const size_t lds = (size_t)CTF_PATCH + (size_t)9 * ((d.Cin + 15) & ~15) * NCOP * 4;     // <= 67,392 B
@@ -275,7 +279,7 @@ int launch_thin_f32(const ssr_conv_desc& d, hipStream_t st) {
     SSR_LAUNCH_CHECK();
     return SSR_OK;
 }
-template <bool X3>
+template <int X3>
 int launch_thin_f32_by_cout(const ssr_conv_desc& d, hipStream_t st) {
     if (d.Cout == 1) return launch_thin_f32<1, X3>(d, st);
     if (d.Cout <= 3) return launch_thin_f32<3, X3>(d, st);
@@ -304,7 +308,7 @@ int launch_thin(const ssr_conv_desc& d, hipStream_t st) {
 }  // namespace
 
 bool ssr_conv_thin_shape_ok(const ssr_conv_desc& d) {
-    const bool f32 = d.dtype == SSR_F32 || d.dtype == SSR_F32X3;
+    const bool f32 = d.dtype == SSR_F32 || d.dtype == SSR_F32X3 || d.dtype == SSR_F32H;
     if (d.dtype != SSR_BF16 && !f32) return false;
     if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1) || d.x2.p || d.up != 1 || d.fix_list) return false;
     if (d.Cin > 64 || (d.Cin % 8) != 0 || d.Cout > 8 || d.Cout < 1) return false;
@@ -330,8 +334,9 @@ bool ssr_conv_thin_qualifies(const ssr_conv_desc& d) {
 
 bool ssr_conv_thin_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool force) {
     if (force ? !ssr_conv_thin_shape_ok(d) : !ssr_conv_thin_qualifies(d)) return false;
-    if (d.dtype == SSR_F32X3) { *rc = launch_thin_f32_by_cout<true>(d, st); return true; }
-    if (d.dtype == SSR_F32) { *rc = launch_thin_f32_by_cout<false>(d, st); return true; }
+    if (d.dtype == SSR_F32H) { *rc = launch_thin_f32_by_cout<2>(d, st); return true; }
+    if (d.dtype == SSR_F32X3) { *rc = launch_thin_f32_by_cout<1>(d, st); return true; }
+    if (d.dtype == SSR_F32) { *rc = launch_thin_f32_by_cout<0>(d, st); return true; }
     if (d.Cout == 1) *rc = launch_thin<1>(d, st);
     else if (d.Cout <= 4) *rc = launch_thin<4>(d, st);
     else *rc = launch_thin<8>(d, st);

@@ -44,8 +44,11 @@ namespace {
 // and a (tile, tap, chunk) step is eight v_mfma_f32_32x32x2_f32 (lane (i, g) multiplies channels 4 g + s and 8 + 4 g + s, s = 0 .. 3)
 // instead of three bf16 MFMAs.  At 64 cycles per MFMA the step is 5.3 x longer than the split step while every byte moves as before:
 // the mode that every gate of the reference holds in (outputs AND gradients) runs MFMA-bound here.
-template <int NTW, int NU, int EP, int TH = 8, bool EX = false>
+// AM: the arithmetic - 0 split-bf16 (SSR_F32X3), 1 = EX above (SSR_F32), 2 = the fp16-split FORWARD arithmetic (SSR_F32H, include/ssr_hip.h):
+// the split-bf16 path with fp16 pieces, v_mfma_f32_32x32x16_f16 and the K-quarter sum multiplied by 2^-SSR_F32H_WSHIFT.
+template <int NTW, int NU, int EP, int TH = 8, int AM = 0>
 __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(const ssr_conv_desc d) {
+    constexpr bool EX = AM == 1, H = AM == 2;
     using T = XrT<NTW, NU, TH>;
     constexpr int NT = NTW, NTT = T::NTT, NMF = T::NMF, BN = T::BN, WR = T::WR, MT = T::MT;
     constexpr int G_NPIX = T::NPIX, G_SUB = T::SUB, G_PV = T::PV, G_NPV = T::NPV;
@@ -80,6 +83,9 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
         // =============================== producer waves: the patch ===============================
         const int pw = wave - NMF;
         const int pt = tid - 64 * NMF;                         // 0..255
+#ifdef XR_PRIO        // (probe switch: the producers win the issue arbitration against the MFMA wave of their SIMD; 1 = until the first chunk is stored)
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const int part = pt & 3, p4 = pt >> 2;
         // vector q of a thread = slot pt + 256 q: patch pixel p4 + 64 q, 16-byte part pt & 3
         int ppix[G_NPV];                                      // global pixel index of the patch vectors (-1: zeros)
@@ -140,12 +146,16 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                     char* base = smem + (c % XR_NS) * G_SUB;
 #pragma unroll
                     for (int q = 0; q < G_NPV; ++q) {
+#ifdef XR_X_NOSTORE   // (tools/x3r_probe.hip switch, LDS bank-conflict attribution: the producers publish without storing)
+                        asm volatile("" :: "v"(rq[j][q]));
+                        continue;
+#endif
                         if constexpr (EX) {                                 // exact mode: the four fp32 channels as they are
                             if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256)
                                 *reinterpret_cast<u32x4*>(base + p4 * XR_ROWB + part * 16 + q * 64 * XR_ROWB) = rq[j][q];
                         } else {
                             uint2 hi, lo;
-                            xr_split4(rq[j][q], hi, lo);
+                            split_f32x4<H>(rq[j][q], hi, lo);
                             if (q < G_NPV - 1 || pt < G_PV - (G_NPV - 1) * 256) {
                                 *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB) = hi;
                                 *reinterpret_cast<uint2*>(base + plo0 + q * 64 * XR_ROWB + 32) = lo;
@@ -156,6 +166,9 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                     asm volatile("" ::: "memory");
                     if (lane == 0) *(xr_lds_int)(uintptr_t)(ctl_addr + 4 * pw) = c + 1;
                     asm volatile("" ::: "memory");
+#if defined(XR_PRIO) && XR_PRIO == 1
+                    if (c == 0) __builtin_amdgcn_s_setprio(0);
+#endif
                 }
                 // refill unconditionally (past the end: out-of-range offsets) so that the number of loads in flight is the same on every
                 // path and the compiler's vmcnt bookkeeping keeps the queue PQ chunks deep
@@ -215,7 +228,13 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             // weights of the first WR steps (they depend on nobody), then the first chunk
-            static_for<0, WR>([&](auto sc) {
+            // (XR_WPRE: only the first WPRE steps before the wait for the first chunk, the others behind it - the producers' first patch
+            //  loads then queue behind WPRE x 2 KB of weight requests per MFMA wave instead of WR x 2 KB; tools/x3r_probe)
+#ifndef XR_WPRE
+#define XR_WPRE 99
+#endif
+            constexpr int WPRE = XR_WPRE < WR ? XR_WPRE : WR;
+            static_for<0, WPRE>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(w + 4 * (s / 3), std::integral_constant<int, s % 3>{}, sc);
@@ -225,6 +244,12 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
             int g = w, c_cur = g / 3;
             int base_cur = base_of(g);
             ensure(c_cur);
+            static_for<WPRE, WR>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(w + 4 * (s / 3), std::integral_constant<int, s % 3>{}, sc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
             RPROBE(tid == 0, 2);
             static_for<0, PD>([&](auto qc) {
                 issue_a(base_cur, qc, std::integral_constant<int, decltype(qc)::value % NSETS>{}, I1{});
@@ -263,8 +288,7 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                             for (int t2 = 0; t2 < TPS; ++t2)
 #pragma unroll
                                 for (int u = 0; u < NT; ++u)
-                                    acc[part * TPS + t2][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[as][t2][P == 0 ? 1 : 0], wf[ws][u][P == 1 ? 1 : 0],
-                                                                                                     acc[part * TPS + t2][u], 0, 0, 0);
+                                    acc[part * TPS + t2][u] = split_mfma<H>(af[as][t2][P == 0 ? 1 : 0], wf[ws][u][P == 1 ? 1 : 0], acc[part * TPS + t2][u]);
                         }
                     };
                     auto reads = [&](auto hc) {
@@ -335,6 +359,7 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
     const bool is_mfma = wave < NMF;
     const int me = is_mfma ? (wave & 3) : wave - NMF;          // the pixel tile this wave finishes (if it is one of the MT tiles) = its K quarter
     const int ut = is_mfma ? NTW * (wave >> 2) : 1;            // ... and the channel tile (producers: the second tile of the one group, NTW = 2)
+#ifndef XR_X_NORED     // (probe switch: no partial tiles through LDS - the sums below read whatever the ring left there)
     if (is_mfma) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -349,6 +374,7 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                     }
                 }
     }
+#endif
     __syncthreads();
     if ((is_mfma || NTW == 2) && me < MT) {
         f32x16 own;
@@ -364,11 +390,16 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
         for (int s = 0; s < 4; ++s) {
             f32x16 part;
             const char* sp = smem + ((s * MT + me) * NTT + ut) * XR_SLOT + lane * 16;
+#ifdef XR_X_NORED
+            part = own;
+            asm volatile("" : "+v"(part));
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sp + q * 1024);
                 part[4 * q] = v[0]; part[4 * q + 1] = v[1]; part[4 * q + 2] = v[2]; part[4 * q + 3] = v[3];
             }
+#endif
             const bool mine = is_mfma && s == me;              // (that slot was never written: its bytes are not used)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -376,19 +407,30 @@ __global__ __launch_bounds__((XrT<NTW, NU, TH>::NTHR)) void conv_x3r_kernel(cons
                 sum[r] = s == 0 ? p : sum[r] + p;
             }
         }
+        if constexpr (H) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[r] *= SSR_F32H_UNSCALE;       // the packed weights carry 2^SSR_F32H_WSHIFT
+        }
         // the transpose slab: a slot no other wave reads (an MFMA wave's own, never written, slot of its tile; a producer's: source quarter 0's)
         char* slab = smem + (((is_mfma ? me : 0) * MT + me) * NTT + ut) * XR_SLOT;
         const int cb = co0 + 32 * ut;
+#ifdef XR_X_NOEPI      // (probe switch: the sums leave through one plain store per lane instead of the transposing epilogue)
+        float keep = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += sum[r];
+        if (keep == 123.456f) reinterpret_cast<float*>(d.y.p)[tid] = keep;
+#else
         if constexpr (EP == XR_EP_GENERIC) conv_epilogue<float, XR_ROT>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
         else xr_epilogue<EP>(d, sum, cb, n, gy0 + 2 * me, gx0, lane, slab);
+#endif
     }
     RPROBE(tid == 0, 11);
 }
 
-template <int NTW, int NU, int EP, int TH = 8, bool EX = false>
+template <int NTW, int NU, int EP, int TH = 8, int AM = 0>
 int launch_x3r(const ssr_conv_desc& d, hipStream_t st) {
     using T = XrT<NTW, NU, TH>;
-    auto kern = conv_x3r_kernel<NTW, NU, EP, TH, EX>;
+    auto kern = conv_x3r_kernel<NTW, NU, EP, TH, AM>;
     static bool attr_done[SSR_MAX_DEVICES] = {};               // the attribute is per DEVICE
     const int dev = ssr_device_ordinal();
     if (!attr_done[dev]) {
@@ -417,13 +459,13 @@ int xr_pick_epilogue(const ssr_conv_desc& d) {
     return XR_EP_GENERIC;
 }
 
-template <int NTW, int NU, int TH = 8, bool EX = false>
+template <int NTW, int NU, int TH = 8, int AM = 0>
 int launch_x3r_ep(const ssr_conv_desc& d, hipStream_t st) {
     switch (xr_pick_epilogue(d)) {
-        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU, TH, EX>(d, st);
-        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN, TH, EX>(d, st);
-        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK, TH, EX>(d, st);
-        default: return launch_x3r<NTW, NU, XR_EP_GENERIC, TH, EX>(d, st);
+        case XR_EP_LRELU: return launch_x3r<NTW, NU, XR_EP_LRELU, TH, AM>(d, st);
+        case XR_EP_LIN: return launch_x3r<NTW, NU, XR_EP_LIN, TH, AM>(d, st);
+        case XR_EP_MASK: return launch_x3r<NTW, NU, XR_EP_MASK, TH, AM>(d, st);
+        default: return launch_x3r<NTW, NU, XR_EP_GENERIC, TH, AM>(d, st);
     }
 }
 
@@ -460,7 +502,7 @@ int xr_wide_form(const ssr_conv_desc& d) {
 // symbol is conv_x3r_kernel<NTW, NU, EP>)
 void ssr_conv_x3r_instance(const ssr_conv_desc& d, int* ntw, int* nu, int* ep) {
     int f = xr_wide_form(d);
-    if (d.dtype == SSR_F32 && f == 2) f = 1;
+    if ((d.dtype == SSR_F32 || d.dtype == SSR_F32H) && f == 2) f = 1;
     *ntw = f == 1 ? 2 : 1;
     *nu = f == 2 ? 2 : 1;
     *ep = xr_pick_epilogue(d);
@@ -469,7 +511,7 @@ int ssr_conv_x3r_tile_height(const ssr_conv_desc& d) { return xr_tile_height(d, 
 
 bool ssr_conv_x3r_shape_ok(const ssr_conv_desc& d) {
     static const bool ex_off = [] { const char* e = getenv("SSR_F32_REGTILE"); return e && e[0] == '0'; }();
-    if (!(d.dtype == SSR_F32X3 || (d.dtype == SSR_F32 && !ex_off)) || d.fix_list) return false;
+    if (!(d.dtype == SSR_F32X3 || d.dtype == SSR_F32H || (d.dtype == SSR_F32 && !ex_off)) || d.fix_list) return false;
     if (d.dtype == SSR_F32 && (d.act == SSR_ACT_RELU || d.m_relu)) return false;      // (the VGG19 layers keep the pipelined kernel: conv2d_impl)
     if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_y == 1 && d.pad_x == 1 && d.up == 1 && !d.s2d)) return false;
     if (d.Gh != d.Hi || d.Gw != d.Wi || (d.CoutPad % 32) != 0) return false;
@@ -491,8 +533,13 @@ bool ssr_conv_x3r_try(const ssr_conv_desc& d, hipStream_t st, int* rc, bool forc
     if (force ? !ssr_conv_x3r_shape_ok(d) : !ssr_conv_x3r_qualifies(d)) return false;
     const int f = xr_wide_form(d);
     if (d.dtype == SSR_F32) {                                  // exact fp32 arithmetic: four-wave forms only
-        if (f != 0) *rc = launch_x3r_ep<2, 1, 8, true>(d, st);
-        else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4, true>(d, st) : launch_x3r_ep<1, 1, 8, true>(d, st);
+        if (f != 0) *rc = launch_x3r_ep<2, 1, 8, 1>(d, st);
+        else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4, 1>(d, st) : launch_x3r_ep<1, 1, 8, 1>(d, st);
+        return true;
+    }
+    if (d.dtype == SSR_F32H) {                                 // fp16-split forward arithmetic: four-wave forms only
+        if (f != 0) *rc = launch_x3r_ep<2, 1, 8, 2>(d, st);
+        else *rc = xr_tile_height(d, f) == 4 ? launch_x3r_ep<1, 1, 4, 2>(d, st) : launch_x3r_ep<1, 1, 8, 2>(d, st);
         return true;
     }
     if (f == 2) *rc = launch_x3r_ep<1, 2>(d, st);

@@ -39,9 +39,16 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // bytes as 16 floats — so the split-bf16 conv kernel copies weight rows to LDS as they are (the weight slab is 60-75 % of what
 // a workgroup stages per chunk, and every workgroup would otherwise repeat the same conversion).  Rows of 8 (the 4x4 stride-2
 // forward layers, which run on the exact fp32 kernel) stay plain fp32.
-template <typename T, bool X3>
+// SSR_F32H (X3 = 2, round 6; forward tables only): the same rows with fp16 pieces of 2^SSR_F32H_WSHIFT w (include/ssr_hip.h).
+template <typename T, int X3>
 __device__ __forceinline__ void put_packed(T* __restrict__ dst, size_t idx, int ck, float v) {
-    if (X3 && ck == 16) {
+    if (X3 == 2 && ck == 16) {
+        _Float16* row = reinterpret_cast<_Float16*>(dst) + (idx >> 4) * 32;
+        const float vs = v * SSR_F32H_WSCALE;
+        const _Float16 h = (_Float16)vs;
+        row[idx & 15] = h;
+        row[16 + (idx & 15)] = (_Float16)(vs - (float)h);
+    } else if (X3 == 1 && ck == 16) {
         __bf16* row = reinterpret_cast<__bf16*>(dst) + (idx >> 4) * 32;
         const __bf16 h = (__bf16)v;
         row[idx & 15] = h;
@@ -51,7 +58,7 @@ __device__ __forceinline__ void put_packed(T* __restrict__ dst, size_t idx, int 
     }
 }
 
-template <typename T, bool X3 = false>
+template <typename T, int X3 = 0>
 __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restrict__ items) {
     const ssr_pack_item it = items[blockIdx.y];
     const int KK = it.KH * it.KW;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const ssr_pack_item* __restri
     }
 }
 
-template <typename T, bool X3 = false>
+template <typename T, int X3 = 0>
 __global__ __launch_bounds__(256) void pack_seg_kernel(const ssr_pack_seg* __restrict__ items) {
     const ssr_pack_seg it = items[blockIdx.y];
     T* __restrict__ dst = reinterpret_cast<T*>(it.dst);
@@ -736,7 +743,8 @@ extern "C" int ssr_pack_weights(const ssr_pack_item* items_dev, int32_t n_items,
     // workgroups per layer to fill the chip (r01 rocprofv3: 42 us for 35 MB); the generator's 351 small layers do not
     dim3 grid(n_items <= 16 ? 1024 : 64, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
-    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_kernel<float, true>), grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_kernel<float, 1>), grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_F32H) hipLaunchKernelGGL((pack_kernel<float, 2>), grid, dim3(256), 0, ST(stream), items_dev);   // (forward tables: the mode's backward is SSR_F32X3)
     else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
     else return SSR_EUNSUP;
     SSR_LAUNCH_CHECK();
@@ -747,7 +755,7 @@ extern "C" int ssr_pack_dgrad_gather(const ssr_pack_seg* items_dev, int32_t n_it
     if (!items_dev || n_items <= 0) return SSR_EINVAL;
     dim3 grid(8, n_items);
     if (dtype == SSR_F32) hipLaunchKernelGGL(pack_seg_kernel<float>, grid, dim3(256), 0, ST(stream), items_dev);
-    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_seg_kernel<float, true>), grid, dim3(256), 0, ST(stream), items_dev);
+    else if (dtype == SSR_F32X3) hipLaunchKernelGGL((pack_seg_kernel<float, 1>), grid, dim3(256), 0, ST(stream), items_dev);
     else if (dtype == SSR_BF16) hipLaunchKernelGGL(pack_seg_kernel<__bf16>, grid, dim3(256), 0, ST(stream), items_dev);
     else return SSR_EUNSUP;
     SSR_LAUNCH_CHECK();

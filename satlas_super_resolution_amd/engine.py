@@ -54,7 +54,7 @@ class ParamStore:
 
     def __init__(self, specs: List[ConvSpec], dtype: int, device="cuda"):
         self.specs = OrderedDict((s.name, s) for s in specs)
-        # mode hip.F32F: forward convolutions exact fp32, everything else (storage, backward convolutions, weight gradients) as fp32x3;
+        # modes hip.F32F / hip.F32H: forward convolutions exact fp32 / fp16-split, everything else (storage, backward convolutions, weight gradients) as fp32x3;
         # `dtype` is what the C ABI sees for tensors and backward launches, `fwd_dtype` what forward conv descriptors and the forward
         # packing carry
         self.mode = dtype
@@ -1152,7 +1152,7 @@ def discriminator_specs(num_in_ch, num_feat=64, in_hw: Optional[Tuple[int, int]]
     below 24 rows (r01 per-layer times at B=32: conv3, 16x16 grid, 82 vs 66 us; conv1/conv2 67/51 vs 99/87 us).  In the split-bf16
     mode the alternative is the exact fp32 MFMA (conv3: 340 us), so half-empty tiles still win there: 16 rows and up."""
     nf = num_feat
-    min_rows = 16 if dtype == hip.F32X3 else 24
+    min_rows = 16 if dtype in (hip.F32X3, hip.F32H3, hip.F32H) else 24
     grid = lambda k: None if in_hw is None or min(in_hw[0] >> k, in_hw[1] >> k) >= min_rows else False
     return _disc_specs(num_in_ch, nf, grid)
 

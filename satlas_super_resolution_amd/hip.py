@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssr_hip.so")
 
 F32, BF16, F32X3 = 0, 1, 2    # F32X3: fp32 storage, split-bf16 matrix math (include/ssr_hip.h)
+F32H3 = 3                     # SSR_F32H: forward convolutions with fp16-split operands (forward descriptors and forward weight tables only)
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 DETERMINISTIC = 0x200          # OR-ed into the dtype of ssr_l1_loss / ssr_bce_logits_loss: per-block loss slots (include/ssr_hip.h)
 LOSS_SLOTS = 256
@@ -213,16 +214,24 @@ def stream_ptr() -> int:
 # decisions are an fp32 evaluation's, and the backward - linear in the incoming gradient given those decisions - keeps its
 # matrix-core speed.  Code > 15: never passed to the library (storage_code() gives the code the C ABI sees).
 F32F = 16 + F32X3
+# "fp32h" (round 6, after fp32f): the same idea at the split-bf16 mode's speed.  What the decisions need is not an exact product but a
+# pre-activation as close to the fp32 value as another fp32 summation order would be: FORWARD convolutions on fp16-split operands
+# (SSR_F32H: two 11-bit pieces = 22 bits of each operand, three v_mfma_f32_32x32x16_f16 per product, weights pre-scaled by 2^10 so that
+# their lo pieces stay in fp16's normal range; include/ssr_hip.h), everything backward in split-bf16 as in fp32x3 / fp32f (gradients of
+# 1e-7 do not fit fp16 without a per-tensor scale, and the backward is linear in them given the decisions).  CPU emulation of the
+# candidate arithmetics on the full-depth generator (tools/experiments/split_forward_flips.py, 22.8 M decisions): flips against the
+# float64 truth - plain fp32 2, bf16 x3 45, fp16 x3 unscaled 23, fp16 x3 with scaled weights 0, bf16 x6 0.
+F32H = 32 + F32X3
 
 
 def storage_code(dt: int) -> int:
     """the dtype code the C ABI sees for tensors / non-conv launches / backward convolutions of mode `dt`"""
-    return F32X3 if dt == F32F else dt
+    return F32X3 if dt in (F32F, F32H) else dt
 
 
 def forward_code(dt: int) -> int:
     """the dtype code of the FORWARD convolutions of mode `dt`"""
-    return F32 if dt == F32F else dt
+    return F32 if dt == F32F else F32H3 if dt == F32H else dt
 
 
 def torch_dtype(dt: int):
@@ -232,14 +241,14 @@ def torch_dtype(dt: int):
 def dtype_code(dt) -> int:
     if isinstance(dt, str):
         try:
-            return {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp32x3": F32X3, "bf16x3": F32X3, "fp32f": F32F}[dt]
+            return {"fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp32x3": F32X3, "bf16x3": F32X3, "fp32f": F32F, "fp32h": F32H}[dt]
         except KeyError:
             raise ValueError(f"unsupported compute dtype {dt!r}") from None
     if dt is torch.float32:
         return F32
     if dt is torch.bfloat16:
         return BF16
-    if dt in (F32, BF16, F32X3, F32F):
+    if dt in (F32, BF16, F32X3, F32F, F32H):
         return int(dt)
     raise ValueError(f"unsupported compute dtype {dt!r}")
 

@@ -242,7 +242,8 @@ def _grad_close(got, ref, what, split=False):
 @pytest.mark.parametrize("mode,c_in,feed_disc_lr", [("bf16", 24, False), ("bf16", 24, True), pytest.param("bf16", 3, False, marks=pytest.mark.slow),
                                                     pytest.param("bf16", 96, False, marks=pytest.mark.slow)]
                          + [("fp32x3", c, f) for c, f in ((3, False), (24, False), (24, True), (96, False))]
-                         + [("fp32", 24, False), ("fp32f", 24, False), pytest.param("fp32f", 24, True, marks=pytest.mark.slow)])
+                         + [("fp32", 24, False), ("fp32f", 24, False), pytest.param("fp32f", 24, True, marks=pytest.mark.slow),
+                            ("fp32h", 24, False), ("fp32h", 24, True)])
 def test_train_step_full_depth_vs_oracle(mode, c_in, feed_disc_lr):
     """One optimize_parameters() at nf=64/gc=32/nb=23, B=4, against the oracle in the same precision model: the six logged
     scalars, every generator and discriminator parameter gradient, the generator output.  (24, True) feeds the 27-channel
@@ -278,7 +279,7 @@ def test_train_step_full_depth_vs_oracle(mode, c_in, feed_disc_lr):
             worst = (k, e)
         if mode != "bf16":
             _grad_close(got, g, k, split=(mode == "fp32x3"))
-    assert worst[1] < (gtol if mode not in ("fp32", "fp32f") else 5e-3), worst      # (fp32f: exact forward, split-bf16 backward - the exact mode's strict gates)
+    assert worst[1] < (gtol if mode not in ("fp32", "fp32f", "fp32h") else 5e-3), worst      # (fp32f / fp32h: exact / fp16-split forward, split-bf16 backward - the exact mode's strict gates)
     out = ts.output().cpu()
     if mode == "bf16":
         assert rel_err(out, orc.output) < otol, rel_err(out, orc.output)
@@ -425,13 +426,13 @@ def _vs_truth(got, ref32, ref64, what, mode, is_input_grad=False):
     e_dev, e_ref, m_dev = float(err.max()) / scale, float((ref32 - ref64).abs().max()) / scale, float(err.mean()) / scale
     print(f"[{mode} {what}] outside gate: device {f_dev:.2e} / reference fp32 {f_ref:.2e}; max-norm: {e_dev:.2e} / {e_ref:.2e}; mean {m_dev:.2e}")
     assert torch.isfinite(got).all()
-    if mode in ("fp32", "fp32f"):      # fp32f (round 6): exact fp32 forward = an fp32 evaluation's LeakyReLU decisions, split-bf16 backward: the SAME unconditional gate
+    if mode in ("fp32", "fp32f", "fp32h"):      # fp32f / fp32h (round 6): exact fp32 / fp16-split forward = an fp32 evaluation's LeakyReLU decisions, split-bf16 backward: the SAME unconditional gate
         assert f_dev <= 1e-3 and e_dev <= 5e-3 and m_dev <= 3e-4, (what, f_dev, e_dev, m_dev)
     else:
         assert e_dev <= 0.1 and m_dev <= 1e-2, (what, f_dev, e_dev, m_dev)      # sanity bound only: see the docstring
 
 
-@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24), ("fp32f", "full_g24", 24),
+@pytest.mark.parametrize("mode,name,c_in", [("fp32", "full_g24", 24), ("fp32x3", "full_g24", 24), ("fp32f", "full_g24", 24), ("fp32h", "full_g24", 24),
                                             pytest.param("fp32x3-fix", "full_g24", 24, marks=pytest.mark.slow)])   # full_g96 pins the oracle (CPU test)
 def test_generator_vs_reference_class_at_full_size(mode, name, c_in, monkeypatch):
     """SSR_RRDBNet(nf=64, gc=32, nb=23) forward + backward on the device against what the UNMODIFIED reference class produced for
@@ -496,7 +497,7 @@ def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
     worst = max(range(len(prec.flips)), key=lambda i: prec.flips[i] / prec.sizes[i])
     print(f"[{mode} masked] LeakyReLU decisions that differ from the float64 oracle's own: {flips} of {total} ({flips / total:.2e}); "
           f"worst activation #{worst}: {prec.flips[worst]} of {prec.sizes[worst]}")
-    tol = 2e-4 if (mode.startswith("fp32x3") or mode == "fp32f") else 1e-4          # of max|ref| per tensor; measured: see the printed lines
+    tol = 2e-4 if (mode.startswith("fp32x3") or mode in ("fp32f", "fp32h")) else 1e-4          # of max|ref| per tensor; measured: see the printed lines
     worst_err = 0.0
     for k, g in got.items():
         ref = xm.grad if k.startswith("dx") else sdm[k].grad
@@ -511,7 +512,7 @@ def _masked_gradient_check(fwd, sd, x, r, masks, got, mode, param_keys=None):
     print(f"[{mode} masked] worst parameter / input gradient deviation from the mask-conditioned float64 oracle: {worst_err:.2e} of max|ref| (asserted <= {tol:.0e})")
 
 
-@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), ("fp32f", "full_d3"), pytest.param("fp32x3-fix", "full_d3", marks=pytest.mark.slow)])                    # full_d27 pins the oracle (CPU test)
+@pytest.mark.parametrize("mode,name", [("fp32", "full_d3"), ("fp32x3", "full_d3"), ("fp32f", "full_d3"), ("fp32h", "full_d3"), pytest.param("fp32x3-fix", "full_d3", marks=pytest.mark.slow)])                    # full_d27 pins the oracle (CPU test)
 def test_discriminator_vs_reference_class_at_full_size(mode, name, monkeypatch):
     """SSR_UNetDiscriminatorSN(nf=64) on 128x128 (3- and 27-channel input) against the unmodified reference class: logits, input
     gradient, parameter gradients through the spectral norm, u / v after the power iteration."""

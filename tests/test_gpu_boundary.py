@@ -293,7 +293,7 @@ def test_quantize_u8_round_and_truncate_bit_exact():
     assert (M.tensor2img_u8(x.cuda(), truncate=True).cpu().numpy() == ref_trunc).all()
 
 
-@pytest.mark.parametrize("compute_dtype", ["fp32x3", "bf16", "fp32f"])
+@pytest.mark.parametrize("compute_dtype", ["fp32x3", "bf16", "fp32f", "fp32h"])
 def test_shipped_option_file_builds_and_trains(tmp_path, monkeypatch, compute_dtype):
     """/root/reference/ssr/options/esrgan_s2naip_urban.yml as shipped (tests/golden/ssr_options.json) driven like train.py does:
     full-size networks (nf=64, nb=23; 36-channel generator input as the file says), L1 + VGG19 perceptual + GAN, USM targets,

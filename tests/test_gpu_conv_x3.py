@@ -255,13 +255,94 @@ def test_regtile_exact_fp32_conv(variant, cin, cout, H, W, B):
     _run_3x3(variant, cin, cout, H, W, B, impl=7, mode="fp32", TOL=2e-6)
 
 
+# ---- the fp16-split FORWARD arithmetic (SSR_F32H, mode fp32h, round 6): the split kernels with fp16 pieces (22 bits per operand), weights
+#      packed x 2^10, v_mfma_f32_32x32x16_f16.  Held to the float64 contract reference at the EXACT mode's tolerance ----
+H_TOL = 2e-6
+
+
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "mask_r1", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 32, 32, 2), (192, 64, 32, 32, 2), (160, 32, 32, 32, 32), (96, 32, 21, 37, 1), (24, 64, 9, 7, 1),
+                                            (320, 64, 16, 16, 1), (40, 20, 24, 24, 1), (128, 32, 32, 32, 4)])
+def test_regtile_fp16_split_conv(variant, cin, cout, H, W, B):
+    """register-tiled kernel (csrc/conv_x3r.hip, AM = 2): full and half-height tiles, both 64-channel forms, ragged tiles, half-filled chunks"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=7, mode="fp32h", TOL=H_TOL)
+
+
+@pytest.mark.parametrize("variant", ["lrelu", "lrelu_r1_y0", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B,up", [(128, 64, 32, 32, 2, 1), (96, 128, 37, 21, 1, 1), (3, 64, 40, 24, 2, 1), (64, 64, 32, 32, 2, 2)])
+def test_big_tile_fp16_split_conv(variant, cin, cout, H, W, B, up):
+    """big-tile kernel (csrc/conv_big_x3.hip, conv_bigh3_kernel4): the accumulators start at 2^10 x bias and leave x 2^-10"""
+    _run_3x3(variant, cin, cout, H, W, B, up=up, impl=4, mode="fp32h", TOL=H_TOL)
+
+
+@pytest.mark.parametrize("variant", ["plain", "lrelu", "generic"])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 32, 16, 16, 2), (72, 96, 12, 20, 1), (16, 64, 8, 8, 3)])
+def test_pipelined_fp16_split_conv(variant, cin, cout, H, W, B):
+    """the pipelined split kernel (csrc/conv.hip, conv_h3_kernel): where every other shape of the mode ends up"""
+    _run_3x3(variant, cin, cout, H, W, B, impl=3, mode="fp32h", TOL=H_TOL)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 3, 128, 128, 2), (64, 1, 64, 64, 1), (24, 8, 70, 66, 1)])
+def test_thin_output_fp16_rows(cin, cout, H, W, B):
+    """thin-output VALU kernel on the mode's packed rows: w = (hi + lo) 2^-10 of the fp16 pieces, fp32 FMAs"""
+    _run_3x3("plain", cin, cout, H, W, B, impl=5, mode="fp32h", TOL=H_TOL)
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -9, 1.0, 2.0 ** 9])
+def test_fp16_split_accuracy_over_the_activation_range(scale):
+    """what the mode promises and what it does not: activations are staged UNSCALED - an element above 2^-3 keeps 22 bits, a smaller one an
+    absolute error of 2^-25.  At ordinary magnitudes (x ~ 0.5) and at x ~ 256 the result is fp32-like; at x ~ 1e-3 the error relative to the
+    result grows to ~2^-25 / 1e-3 = 3e-5 - still inside the output gate, but no longer decision-exact (documented in include/ssr_hip.h)"""
+    engine, hip = _mods()
+    torch.manual_seed(5)
+    cin, cout, H, W, B = 128, 32, 32, 32, 2
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], hip.dtype_code("fp32h"))
+    w = torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    st.load_state_dict({"c.weight": w, "c.bias": torch.zeros(cout)})
+    st.pack()
+    xb = (torch.randn(B, H, W, cin, device="cuda") * 0.5 * scale).contiguous()
+    y = torch.zeros(B, H, W, cout, device="cuda")
+    d = engine._ConvBuilder(st, B).conv(engine.Launcher(), "c", hip.view(xb), H, W, hip.view(y), cin=cin)
+    hip.check(hip.lib().ssr_conv2d(C.byref(d), hip.stream_ptr()), "ssr_conv2d")
+    torch.cuda.synchronize()
+    ref = F.conv2d(_nchw(xb, cin), w.double(), None, padding=1)
+    e = rel_err(y.cpu().permute(0, 3, 1, 2).double(), ref)
+    print(f"[fp32h] activation scale {scale:g}: {e:.2e} of max|ref|")
+    assert torch.isfinite(y).all()
+    assert e < (2e-6 if scale >= 1.0 else 2e-4), e
+
+
+def test_fp16_split_forward_space_to_depth():
+    """4x4 stride-2 layer through the space-to-depth view on the fp16-split big-tile kernel"""
+    engine, hip = _mods()
+    cin, cout, H, W, B = 64, 128, 32, 32, 2
+    torch.manual_seed(11)
+    st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 4, 2, False, True)], hip.dtype_code("fp32h"))
+    assert st.s2d["c"]
+    w = torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5)
+    st.load_state_dict({"c.weight_orig": w, "c.weight_u": torch.randn(cout), "c.weight_v": torch.randn(cin * 16)})
+    st.spectral_norm(power_iter=False)
+    st.pack()
+    sigma = float(st.sigma[0])
+    xb = (torch.randn(B, H, W, cin, device="cuda") * 0.5).contiguous()
+    yb = torch.zeros(B, H // 2, W // 2, cout, device="cuda")
+    L = engine.Launcher()
+    d = engine._ConvBuilder(st, B).conv(L, "c", hip.view(xb), H, W, hip.view(yb), act=hip.ACT_LRELU)
+    assert d.s2d == 1 and d.dtype == hip.F32H3 and hip.conv_symbol(d).startswith("conv_bigh3_kernel4<2>")
+    L.run()
+    torch.cuda.synchronize()
+    yr = F.leaky_relu(F.conv2d(_nchw(xb, cin), (w / sigma).double(), None, stride=2, padding=1), 0.2)
+    e = rel_err(yb.cpu().permute(0, 3, 1, 2).double(), yr)
+    assert e < H_TOL, e
+
+
 def test_regtile_exact_fp32_is_the_automatic_choice_for_the_body():
     engine, hip = _mods()
     st = engine.ParamStore([engine.ConvSpec("b", 32, 160, 3, 1, True, False)], hip.F32)
     cb = engine._ConvBuilder(st, 32)
     buf = torch.zeros(32, 32, 32, 192, device="cuda")
     d = cb.conv(engine.Launcher(), "b", hip.view(buf, 0), 32, 32, hip.view(buf, 160), act=hip.ACT_LRELU, cin=160)
-    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5 and hip.conv_symbol(d) == "conv_x3r_kernel<1, 1, 0, 8, true>"
+    assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5 and hip.conv_symbol(d) == "conv_x3r_kernel<1, 1, 0, 8, 1>"
 
 
 def test_regtile_x3_linear_epilogue_with_two_residuals():

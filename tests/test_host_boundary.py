@@ -352,3 +352,25 @@ def test_wgrad_batches_of_the_split_mode_pick_the_one_pass_kernel_for_3x3_layers
     paired = wb._pair(wb.items)
     assert sum(it.nco == 2 for it in paired if it.layer < 5) == 6                      # as the bf16 kernel: 6 pairs + 2 singles per block
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, wb.kdt, 3) == 128
+
+
+def test_arithmetic_mode_codes_split_into_storage_and_forward_codes():
+    """compute_dtype names -> mode codes; a mode is (what the C ABI sees for tensors / backward launches, what its forward convolutions carry):
+    fp32f = exact forward on split-bf16 storage, fp32h = fp16-split forward (include/ssr_hip.h SSR_F32H) on split-bf16 storage"""
+    from satlas_super_resolution_amd import hip
+    table = {"fp32": (hip.F32, hip.F32), "bf16": (hip.BF16, hip.BF16), "fp32x3": (hip.F32X3, hip.F32X3), "fp32f": (hip.F32X3, hip.F32),
+             "fp32h": (hip.F32X3, hip.F32H3)}
+    for name, (st, fw) in table.items():
+        m = hip.dtype_code(name)
+        assert hip.dtype_code(m) == m and (hip.storage_code(m), hip.forward_code(m)) == (st, fw), name
+    assert hip.F32H3 == 3 and len({hip.dtype_code(n) for n in table}) == 5
+    import re
+    hdr = open(__file__.replace("tests/test_host_boundary.py", "include/ssr_hip.h")).read()
+    assert re.search(r"#define SSR_F32H 3\b", hdr) and re.search(r"#define SSR_F32H_WSHIFT 10\b", hdr)
+    with pytest.raises(ValueError):
+        hip.dtype_code("fp16")
+    # the stride-2 layers of the discriminator take the space-to-depth form from 16-row grids on in both split forward arithmetics
+    from satlas_super_resolution_amd import engine
+    for dt in (hip.F32X3, hip.F32H3, hip.dtype_code("fp32h")):
+        assert {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=(128, 128), dtype=dt) if s.k == 4}["conv3"] is None
+    assert {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=(128, 128), dtype=hip.F32) if s.k == 4}["conv3"] is False

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     hipMalloc(&x, nb); hipMalloc(&y, nb); hipMalloc(&r, nb); hipMalloc(&y0, nb);
     hipMalloc(&w, (size_t)nchunks * 9 * CoutPad * 64);
     hipMemset(x, 0, nb); hipMemset(r, 0, nb); hipMemset(w, 0, (size_t)nchunks * 9 * CoutPad * 64);
-    const int nblk = N * ((H + 7) / 8) * ((W + 15) / 16) * ((CoutPad % 64) == 0 ? CoutPad / 64 : CoutPad / 32);
+    const int nblk = N * ((H + 3) / 4) * ((W + 15) / 16) * (CoutPad / 32);      // (upper bound: half-height tiles, 32-channel workgroups)
     unsigned long long* probe; hipMalloc(&probe, (size_t)nblk * 16 * 8); hipMemset(probe, 0, (size_t)nblk * 16 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &probe, sizeof(probe));
     ssr_conv_desc d{};

@@ -6,7 +6,7 @@ ssr/options/infer_example.yml):
 Same inputs (every PNG under `data_dir`, each [n_s2_images*32, 32, 3]) and the same outputs: `{save_path}/{i}/lr.png` (the first
 Sentinel-2 frame, for comparison) and `{save_path}/{i}/sr.png` (clamp(0,1) * 255 truncated to uint8, infer.py:58-61), i = position of
 the image in the listing.  The listing is sorted here (the reference takes glob's order, which is the file system's); the images
-go through the HIP generator in batches instead of one at a time; `compute_dtype` (default fp32x3, the parity mode) and `batch` are
+go through the HIP generator in batches instead of one at a time; `compute_dtype` (default fp32h, the all-gates mode) and `batch` are
 this package's two extra option keys."""
 from __future__ import annotations
 

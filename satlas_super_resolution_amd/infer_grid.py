@@ -9,7 +9,7 @@ stitched_sr.png 2048x2048 and stitched_s2.png 512x512 per complete tile).  What 
 chunk at a time through the network; here the chunk list is sharded over the ranks (rank r takes chunks r, r + world, ...: no
 collective on the data path), every rank runs its share in batches through the HIP generator, quantises on the
 device (truncating uint8, infer_grid.py:60-64) and writes its own PNGs; rank 0 stitches after a barrier.
-`compute_dtype` in the option file (our extension; default fp32x3 = the parity mode) selects the arithmetic; `batch` the chunk batch."""
+`compute_dtype` in the option file (our extension; default fp32h = the all-gates mode; its forward runs at fp32x3 speed) selects the arithmetic; `batch` the chunk batch."""
 from __future__ import annotations
 
 import argparse
@@ -33,7 +33,7 @@ def load_generator(opt: Dict, device) -> torch.nn.Module:
     from .utils.model_utils import build_network
     opt = dict(opt)
     net_opt = dict(opt["network_g"])
-    net_opt.setdefault("compute_dtype", opt.get("compute_dtype", "fp32x3"))
+    net_opt.setdefault("compute_dtype", opt.get("compute_dtype", "fp32h"))
     opt["network_g"] = net_opt
     model = build_network(opt)
     path = opt.get("path", {})

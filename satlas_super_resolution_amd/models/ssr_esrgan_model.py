@@ -86,10 +86,11 @@ class SSRESRGANModel:
         self.device = torch.device("cuda")
         self.dp = init_distributed() if opt.get("dist", False) else None
         self.g_kwargs = _arch_kwargs(opt["network_g"], "SSR_RRDBNet")
-        # default arithmetic: fp32f - exact fp32 forward (outputs and LeakyReLU decisions of an fp32 evaluation), split-bf16 backward: the
-        # fastest mode inside EVERY gate of the reference (outputs and parameter gradients at 1e-3, hip.F32F); `compute_dtype: fp32` is
-        # exact throughout, `fp32x3` / `bf16` the faster modes outside the gradient gate
-        self.compute_dtype = self.g_kwargs.pop("compute_dtype", opt.get("compute_dtype", "fp32f"))
+        # default arithmetic: fp32h - fp16-split forward (22 bits per operand: outputs and LeakyReLU decisions of an fp32 evaluation),
+        # split-bf16 backward: the fastest mode inside EVERY gate of the reference (outputs and parameter gradients at 1e-3, hip.F32H);
+        # `compute_dtype: fp32f` has the forward in exact fp32 (no fp16 range: activations beyond 65504), `fp32` is exact throughout,
+        # `fp32x3` (outputs inside the gate) / `bf16` are the modes outside the gradient gate
+        self.compute_dtype = self.g_kwargs.pop("compute_dtype", opt.get("compute_dtype", "fp32h"))
         self.feed_disc_lr = bool(opt.get("feed_disc_lr", False))
         if self.is_train:      # test.py builds the model with is_train=False: generator only (SRGANModel.__init__ / init_training_settings)
             self.d_kwargs = _arch_kwargs(opt["network_d"], "SSR_UNetDiscriminatorSN")

@@ -101,7 +101,7 @@ def _opt(tmp_path, fx, **over):
     opt = {
         "model_type": "SSRESRGANModel", "scale": 4, "manual_seed": 0, "is_train": True, "dist": False, "name": "t",
         # these tests pin the plugin's CONTROL FLOW to fixtures of the reference's own methods through Adam-normalised parameter updates
-        # (a relative error of a near-zero gradient is amplified to an update of +-lr): exact arithmetic, not the plugin's default fp32f
+        # (a relative error of a near-zero gradient is amplified to an update of +-lr): exact arithmetic, not the plugin's default fp32h
         "compute_dtype": "fp32",
         "l1_gt_usm": False, "percep_gt_usm": False, "gan_gt_usm": False, "feed_disc_lr": False,
         "network_g": dict(type="SSR_RRDBNet", **fx["g_kwargs"]),
@@ -293,7 +293,7 @@ def test_quantize_u8_round_and_truncate_bit_exact():
     assert (M.tensor2img_u8(x.cuda(), truncate=True).cpu().numpy() == ref_trunc).all()
 
 
-@pytest.mark.parametrize("compute_dtype", ["fp32x3", "bf16", "fp32f", "fp32h"])
+@pytest.mark.parametrize("compute_dtype", ["fp32x3", "bf16", "fp32h", pytest.param("fp32f", marks=pytest.mark.slow)])
 def test_shipped_option_file_builds_and_trains(tmp_path, monkeypatch, compute_dtype):
     """/root/reference/ssr/options/esrgan_s2naip_urban.yml as shipped (tests/golden/ssr_options.json) driven like train.py does:
     full-size networks (nf=64, nb=23; 36-channel generator input as the file says), L1 + VGG19 perceptual + GAN, USM targets,

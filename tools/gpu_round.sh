@@ -1,10 +1,11 @@
 #!/bin/bash
-# One GPU-box visit: the whole -m gpu suite, HBM-traffic PMC passes (the headline mode fp32x3 + the bf16 / fp32 legs), the default bench
+# One GPU-box visit: the whole -m gpu suite, HBM-traffic PMC passes (the headline mode - HEAD_DTYPE, default fp32h - + the bf16 / fp32 legs), the default bench
 # line (which then carries roofline.traffic for this very build), rocprofv3 kernel stats of the headline mode (overlapped and serial),
 # SQ/GRBM counters, and the other BASELINE.json configurations.
 #   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r05z'
 # Env: SKIP_TESTS=1, SKIP_TRAFFIC=1, SKIP_LEG_TRAFFIC=1, SKIP_PROF=1, SKIP_CONFIGS=1, PYTEST_ARGS, BENCH_ARGS
 TAG=${1:-run}
+HEAD=${HEAD_DTYPE:-fp32h}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
@@ -26,10 +27,10 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 if [ "${SKIP_TRAFFIC:-0}" != "1" ]; then      # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one), --kernel-trace only
   # (SSR_G_SPLIT=0: full-batch launches, the launch shape roofline.kernel is measured at - bench.py unsplit_twin - and the serial trace uses)
-  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
-  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --dtype fp32x3 $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
-  SSR_PMC_DTYPE=fp32x3 python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic_fp32x3.json > /dev/null && cp $O/${TAG}_traffic_fp32x3.json profiles/traffic_fp32x3.json && python -c "
-import json; d=json.load(open('$O/${TAG}_traffic_fp32x3.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
+  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch_$TAG -- python $R/bench.py --dtype $HEAD $PMC_BENCH > /tmp/pmcf_$TAG.log 2>&1)
+  (cd /tmp && SSR_G_SPLIT=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write_$TAG -- python $R/bench.py --dtype $HEAD $PMC_BENCH > /tmp/pmcw_$TAG.log 2>&1)
+  SSR_PMC_DTYPE=$HEAD python tools/pmc_traffic.py /tmp/pmc_fetch_$TAG /tmp/pmc_write_$TAG $O/${TAG}_traffic_$HEAD.json > /dev/null && cp $O/${TAG}_traffic_$HEAD.json profiles/traffic_$HEAD.json && python -c "
+import json; d=json.load(open('$O/${TAG}_traffic_$HEAD.json')); [print(k, round(v['hbm_read_bytes_per_launch']/1e6,1), 'MB read', round(v['hbm_write_bytes_per_launch']/1e6,1), 'MB written') for k,v in d.items() if k!='_meta']"
 fi
 if [ "${SKIP_LEG_TRAFFIC:-0}" != "1" ]; then  # the parity legs' dominant kernels -> profiles/traffic_<dtype>.json (bench.py legs.*.roofline.traffic)
   for DT in bf16 fp32; do
@@ -65,7 +66,7 @@ for ln in open('$O/${TAG}_dp_world1.jsonl'):
 fi
 if [ "${SKIP_CONFIGS:-0}" != "1" ]; then      # the other BASELINE.json configurations on this build, one JSON line each
   : > $O/${TAG}_bench_configs.jsonl
-  for ARGS in "--frames 1 --batch 16" "--frames 32 --batch 16" "--feed-disc-lr" "--perceptual" "--dtype bf16" "--dtype bf16 --frames 1 --batch 16" "--dtype bf16 --frames 32 --batch 16" "--dtype fp32"; do
+  for ARGS in "--frames 1 --batch 16" "--frames 32 --batch 16" "--feed-disc-lr" "--perceptual" "--dtype fp32x3" "--dtype fp32x3 --frames 1 --batch 16" "--dtype bf16" "--dtype bf16 --frames 1 --batch 16" "--dtype bf16 --frames 32 --batch 16" "--dtype fp32f" "--dtype fp32"; do
     SSR_VGG19_RANDOM=1 python bench.py $ARGS --no-cpu-baseline --no-legs 2>/dev/null | tail -1 >> $O/${TAG}_bench_configs.jsonl
   done
   SSR_DETERMINISTIC=1 python bench.py --no-cpu-baseline --no-legs 2>/dev/null | tail -1 | python -c "

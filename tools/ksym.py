@@ -23,9 +23,10 @@ def bare(name: str) -> str:
 
 def family(name: str) -> str:
     s = bare(name)
-    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d), (\w+)>", s)      # <channel tiles per wave, wave groups, epilogue, tile height>
-    if m:
-        return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}, {m.group(4)}>"
+    m = re.match(r"conv_x3r_kernel<(\d), (\d), \d, (\d), (\w+)>", s)      # <channel tiles per wave, wave groups, epilogue, tile height, arithmetic>
+    if m:      # arithmetic 0 (split-bf16) and 2 (split-fp16, the forward launches of mode fp32h): one row, as in bench.py family()
+        am = "0|2" if m.group(4) in ("0", "2") else m.group(4)
+        return f"conv_x3r_kernel<{m.group(1)}, {m.group(2)}, *, {m.group(3)}, {am}>"
     return s
 
 

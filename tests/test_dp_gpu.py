@@ -130,7 +130,7 @@ def test_bench_n_ranks_on_one_gpu_prints_one_json_line(world):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["config"]["global_batch"] == 2 * world and out["losses_finite"]
-    assert out["config"]["parallelism"] == f"dp{world}" and out["scaling"] == "weak" and out["dtype"] == "fp32x3"
+    assert out["config"]["parallelism"] == f"dp{world}" and out["scaling"] == "weak" and out["dtype"] == "fp32h"
     assert out["value"] == pytest.approx(2 * world * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-6)   # whole-job rate
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
     # per-rank diagnostics: a sub-linear scaling result must be attributable (compute / exposed communication / host) from this one line
@@ -159,7 +159,7 @@ def test_bench_over_rccl_ends_stdout_with_the_json_line():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     out = json.loads(lines[-1])                                # the LAST line
-    assert sum(ln.startswith("{") for ln in lines) == 1 and out["losses_finite"] and out["dtype"] == "fp32x3"
+    assert sum(ln.startswith("{") for ln in lines) == 1 and out["losses_finite"] and out["dtype"] == "fp32h"
 
 
 def _rccl_worker(port, outdir):

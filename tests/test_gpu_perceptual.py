@@ -62,7 +62,7 @@ def _run_plan(mode, B, H, W, sd, x, gt):
     return plan, float(loss[0]), gbuf[..., :3].float().cpu().permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("mode,B,H,W", [("fp32", 2, 32, 48), ("fp32x3", 2, 32, 48), ("bf16", 2, 128, 128)])
+@pytest.mark.parametrize("mode,B,H,W", [("fp32", 2, 32, 48), ("fp32x3", 2, 32, 48), ("fp32h", 2, 32, 48), ("bf16", 2, 128, 128)])
 def test_perceptual_plan_matches_oracle(mode, B, H, W):
     """loss value, every tapped feature, and d loss / d image; bf16 at the 128x128 size of the train step against the bf16
     precision model of the oracle."""

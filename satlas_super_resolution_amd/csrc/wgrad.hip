@@ -156,7 +156,7 @@ int ssr_wgrad_x3_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* i
                           hipStream_t st);
 
 extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dtype, int32_t KH) {
-    const int th = dtype == SSR_BF16 ? wgrad_bf16_th(KH) : WG_TH;
+    const int th = dtype == SSR_BF16 ? wgrad_bf16_th(KH) : (dtype == SSR_F32X3 && KH == 4) ? 4 : WG_TH;      // (the one-pass 4x4 kernel: 4 x 16-pixel tiles, wgrad_x3.hip)
     return N * ((Gh + th - 1) / th) * ((Gw + WG_TW - 1) / WG_TW);
 }
 

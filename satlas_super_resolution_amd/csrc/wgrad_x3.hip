@@ -1,4 +1,5 @@
-// fp32x3 (split-bf16) weight gradient of the 3x3 stride-1 layers in ONE pass over the fp32 buffers (round 5).
+// fp32x3 (split-bf16) weight gradient of the 3x3 stride-1 layers (round 5) and of the 4x4 stride-2 layers (round 6, further down) in ONE pass
+// over the fp32 buffers.
 //   dW[co][ci][ky][kx] += alpha * sum_pixels dY[p][co] * X[p + (ky,kx) - pad][ci]      (autograd of nn.Conv2d at
 //   /root/reference/ssr/archs/rrdbnet_arch.py:30-34,104-113 and discriminator_arch.py:28-40, executed by
 //   l_g_total.backward() / l_d_real.backward() / l_d_fake.backward(): ssr/models/ssr_esrgan_model.py:188,219,227)
@@ -376,10 +377,294 @@ __global__ __launch_bounds__(512) void wgrad_x3_k3_kernel(const ssr_wgrad_layer*
     });
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 4x4 stride 2 (the discriminator's conv1..conv3, discriminator_arch.py:31-33), round 6: the same one-pass idea on the GENERIC kernel's
+// work decomposition (wgrad_bf16.hip, wgrad_bf16_kernel<4, 4, 2, true>: 32 co x 32 ci per workgroup, MFMA wave w owns tap row ky = w
+// with four accumulators kx = 0..3).  Until now these layers took ssr_split_bf16_multi over their buffers and three launches of the bf16
+// kernel over the planes (1.1 + 0.2 ms per step, six write-outs per item).  Here the loader waves read the fp32 tiles (8 channels of a
+// pixel = two 16-byte loads), split them on the way into LDS (hi plane, lo plane) and the MFMA waves issue the three products of every
+// (dY, X) fragment pair into ONE accumulator set: per k-step (one tile row of 16 output pixels) 2 dY + 8 X fragment reads for 12 MFMAs
+// (the three bf16 passes: 15 reads for 12 MFMAs).  A stage holds hi AND lo planes, so the pixel tile is 4 x 16 instead of 8 x 16:
+//   stage = dY hi, lo [64 px][32 co] + X hi, lo [10 x 34 px][32 ci] bf16 = 51,712 B; three stages + the control words = 155,648 B.
+struct Wx4 {
+    static constexpr int TH = 4, S = 2, KH = 4, KW = 4, PH = (TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW, ROW = 32;   // patch 10 x 34
+    static constexpr int DYP = TH * WG_TW * 64;              // bytes of one dY plane [64 px][32 co] bf16
+    static constexpr int XP = PH * PW * 64;                  // bytes of one X plane [340 px][32 ci] bf16
+    static constexpr int XBASE = 2 * DYP;
+    static constexpr int STAGE = 2 * DYP + 2 * XP;           // 51,712 B
+    static constexpr int NDYU = TH * WG_TW * 4;              // loader units (8 fp32 channels of a pixel = 32 B): 256 of dY
+    static constexpr int NXU = PH * PW * 4;                  // 1360 of X
+    static constexpr int NLU = (NDYU + NXU + 255) / 256;     // 7 per loader thread: unit 0 is a dY unit, units 1..6 are X units
+    static constexpr int NST = 3;
+    static constexpr int CTL = NST * STAGE;
+    static constexpr int LDS = CTL + 512;
+    static_assert(NDYU == 256 && NLU == 7, "operand lists of wait_tile / hold");
+    static_assert(LDS <= 160 * 1024 && 32 * 32 * 16 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
+};
+
+__global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer* __restrict__ layers,
+                                                          const ssr_wgrad_item* __restrict__ items) {
+    using C = Wx4;
+    constexpr int TH = C::TH, S = C::S, KW = C::KW, PW = C::PW, ROW = C::ROW, NST = C::NST, NLU = C::NLU;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ctl = reinterpret_cast<int*>(smem + C::CTL);
+    const ssr_wgrad_item it = items[blockIdx.x];
+    const ssr_wgrad_layer L = layers[it.layer];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
+    const int ntile = it.tile_end - it.tile_begin;
+    if (tid < 128) ctl[tid] = 0;
+    __syncthreads();   // the only barrier
+
+    if (wave >= 4) {
+        // =============================== loader waves ===============================
+        // unit u = lt + 256 q: q = 0: dY pixel lt >> 2 of the tile, channel octet lt & 3; q >= 1: X patch pixel (lt + 256 (q - 1)) >> 2, octet lt & 3
+        const int lt = tid - 256;
+        const int upshift = L.up == 2 ? 1 : 0;
+        const int LH = L.Hi << upshift, LW = L.Wi << upshift;
+        const int oct = lt & 3;
+        int yx[NLU];                                           // (y, x) relative to the tile / patch origin; 0x7fff7fff = never inside
+#pragma unroll
+        for (int q = 0; q < NLU; ++q) {
+            if (q == 0) {
+                const int pix = lt >> 2;
+                yx[q] = (it.co0 + oct * 8 < L.Cout) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x7fff7fff;
+            } else {
+                const int vx = lt + (q - 1) * 256;
+                const int pix = vx >> 2;
+                const int py = pix / PW, px = pix - py * PW;
+                const int y = py - L.pad_y, x = px - L.pad_x;
+                yx[q] = (vx < C::NXU && it.ci0 + oct * 8 < L.Cin) ? ((y & 0xffff) | (x << 16)) : 0x7fff7fff;
+            }
+        }
+        const int lo_dy = (lt >> 2) * 64 + oct * 16;
+        const int lo_x = C::XBASE + (lt >> 2) * 64 + oct * 16;
+        const bool do_bias = L.db != nullptr && it.ci0 == 0;
+        float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4 ra[2 * NLU], rb[2 * NLU];
+        const wx_gptr zero32 = (wx_gptr)&g_wx_zero32[0];
+        const wx_gptr dyg1 = (wx_gptr)(reinterpret_cast<const float*>(L.dy.p) + L.dy.coff + it.co0);
+        const wx_gptr xg1 = (wx_gptr)(reinterpret_cast<const float*>(L.x.p) + L.x.coff + it.ci0);
+        auto load_tile = [&](int k, u32x4 (&r)[2 * NLU]) {
+            int b = it.tile_begin + k;
+            const int tx_i = b % tiles_x; b /= tiles_x;
+            const int ty_i = b % tiles_y;
+            const int n = b / tiles_y;
+            const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
+            const wx_gptr dyb = dyg1 + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs * 4;
+            const wx_gptr xb = xg1 + ((size_t)(n * L.Hi + ((gy0 * S) >> upshift)) * L.Wi + ((gx0 * S) >> upshift)) * L.x.cs * 4;
+#pragma unroll
+            for (int q = 0; q < NLU; ++q) {
+                int yxq = yx[q];
+                asm volatile("" : "+v"(yxq));                  // keeps the offsets below from being hoisted into more registers
+                const int y = (int)(short)(yxq & 0xffff), x = yxq >> 16;
+                wx_gptr src;
+                if (q == 0) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyb + ((y * L.Gw + x) * L.dy.cs + oct * 8) * 4 : zero32;
+                else src = ((unsigned)(gy0 * S + y) < (unsigned)LH && (unsigned)(gx0 * S + x) < (unsigned)LW)
+                               ? xb + (((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + oct * 8) * 4 : zero32;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[2 * q]) : "v"(src) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[2 * q + 1]) : "v"(src) : "memory");
+            }
+        };
+        auto pass = [&](u32x4 (&r)[2 * NLU]) {
+            asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) :: "memory");
+            asm volatile("" : "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]) :: "memory");
+        };
+        auto wait_tile = [&](u32x4 (&r)[2 * NLU]) {            // every load older than the newest 2 NLU has landed
+            pass(r);
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            pass(r);
+        };
+        auto put = [&](int k, int st, u32x4 (&r)[2 * NLU]) {
+            wait_tile(r);
+            if (k >= NST) {
+                for (;;) {
+                    u32x4 dn;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"((int)(C::CTL + 4 * WXC_DONE)) : "memory");
+                    if ((int)min(min(dn[0], dn[1]), min(dn[2], dn[3])) >= k - NST + 1) break;
+                }
+            }
+            char* base = smem + st * C::STAGE;
+#pragma unroll
+            for (int q = 0; q < NLU; ++q) {
+                const f32x4 v0 = __builtin_bit_cast(f32x4, r[2 * q]), v1 = __builtin_bit_cast(f32x4, r[2 * q + 1]);
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (__bf16)v0[e];
+                    l[e] = (__bf16)(v0[e] - (float)h[e]);
+                    h[4 + e] = (__bf16)v1[e];
+                    l[4 + e] = (__bf16)(v1[e] - (float)h[4 + e]);
+                }
+                if (q == 0) {
+                    *reinterpret_cast<u32x4*>(base + lo_dy) = __builtin_bit_cast(u32x4, h);
+                    *reinterpret_cast<u32x4*>(base + lo_dy + C::DYP) = __builtin_bit_cast(u32x4, l);
+                    if (do_bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bacc[e] += v0[e];
+                            bacc[4 + e] += v1[e];
+                        }
+                    }
+                } else if (lt + (q - 1) * 256 < C::NXU) {
+                    *reinterpret_cast<u32x4*>(base + lo_x + (q - 1) * 4096) = __builtin_bit_cast(u32x4, h);
+                    *reinterpret_cast<u32x4*>(base + lo_x + C::XP + (q - 1) * 4096) = __builtin_bit_cast(u32x4, l);
+                }
+            }
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WXC_READY + st))), "v"(1) : "memory");
+        };
+        // two tiles in flight, no branch around a load (past the end the last tile is loaded again and never stored)
+        const int last = ntile - 1;
+        if (ntile > 0) {
+            load_tile(0, ra);
+            load_tile(min(1, last), rb);
+        }
+        int st = 0, k = 0;
+        for (; k + 1 < ntile; k += 2) {
+            put(k, st, ra);
+            st = st + 1 == NST ? 0 : st + 1;
+            load_tile(min(k + 2, last), ra);
+            put(k + 1, st, rb);
+            st = st + 1 == NST ? 0 : st + 1;
+            load_tile(min(k + 3, last), rb);
+        }
+        if (k < ntile) put(k, st, ra);
+        if (ntile > 0) {                                       // the loads past the end: their registers stay allocated until they have landed
+            pass(ra); pass(rb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pass(ra); pass(rb);
+        }
+        if (do_bias) {
+            // 64 threads share each channel octet (lane & 3): xor-shuffle tree over the 16 lanes of a wave that hold the octet, then the
+            // four loader waves in turn, then one global add per channel (fixed order)
+            volatile float* bl = reinterpret_cast<volatile float*>(ctl + WXC_BIAS);
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bacc[e] += __shfl_xor(bacc[e], m);
+            const int lw = lt >> 6;
+            while (wx_ld(ctl + WXC_LSYNC) < lw) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bl[lane * 8 + e] = lw == 0 ? bacc[e] : bl[lane * 8 + e] + bacc[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __atomic_fetch_add(ctl + WXC_LSYNC, 1, __ATOMIC_RELAXED);
+            while (wx_ld(ctl + WXC_LSYNC) < 4) {}
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lt < 32 && it.co0 + lt < L.Cout) atomicAdd(L.db + it.co0 + lt, L.alpha * bl[lt]);
+        }
+        return;
+    }
+
+    // =============================== MFMA waves: tap row ky = wave, accumulators kx = 0..3 ===============================
+    const int g = lane >> 5;
+    const int t16 = lane & 15;
+    const int src_px = 8 * g + (t16 >> 2);                    // + 4 for the second read of the pair
+    const int src_ch = 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
+    constexpr int DYLO = C::DYP / 2, XLO = C::XP / 2;         // bf16 elements between a hi plane and its lo plane
+    f32x16 acc[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int st = 0, target = 4;                                    // stage of tile k and its ready target 4 * (uses + 1)
+    for (int k = 0; k < ntile; ++k) {
+        while (wx_ld(ctl + WXC_READY + st) < target) {}
+        const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+        const __bf16* lx = ldy + C::XBASE / 2;
+        // operand stream of the tile: per k-step s (tile row) dY hi, dY lo, then (X hi, X lo) of the four taps; reads run PF operands ahead
+        constexpr int PER = 2 + 2 * KW, NOP = TH * PER, PF = 8;
+        bf16x8 op[NOP];
+        auto issue = [&](auto nc) {
+            constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
+            if constexpr (r < 2) {
+                const __bf16* ap = ldy + r * DYLO + (s * WG_TW + src_px) * ROW + src_ch;
+                op[n] = wx_tr_pair(ap, ap + 4 * ROW);
+            } else {
+                constexpr int t = (r - 2) >> 1, lo = (r - 2) & 1;
+                const __bf16* bp = lx + lo * XLO + ((s * S + wave) * PW + src_px * S + t) * ROW + src_ch;
+                op[n] = wx_tr_pair(bp, bp + 4 * S * ROW);
+            }
+        };
+        static_for<0, PF>([&](auto nc) { issue(nc); });
+        static_for<0, NOP>([&](auto nc) {
+            constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
+            if constexpr (n + PF == NOP - 1) {
+                if (lane == 0) __atomic_store_n(ctl + WXC_DONE + wave, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (r >= 2 && ((r - 2) & 1) == 1) {      // the lo fragment of tap t has arrived: its three products
+                constexpr int t = (r - 2) >> 1, a = s * PER;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 1], op[n - 1], acc[t], 0, 0, 0);   // dy_lo . x_hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[n], acc[t], 0, 0, 0);           // dy_hi . x_lo
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[n - 1], acc[t], 0, 0, 0);       // dy_hi . x_hi
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 == NST) { st = 0; target += 4; } else ++st;
+    }
+
+    // =============================== write-out (wgrad_bf16_kernel's, tap-split form) ===============================
+    // accumulators -> LDS [tap][16 regs][64 lanes] -> LDS out tile [co][ci][tap] -> contiguous fp32 atomic adds (each co row of the tile
+    // is 32 * 16 consecutive floats of dW)
+    constexpr int KK = 16, NOUT = 32 * 32 * KK, PER_T = NOUT / 256;
+    float* red = reinterpret_cast<float*>(smem);
+    int phase = 0;
+    wx_sync4(ctl + WXC_SYNC, phase, lane);   // all four waves are finished reading the ring
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        const int slot = wave * KW + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(slot * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    wx_sync4(ctl + WXC_SYNC, phase, lane);
+    float sum[PER_T];
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q) {
+        const int e = tid + q * 256;                           // ci fastest: conflict-free reads
+        const int ci = e & 31, tap = (e >> 5) % KK, co = e / (32 * KK);
+        const int r = (co & 3) + 4 * (co >> 3), ln = ((co >> 2) & 1) * 32 + ci;
+        sum[q] = L.alpha * red[(tap * 16 + r) * 64 + ln];
+    }
+    wx_sync4(ctl + WXC_SYNC, phase, lane);   // every partial has been read
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q) {
+        const int e = tid + q * 256;
+        const int ci = e & 31, tap = (e >> 5) % KK, co = e / (32 * KK);
+        red[(co * 32 + ci) * KK + tap] = sum[q];
+    }
+    wx_sync4(ctl + WXC_SYNC, phase, lane);
+    float* __restrict__ dw = L.dw;
+    const int nci = min(32, L.Cin_w - it.ci0);
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q) {
+        const int e = tid + q * 256;                           // (co, ci * 16 + tap): contiguous in dW per co row
+        const int co = e / (32 * KK), rem = e - co * (32 * KK);
+        if (it.co0 + co < L.Cout && rem < nci * KK) atomicAdd(dw + ((size_t)(it.co0 + co) * L.Cin_w + it.ci0) * KK + rem, red[e]);
+    }
+}
+
 }  // namespace
 
 int ssr_wgrad_x3_dispatch(const ssr_wgrad_layer* layers, const ssr_wgrad_item* items, int n_items, int KH, int KW, int S,
                           hipStream_t st) {
+    if (KH == 4 && KW == 4 && S == 2) {                        // the discriminator's stride-2 layers (round 6)
+        static bool attr4_done[SSR_MAX_DEVICES] = {};
+        const int dev4 = ssr_device_ordinal();
+        if (!attr4_done[dev4]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_k4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wx4::LDS);
+            if (e != hipSuccess) return (int)e;
+            attr4_done[dev4] = true;
+        }
+        hipLaunchKernelGGL(wgrad_x3_k4_kernel, dim3(n_items), dim3(512), Wx4::LDS, st, layers, items);
+        SSR_LAUNCH_CHECK();
+        return SSR_OK;
+    }
     if (!(KH == 3 && KW == 3 && S == 1)) return SSR_EUNSUP;
     static bool attr_done[SSR_MAX_DEVICES] = {};      // the attribute is per DEVICE
     const int attr_dev = ssr_device_ordinal();

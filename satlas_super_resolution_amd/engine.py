@@ -525,8 +525,9 @@ class WgradBatch:
     hip.F32X3 (fp32 storage, split-bf16 matrix math; x = hi + lo to 2^-17, the dropped lo*lo term is 2^-16 relative):
     3x3 stride-1 layers: ONE launch of csrc/wgrad_x3.hip over the fp32 buffers - its loader waves split the tiles on the way
     into LDS and the three products (dy_lo.x_hi + dy_hi.x_lo + dy_hi.x_hi) go into one accumulator set (round 5; SSR_X3_WGRAD_FUSED=0
-    = the older form).  Other layers (4x4 stride 2): the bf16 transpose-read kernel runs three times over bf16 hi/lo planes of the
-    fp32 buffers, accumulated in the fp32 gradient arena, after one ssr_split_bf16_multi pass over the distinct parent buffers."""
+    = the older form); 4x4 stride-2 layers the same since round 6 (wgrad_x3_k4_kernel, 4 x 16-pixel tiles; SSR_X3_WGRAD_FUSED4=0 = the
+    older form: the bf16 transpose-read kernel three times over bf16 hi/lo planes of the fp32 buffers, accumulated in the fp32 gradient
+    arena, after one ssr_split_bf16_multi pass over the distinct parent buffers)."""
 
     # by kernel size: the 4x4 layers have few (co, ci) tiles -> more pixel splits (SSR_WGRAD_T3 / _T4: tuning hooks)
     MAX_TILES_PER_ITEM = {3: int(os.environ.get("SSR_WGRAD_T3", "128")), 4: int(os.environ.get("SSR_WGRAD_T4", "64"))}
@@ -535,7 +536,8 @@ class WgradBatch:
         self.dtype, self.k, self.stride = dtype, k, stride
         self.force_atomic = force_atomic       # another launch accumulates into the same gradients concurrently
         # element type the wgrad kernel reads: bf16 planes of the fp32 buffers in the split passes, the fp32 buffers themselves in the fused 3x3 kernel
-        fused = dtype == hip.F32X3 and k == 3 and stride == 1 and os.environ.get("SSR_X3_WGRAD_FUSED", "1") == "1"
+        fused = dtype == hip.F32X3 and ((k == 3 and stride == 1 and os.environ.get("SSR_X3_WGRAD_FUSED", "1") == "1")
+                                        or (k == 4 and stride == 2 and os.environ.get("SSR_X3_WGRAD_FUSED4", "1") == "1"))
         self.kdt = hip.F32X3 if fused else hip.BF16 if dtype == hip.F32X3 else dtype
         self.layers: List[WgradLayer] = []
         self.items: List[WgradItem] = []

@@ -133,3 +133,76 @@ def test_agrees_with_three_pass_form():
     _, three, _ = _run(DENSE, 2, 32, 32, cbuf=192, fused=False)
     for (dw1, db1), (dw2, db2) in zip(fused, three):
         assert rel_err(dw1, dw2) < TOL and rel_err(db1, db2) < TOL
+
+
+# ---- 4x4 stride 2 (round 6, wgrad_x3_k4_kernel): the discriminator's conv1..conv3 (discriminator_arch.py:31-33) ----
+def _run4(layers, B, H, W, max_tiles=None, det=False, fused=True, with_bias=False):
+    """layers: list of (cin, cout, alpha), each with its own input buffer [B, H, W, cin] and output-gradient buffer [B, H/2, W/2, cout]"""
+    engine, hip = _mods()
+    old = os.environ.get("SSR_X3_WGRAD_FUSED4")
+    os.environ["SSR_X3_WGRAD_FUSED4"] = "1" if fused else "0"
+    try:
+        torch.manual_seed(B * 1000 + H * 10 + len(layers) + 4)
+        wb = engine.WgradBatch(hip.F32X3, 4, 2, det=det)
+        assert (wb.kdt == hip.F32X3) == fused
+        if max_tiles:
+            wb.MAX_TILES_PER_ITEM = {4: max_tiles}
+        Ho, Wo = (H + 2 - 4) // 2 + 1, (W + 2 - 4) // 2 + 1
+        keep, got, ref = [], [], []
+        for cin, cout, alpha in layers:
+            cinp, coutp = engine.rup(cin, 8), engine.rup(cout, 8)
+            x = (torch.randn(B, H, W, cinp, device="cuda") * 0.5).contiguous()
+            x[..., cin:] = 0
+            dy = (torch.randn(B, Ho, Wo, coutp, device="cuda") * 0.25).contiguous()
+            dy[..., cout:] = 0
+            dw = torch.zeros(cout, cin, 4, 4, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            wb.add(hip.view(x), hip.view(dy), B, H, W, 1, cinp, cout, Ho, Wo, alpha, dw.data_ptr(), cin, db.data_ptr() if with_bias else None)
+            keep.append((x, dy, dw, db))
+            xi = x.double().cpu().permute(0, 3, 1, 2)[:, :cin]
+            w = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
+            b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+            (F.conv2d(xi, w, b, stride=2, padding=1) * dy.double().cpu().permute(0, 3, 1, 2)[:, :cout]).sum().backward()
+            ref.append((alpha * w.grad, alpha * b.grad))
+        wb.finalize()
+        L = engine.Launcher()
+        wb.launch(L)
+        L.run()
+        torch.cuda.synchronize()
+        return wb, [(dw.double().cpu(), db.double().cpu()) for _, _, dw, db in keep], ref
+    finally:
+        if old is None:
+            os.environ.pop("SSR_X3_WGRAD_FUSED4", None)
+        else:
+            os.environ["SSR_X3_WGRAD_FUSED4"] = old
+
+
+@pytest.mark.parametrize("layers,B,H,W", [
+    ([(64, 128, 1.0)], 2, 32, 32),               # conv1's shape class
+    ([(128, 256, 0.5), (64, 128, 1.0)], 1, 24, 40),   # two layers of different grids cannot share a batch: same grid here, ragged tiles (12 x 20)
+    ([(256, 512, 1.0)], 2, 16, 16),              # conv3: many (co, ci) tiles, a single 4-row tile band per image row pair
+    ([(16, 24, 1.0)], 3, 10, 14),                # half-filled channel tiles, 5 x 7 outputs
+    ([(40, 72, 1.0)], 1, 66, 34),                # 33 x 17 outputs: ragged in both directions, three output-channel blocks
+])
+def test_stride2_4x4_layers_one_pass(layers, B, H, W):
+    wb, got, ref = _run4(layers, B, H, W)
+    _check(got, ref, with_bias=False)
+
+
+def test_stride2_4x4_pixel_splits_bias_and_deterministic_mode():
+    wb, got, ref = _run4([(64, 128, 1.0)], 4, 32, 32, max_tiles=3, with_bias=True)
+    assert max(it.atomic for it in wb.items) == 1 and len(wb.items) > 16
+    _check(got, ref, with_bias=True)
+    a = _run4([(64, 64, 1.0)], 4, 32, 32, max_tiles=4, det=True, with_bias=True)
+    b = _run4([(64, 64, 1.0)], 4, 32, 32, max_tiles=4, det=True, with_bias=True)
+    assert a[0].partial is not None
+    _check(a[1], a[2], with_bias=True)
+    for (dw1, db1), (dw2, db2) in zip(a[1], b[1]):
+        assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+def test_stride2_4x4_agrees_with_three_pass_form():
+    _, fused, ref = _run4([(128, 256, 1.0)], 2, 32, 32)
+    _, three, _ = _run4([(128, 256, 1.0)], 2, 32, 32, fused=False)
+    for (dw1, _), (dw2, _) in zip(fused, three):
+        assert rel_err(dw1, dw2) < TOL

@@ -324,20 +324,29 @@ def test_wgrad_items_are_paired_without_losing_or_duplicating_work():
     assert wb._makespan(wb._balance(paired)) <= wb._makespan(paired)
 
 
-def test_wgrad_batches_of_the_split_mode_pick_the_one_pass_kernel_for_3x3_layers_only(monkeypatch):
+def test_wgrad_batches_of_the_split_mode_pick_the_one_pass_kernels(monkeypatch):
     """engine.WgradBatch in the fp32x3 mode: 3x3 stride-1 layers read the fp32 buffers themselves (csrc/wgrad_x3.hip: 8 x 16-pixel
-    tiles, paired 64-channel items, as many pixels per item as the bf16 kernel's), 4x4 stride-2 layers keep the split pass + three
-    bf16 launches, SSR_X3_WGRAD_FUSED=0 restores the older form everywhere; the pairing rules are the bf16 kernel's."""
+    tiles, paired 64-channel items, as many pixels per item as the bf16 kernel's), and since round 6 the 4x4 stride-2 layers too (4 x 16-pixel
+    tiles, 32 x 32-channel items); SSR_X3_WGRAD_FUSED=0 / SSR_X3_WGRAD_FUSED4=0 restore the split pass + three bf16 launches; the pairing rules
+    are the bf16 kernel's."""
     from satlas_super_resolution_amd import engine, hip
     V = hip.View
     monkeypatch.delenv("SSR_X3_WGRAD_FUSED", raising=False)
+    monkeypatch.delenv("SSR_X3_WGRAD_FUSED4", raising=False)
     wb = engine.WgradBatch(hip.F32X3, 3, 1)
     assert wb.kdt == hip.F32X3
-    assert engine.WgradBatch(hip.F32X3, 4, 2).kdt == hip.BF16 and engine.WgradBatch(hip.BF16, 3, 1).kdt == hip.BF16
+    assert engine.WgradBatch(hip.F32X3, 4, 2).kdt == hip.F32X3 and engine.WgradBatch(hip.BF16, 3, 1).kdt == hip.BF16
     assert engine.WgradBatch(hip.F32, 3, 1).kdt == hip.F32
     monkeypatch.setenv("SSR_X3_WGRAD_FUSED", "0")
-    assert engine.WgradBatch(hip.F32X3, 3, 1).kdt == hip.BF16
+    monkeypatch.setenv("SSR_X3_WGRAD_FUSED4", "0")
+    assert engine.WgradBatch(hip.F32X3, 3, 1).kdt == hip.BF16 and engine.WgradBatch(hip.F32X3, 4, 2).kdt == hip.BF16
     monkeypatch.delenv("SSR_X3_WGRAD_FUSED")
+    monkeypatch.delenv("SSR_X3_WGRAD_FUSED4")
+    w4 = engine.WgradBatch(hip.F32X3, 4, 2)                       # D conv2 at B = 32: 128 -> 256 channels, 64 x 64 -> 32 x 32
+    w4.add(V(0x10000000, 128, 0), V(0x20000000, 256, 0), 32, 64, 64, 1, 128, 256, 32, 32, 1.0, 0x9000, 128, None)
+    assert hip.lib().ssr_wgrad_tiles(32, 32, 32, w4.kdt, 4) == 32 * 8 * 2 and hip.lib().ssr_wgrad_tiles(32, 32, 32, hip.BF16, 4) == 32 * 4 * 2
+    assert hip.lib().ssr_wgrad_ci_tile(w4.kdt, 4) == 32 and len({(it.co0, it.ci0) for it in w4.items}) == 8 * 4
+    assert all(it.tile_end - it.tile_begin == 128 for it in w4.items)            # 128 tiles of 4 x 16 pixels: the bf16 kernel's 64 of 8 x 16
     base = 0x10000000
     for k in range(5):                                            # one dense block at B = 16 (a half-batch chain of the step)
         cin, cout = 64 + 32 * k, (64 if k == 4 else 32)

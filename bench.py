@@ -139,7 +139,8 @@ def instrumented_step(ts, args, dtype=None):
                 fl = 2.0 * RDB_MACS * d.N * d.H * d.W
             elif name == "ssr_conv2d_wgrad":
                 wdt = "fp32x3" if dtype in ("fp32f", "fp32h") else dtype          # fp32f / fp32h: the backward is the split-bf16 mode's
-                sym = {("fp32x3", 3): "wgrad_x3_k3_kernel", ("bf16", 3): "wgrad_bf16_k3_kernel", ("fp32x3", 4): "wgrad_bf16_kernel<4, 4, 2, true> x3 (split passes)",
+                k4 = "wgrad_x3_k4_kernel" if os.environ.get("SSR_X3_WGRAD_FUSED4", "1") == "1" else "wgrad_bf16_kernel<4, 4, 2, true> x3 (split passes)"
+                sym = {("fp32x3", 3): "wgrad_x3_k3_kernel", ("bf16", 3): "wgrad_bf16_k3_kernel", ("fp32x3", 4): k4,
                        ("bf16", 4): "wgrad_bf16_kernel<4, 4, 2, false>"}.get((wdt, a[4]), f"wgrad_kernel<{wdt},K{a[4]}>")
                 fl = WGRAD_FLOPS.get(a[0], 0.0)
             # one event pair per RUN of consecutive launches of the same kernel symbol (the 69 dense blocks of the forward chain are

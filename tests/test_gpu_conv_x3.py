@@ -543,3 +543,31 @@ def test_regtile_x3_is_the_automatic_choice_for_the_body(monkeypatch):
     buf = torch.zeros(32, 32, 32, 192, device="cuda")
     d = cb.conv(L, "b", hip.view(buf, 0), 32, 32, hip.view(buf, 160), act=hip.ACT_LRELU, cin=160)
     assert hip.lib().ssr_conv2d_variant(C.byref(d)) % 10 == 5            # digit 5 = csrc/conv_x3r.hip (6 = the ring kernel it replaced)
+
+
+def test_fp16_split_overflow_is_loud_not_wrong():
+    """the documented range of the mode (include/ssr_hip.h, SSR_F32H): an activation beyond fp16's 65504 - or a weight beyond 65504 / 2^10 - becomes
+    inf in its hi piece and the outputs that touch it come out non-finite; nothing is silently clamped.  (Inside the range: the tests above.)"""
+    engine, hip = _mods()
+    torch.manual_seed(3)
+    cin, cout, H, W, B = 64, 32, 16, 16, 1
+    for big_x, big_w in ((True, False), (False, True)):
+        st = engine.ParamStore([engine.ConvSpec("c", cout, cin, 3, 1, True, False)], hip.dtype_code("fp32h"))
+        w = torch.randn(cout, cin, 3, 3) * 0.05
+        if big_w:
+            w[5, 7, 1, 1] = 100.0                                   # 100 x 2^10 > 65504
+        st.load_state_dict({"c.weight": w, "c.bias": torch.zeros(cout)})
+        st.pack()
+        xb = (torch.randn(B, H, W, cin, device="cuda") * 0.5).contiguous()
+        if big_x:
+            xb[0, 8, 8, 3] = 1.0e5
+        y = torch.zeros(B, H, W, cout, device="cuda")
+        d = engine._ConvBuilder(st, B).conv(engine.Launcher(), "c", hip.view(xb), H, W, hip.view(y), cin=cin)
+        hip.check(hip.lib().ssr_conv2d(C.byref(d), hip.stream_ptr()), "ssr_conv2d")
+        torch.cuda.synchronize()
+        bad = ~torch.isfinite(y)
+        assert bad.any(), (big_x, big_w)
+        if big_x:       # exactly the 3 x 3 neighbourhood of the pixel, every output channel; everything else is untouched by it
+            assert bad[0, 7:10, 7:10, :].all() and int(bad.sum()) == 9 * cout
+        else:           # the one output channel whose weight overflowed
+            assert bad[..., 5].any() and not bad[..., :5].any() and not bad[..., 6:].any()

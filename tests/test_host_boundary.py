@@ -383,3 +383,32 @@ def test_arithmetic_mode_codes_split_into_storage_and_forward_codes():
     for dt in (hip.F32X3, hip.F32H3, hip.dtype_code("fp32h")):
         assert {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=(128, 128), dtype=dt) if s.k == 4}["conv3"] is None
     assert {s.name: s.s2d for s in engine.discriminator_specs(3, 64, in_hw=(128, 128), dtype=hip.F32) if s.k == 4}["conv3"] is False
+
+
+def test_wgrad_hybrid_item_order_is_a_cost_sorted_permutation_with_buffer_groups_on_one_xcd(monkeypatch):
+    """engine.WgradBatch, SSR_WGRAD_ORDER=hybrid: the items of a launch stay sorted by cost (list scheduling), and inside a run of equal cost the items
+    that read one buffer over the same tiles sit on ONE XCD (block index % 8), next to each other in its queue"""
+    from satlas_super_resolution_amd import engine, hip
+    V = hip.View
+    monkeypatch.setattr(engine, "_device_cus", lambda: (256, 8))
+    monkeypatch.setenv("SSR_WGRAD_ORDER", "hybrid")
+    wb = engine.WgradBatch(hip.F32X3, 3, 1)
+    for blk in range(24):                                         # 24 dense blocks at B = 16, each over its own 192-channel buffer
+        base = 0x10000000 + blk * 0x4000000
+        for k in range(5):
+            cin, cout = 64 + 32 * k, (64 if k == 4 else 32)
+            dy = V(base + 0x1000000, 192, 64 + 32 * k) if k < 4 else V(base + 0x2000000, 192, 0)
+            wb.add(V(base, 192, 0), dy, 16, 32, 32, 1, cin, cout, 32, 32, 1.0, 0x5000 + 64 * (5 * blk + k), cin, 0x6000)
+    ref = wb._pair(list(wb.items))
+    key = lambda it: (it.layer, it.co0, it.ci0, it.tile_begin, it.tile_end, it.nco, it.layer_b, it.co0_b)
+    got = wb._cost_xcd_order(ref)
+    assert sorted(map(key, got)) == sorted(map(key, ref))                                   # a permutation
+    costs = [wb._cost(it) for it in got]
+    assert costs == sorted(costs, reverse=True)                                             # longest first
+    same_xcd = 0
+    groups = {}
+    for pos, it in enumerate(got):
+        groups.setdefault((wb._cost(it), wb.layers[it.layer].x.p), []).append(pos % 8)
+    for xs in groups.values():
+        same_xcd += len(set(xs)) == 1
+    assert same_xcd >= 0.9 * len(groups), (same_xcd, len(groups))                           # (the last groups of a run fill the short queues)

@@ -473,3 +473,44 @@ def test_model_plugin_against_the_unmodified_reference_method(tmp_path, name):
         assert rel_err(tgt, fx["gt_usm_last"]) < 1e-5, rel_err(tgt, fx["gt_usm_last"])
     m.test()                                      # :235-244: net_g_ema under no_grad on the last batch
     assert parity_close(m.output.cpu(), fx["test_output"]), rel_err(m.output.cpu(), fx["test_output"])
+
+
+@pytest.mark.parametrize("name", ["stepref_plain", "stepref_feedlr_oldhr"])
+def test_model_plugin_in_its_default_arithmetic_against_the_unmodified_reference_method(tmp_path, name):
+    """The same fixtures (executions of the unmodified SSRESRGANModel methods, oracle/make_golden_refstep.py) with the plugin left at its DEFAULT
+    arithmetic - fp32h since round 6 (fp16-split forward, split-bf16 backward): the logged losses at 1e-3, the test() output at the gate, and the
+    post-step parameters on the update with the noise-robust criterion (Adam turns a gradient at rounding level into a +-lr step in ANY fp32
+    implementation: at most 0.1 % of a tensor's elements outside the tight bound, none by more than the maximal Adam step)."""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden(name)
+    opt = _opt(tmp_path, fx, feed_disc_lr=bool(fx["opt"].get("feed_disc_lr", False)), l1_gt_usm=bool(fx["opt"].get("l1_gt_usm", False)),
+               gan_gt_usm=bool(fx["opt"].get("gan_gt_usm", False)))
+    del opt["compute_dtype"]                                      # the plugin's own default
+    opt["train"].update({"ema_decay": fx["ema_decay"], "net_d_iters": fx["net_d_iters"], "net_d_init_iters": fx["net_d_init_iters"],
+                         "optim_d": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])},
+                         "optim_g": {"type": "Adam", "lr": fx["lr"], "weight_decay": 0, "betas": list(fx["betas"])}})
+    opt["train"].pop("scheduler", None)
+    torch.save({"params": fx["g0"], "params_ema": fx["g0"]}, tmp_path / "g0.pth")
+    torch.save({"params": fx["d0"]}, tmp_path / "d0.pth")
+    opt["path"].update({"pretrain_network_g": str(tmp_path / "g0.pth"), "pretrain_network_d": str(tmp_path / "d0.pth"),
+                        "param_key_g": "params", "strict_load_g": True})
+    m = build_model(opt)
+    assert m.compute_dtype == "fp32h"
+    for it, batch in enumerate(fx["data"], start=1):
+        m.feed_data(batch)
+        m.optimize_parameters(it)
+        log, ref = m.get_current_log(), fx["logs"][it - 1]
+        for k, v in ref.items():
+            assert abs(log[k] - v) <= 1e-3 * max(1.0, abs(v)), (it, k, log[k], v)
+    steps = fx["lr"] * len(fx["data"])
+    for k, v in fx["g_final"].items():
+        _close_update(m.ts.g_store.tensor(k).cpu(), v, fx["g0"][k], ("G", k), 5e-2, steps)
+    sd_d = m.ts.d_store.state_dict()
+    for k, v in fx["d_final"].items():
+        if k.endswith("_u") or k.endswith("_v"):
+            assert rel_err(sd_d[k].cpu(), v) < 1e-3, ("D buffer", k)
+        else:
+            _close_update(sd_d[k].cpu(), v, fx["d0"][k], ("D", k), 5e-2, steps)
+    m.test()
+    assert parity_close(m.output.cpu(), fx["test_output"]), rel_err(m.output.cpu(), fx["test_output"])

@@ -162,7 +162,8 @@ extern "C" int32_t ssr_wgrad_tiles(int32_t N, int32_t Gh, int32_t Gw, int32_t dt
 
 // width of the input-channel tile of one work item (host helper for building items)
 extern "C" int32_t ssr_wgrad_ci_tile(int32_t dtype, int32_t KH) { return ((dtype == SSR_BF16 || dtype == SSR_F32X3) && KH == 3) ? 64 : 32; }
-extern "C" int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH) { return ((dtype == SSR_BF16 || dtype == SSR_F32X3) && KH == 3) ? 64 : 32; }
+// 64: the kernel takes PAIRED items (two 32-channel blocks of dY against one input patch): the 3x3 kernels, and since round 6 the one-pass 4x4 stride-2 kernel of the split mode
+extern "C" int32_t ssr_wgrad_co_tile(int32_t dtype, int32_t KH) { return (((dtype == SSR_BF16 || dtype == SSR_F32X3) && KH == 3) || (dtype == SSR_F32X3 && KH == 4)) ? 64 : 32; }
 
 extern "C" int ssr_conv2d_wgrad(const ssr_wgrad_layer* layers_dev, const ssr_wgrad_item* items_dev, int32_t n_items,
                                 int32_t dtype, int32_t KH, int32_t KW, int32_t stride, void* stream) {

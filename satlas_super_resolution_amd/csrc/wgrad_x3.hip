@@ -380,37 +380,84 @@ __global__ __launch_bounds__(512) void wgrad_x3_k3_kernel(const ssr_wgrad_layer*
 
 // ------------------------------------------------------------------------------------------------------------------
 // 4x4 stride 2 (the discriminator's conv1..conv3, discriminator_arch.py:31-33), round 6: the same one-pass idea on the GENERIC kernel's
-// work decomposition (wgrad_bf16.hip, wgrad_bf16_kernel<4, 4, 2, true>: 32 co x 32 ci per workgroup, MFMA wave w owns tap row ky = w
-// with four accumulators kx = 0..3).  Until now these layers took ssr_split_bf16_multi over their buffers and three launches of the bf16
-// kernel over the planes (1.1 + 0.2 ms per step, six write-outs per item).  Here the loader waves read the fp32 tiles (8 channels of a
-// pixel = two 16-byte loads), split them on the way into LDS (hi plane, lo plane) and the MFMA waves issue the three products of every
-// (dY, X) fragment pair into ONE accumulator set: per k-step (one tile row of 16 output pixels) 2 dY + 8 X fragment reads for 12 MFMAs
-// (the three bf16 passes: 15 reads for 12 MFMAs).  A stage holds hi AND lo planes, so the pixel tile is 4 x 16 instead of 8 x 16:
-//   stage = dY hi, lo [64 px][32 co] + X hi, lo [10 x 34 px][32 ci] bf16 = 51,712 B; three stages + the control words = 155,648 B.
+// work decomposition (wgrad_bf16.hip, wgrad_bf16_kernel<4, 4, 2, true>: MFMA wave w owns tap row ky = w with four accumulators kx = 0..3
+// per dY plane).  Until now these layers took ssr_split_bf16_multi over their buffers and three launches of the bf16 kernel over the planes
+// (1.1 + 0.2 ms per step, six write-outs per item).  Here the loader waves read the fp32 tiles (8 channels of a pixel = two 16-byte
+// loads), split them on the way into LDS (hi plane, lo plane) and the MFMA waves issue the three products of every (dY, X) fragment pair
+// into ONE accumulator set.  The X patch of a stride-2 layer is 5.3 input pixels per output pixel (10 x 34 for a 4 x 16 tile): a PAIRED
+// item contracts TWO 32-channel blocks of dY (it.co0, it.co0_b; the engine pairs the blocks of one layer) with the same patch - per
+// k-step (one tile row of 16 output pixels) 4 dY + 8 X fragment reads for 24 MFMAs (the first cut, one block per item, was loader-bound:
+// 51 KB of fp32 per tile for 48 MFMAs per wave, 0.27 MFMA-busy).  A stage holds hi AND lo planes, so the pixel tile is 4 x 16:
+//   stage = dY A hi, A lo, B hi, B lo [64 px][32 co] + X hi, lo [10 x 34 px][32 ci] bf16 = 59,904 B; two stages + the control words = 120,320 B.
 struct Wx4 {
     static constexpr int TH = 4, S = 2, KH = 4, KW = 4, PH = (TH - 1) * S + KH, PW = (WG_TW - 1) * S + KW, ROW = 32;   // patch 10 x 34
     static constexpr int DYP = TH * WG_TW * 64;              // bytes of one dY plane [64 px][32 co] bf16
     static constexpr int XP = PH * PW * 64;                  // bytes of one X plane [340 px][32 ci] bf16
-    static constexpr int XBASE = 2 * DYP;
-    static constexpr int STAGE = 2 * DYP + 2 * XP;           // 51,712 B
-    static constexpr int NDYU = TH * WG_TW * 4;              // loader units (8 fp32 channels of a pixel = 32 B): 256 of dY
+    static constexpr int XBASE = 4 * DYP;
+    static constexpr int STAGE = 4 * DYP + 2 * XP;           // 59,904 B
+    static constexpr int NDYU = TH * WG_TW * 4;              // loader units (8 fp32 channels of a pixel = 32 B): 256 per dY plane
     static constexpr int NXU = PH * PW * 4;                  // 1360 of X
-    static constexpr int NLU = (NDYU + NXU + 255) / 256;     // 7 per loader thread: unit 0 is a dY unit, units 1..6 are X units
-    static constexpr int NST = 3;
+    static constexpr int NLU = 2 + (NXU + 255) / 256;        // 8 per loader thread: unit 0 / 1 = dY plane A / B, units 2..7 are X units
+    static constexpr int NST = 2;
     static constexpr int CTL = NST * STAGE;
     static constexpr int LDS = CTL + 512;
-    static_assert(NDYU == 256 && NLU == 7, "operand lists of wait_tile / hold");
+    static_assert(NDYU == 256 && NLU == 8, "operand lists of wait_tile / hold");
     static_assert(LDS <= 160 * 1024 && 32 * 32 * 16 * 4 <= CTL, "LDS budget / write-out tile fits in the ring");
 };
+
+// one MFMA wave's share of a tile: tap row ky = wave, the four taps kx, NP dY planes (1: single item, 2: paired)
+template <int NP>
+__device__ __forceinline__ void wx4_rows(f32x16 (&acc)[2][4], const __bf16* ldy, const __bf16* lx, int* done_word, int k, int wave, int lane,
+                                         int src_px, int src_ch) {
+    using C = Wx4;
+    constexpr int TH = C::TH, S = C::S, KW = C::KW, PW = C::PW, ROW = C::ROW;
+    constexpr int DYLO = C::DYP / 2, XLO = C::XP / 2;         // bf16 elements between a hi plane and its lo plane
+    // operand stream: per k-step s (tile row) the dY fragments (plane A hi, lo[, plane B hi, lo]), then (X hi, X lo) of the four taps
+    constexpr int NDY = 2 * NP, PER = NDY + 2 * KW, NOP = TH * PER, PF = 8;
+    bf16x8 op[NOP];
+    auto issue = [&](auto nc) {
+        constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
+        if constexpr (r < NDY) {
+            const __bf16* ap = ldy + r * DYLO + (s * WG_TW + src_px) * ROW + src_ch;      // planes lie A hi, A lo, B hi, B lo
+            op[n] = wx_tr_pair(ap, ap + 4 * ROW);
+        } else {
+            constexpr int t = (r - NDY) >> 1, lo = (r - NDY) & 1;
+            const __bf16* bp = lx + lo * XLO + ((s * S + wave) * PW + src_px * S + t) * ROW + src_ch;
+            op[n] = wx_tr_pair(bp, bp + 4 * S * ROW);
+        }
+    };
+    static_for<0, PF>([&](auto nc) { issue(nc); });
+    static_for<0, NOP>([&](auto nc) {
+        constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
+        if constexpr (n + PF == NOP - 1) {
+            if (lane == 0) __atomic_store_n(done_word, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (r >= NDY && ((r - NDY) & 1) == 1) {      // the lo fragment of tap t has arrived: its three products per plane
+            constexpr int t = (r - NDY) >> 1, a = s * PER;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 2 * p + 1], op[n - 1], acc[p][t], 0, 0, 0);   // dy_lo . x_hi
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 2 * p], op[n], acc[p][t], 0, 0, 0);           // dy_hi . x_lo
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 2 * p], op[n - 1], acc[p][t], 0, 0, 0);       // dy_hi . x_hi
+            }
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer* __restrict__ layers,
                                                           const ssr_wgrad_item* __restrict__ items) {
     using C = Wx4;
-    constexpr int TH = C::TH, S = C::S, KW = C::KW, PW = C::PW, ROW = C::ROW, NST = C::NST, NLU = C::NLU;
+    constexpr int TH = C::TH, S = C::S, KW = C::KW, PW = C::PW, NST = C::NST, NLU = C::NLU;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* ctl = reinterpret_cast<int*>(smem + C::CTL);
     const ssr_wgrad_item it = items[blockIdx.x];
+    const bool pair = it.nco == 2;
     const ssr_wgrad_layer L = layers[it.layer];
+    const ssr_wgrad_layer LB = layers[pair ? it.layer_b : it.layer];   // layer of the second dY plane (the engine pairs blocks of ONE layer; any layer over the same x works)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (L.Gw + WG_TW - 1) / WG_TW, tiles_y = (L.Gh + TH - 1) / TH;
     const int ntile = it.tile_end - it.tile_begin;
@@ -419,7 +466,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
 
     if (wave >= 4) {
         // =============================== loader waves ===============================
-        // unit u = lt + 256 q: q = 0: dY pixel lt >> 2 of the tile, channel octet lt & 3; q >= 1: X patch pixel (lt + 256 (q - 1)) >> 2, octet lt & 3
+        // unit q of a thread: q = 0 / 1: dY pixel lt >> 2 of the tile in plane A / B, channel octet lt & 3; q >= 2: X patch pixel (lt + 256 (q - 2)) >> 2, octet lt & 3
         const int lt = tid - 256;
         const int upshift = L.up == 2 ? 1 : 0;
         const int LH = L.Hi << upshift, LW = L.Wi << upshift;
@@ -427,11 +474,12 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
         int yx[NLU];                                           // (y, x) relative to the tile / patch origin; 0x7fff7fff = never inside
 #pragma unroll
         for (int q = 0; q < NLU; ++q) {
-            if (q == 0) {
+            if (q < 2) {
                 const int pix = lt >> 2;
-                yx[q] = (it.co0 + oct * 8 < L.Cout) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x7fff7fff;
+                const bool ok = q == 0 ? it.co0 + oct * 8 < L.Cout : (pair && it.co0_b + oct * 8 < LB.Cout);
+                yx[q] = ok ? ((pix >> 4) | ((pix & 15) << 16)) : 0x7fff7fff;
             } else {
-                const int vx = lt + (q - 1) * 256;
+                const int vx = lt + (q - 2) * 256;
                 const int pix = vx >> 2;
                 const int py = pix / PW, px = pix - py * PW;
                 const int y = py - L.pad_y, x = px - L.pad_x;
@@ -440,11 +488,12 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
         }
         const int lo_dy = (lt >> 2) * 64 + oct * 16;
         const int lo_x = C::XBASE + (lt >> 2) * 64 + oct * 16;
-        const bool do_bias = L.db != nullptr && it.ci0 == 0;
-        float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool bias_a = L.db != nullptr && it.ci0 == 0, bias_b = pair && LB.db != nullptr && it.ci0 == 0;
+        float bacc[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
         u32x4 ra[2 * NLU], rb[2 * NLU];
         const wx_gptr zero32 = (wx_gptr)&g_wx_zero32[0];
-        const wx_gptr dyg1 = (wx_gptr)(reinterpret_cast<const float*>(L.dy.p) + L.dy.coff + it.co0);
+        const wx_gptr dyga = (wx_gptr)(reinterpret_cast<const float*>(L.dy.p) + L.dy.coff + it.co0);
+        const wx_gptr dygb = (wx_gptr)(reinterpret_cast<const float*>(LB.dy.p) + LB.dy.coff + it.co0_b);
         const wx_gptr xg1 = (wx_gptr)(reinterpret_cast<const float*>(L.x.p) + L.x.coff + it.ci0);
         auto load_tile = [&](int k, u32x4 (&r)[2 * NLU]) {
             int b = it.tile_begin + k;
@@ -452,7 +501,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
             const int ty_i = b % tiles_y;
             const int n = b / tiles_y;
             const int gy0 = ty_i * TH, gx0 = tx_i * WG_TW;
-            const wx_gptr dyb = dyg1 + ((size_t)(n * L.Gh + gy0) * L.Gw + gx0) * L.dy.cs * 4;
+            const size_t pix0 = (size_t)(n * L.Gh + gy0) * L.Gw + gx0;
+            const wx_gptr dyba = dyga + pix0 * L.dy.cs * 4, dybb = dygb + pix0 * LB.dy.cs * 4;
             const wx_gptr xb = xg1 + ((size_t)(n * L.Hi + ((gy0 * S) >> upshift)) * L.Wi + ((gx0 * S) >> upshift)) * L.x.cs * 4;
 #pragma unroll
             for (int q = 0; q < NLU; ++q) {
@@ -460,7 +510,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
                 asm volatile("" : "+v"(yxq));                  // keeps the offsets below from being hoisted into more registers
                 const int y = (int)(short)(yxq & 0xffff), x = yxq >> 16;
                 wx_gptr src;
-                if (q == 0) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyb + ((y * L.Gw + x) * L.dy.cs + oct * 8) * 4 : zero32;
+                if (q == 0) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dyba + ((y * L.Gw + x) * L.dy.cs + oct * 8) * 4 : zero32;
+                else if (q == 1) src = (gy0 + y < L.Gh && gx0 + x < L.Gw) ? dybb + ((y * L.Gw + x) * LB.dy.cs + oct * 8) * 4 : zero32;
                 else src = ((unsigned)(gy0 * S + y) < (unsigned)LH && (unsigned)(gx0 * S + x) < (unsigned)LW)
                                ? xb + (((y >> upshift) * L.Wi + (x >> upshift)) * L.x.cs + oct * 8) * 4 : zero32;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[2 * q]) : "v"(src) : "memory");
@@ -468,12 +519,12 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
             }
         };
         auto pass = [&](u32x4 (&r)[2 * NLU]) {
-            asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) :: "memory");
-            asm volatile("" : "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]) :: "memory");
+            asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
+            asm volatile("" : "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) :: "memory");
         };
         auto wait_tile = [&](u32x4 (&r)[2 * NLU]) {            // every load older than the newest 2 NLU has landed
             pass(r);
-            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             pass(r);
         };
         auto put = [&](int k, int st, u32x4 (&r)[2 * NLU]) {
@@ -497,19 +548,21 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
                     h[4 + e] = (__bf16)v1[e];
                     l[4 + e] = (__bf16)(v1[e] - (float)h[4 + e]);
                 }
-                if (q == 0) {
-                    *reinterpret_cast<u32x4*>(base + lo_dy) = __builtin_bit_cast(u32x4, h);
-                    *reinterpret_cast<u32x4*>(base + lo_dy + C::DYP) = __builtin_bit_cast(u32x4, l);
-                    if (do_bias) {
+                if (q < 2) {
+                    if (q == 0 || pair) {
+                        *reinterpret_cast<u32x4*>(base + q * 2 * C::DYP + lo_dy) = __builtin_bit_cast(u32x4, h);
+                        *reinterpret_cast<u32x4*>(base + q * 2 * C::DYP + C::DYP + lo_dy) = __builtin_bit_cast(u32x4, l);
+                    }
+                    if (q == 0 ? bias_a : bias_b) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            bacc[e] += v0[e];
-                            bacc[4 + e] += v1[e];
+                            bacc[q][e] += v0[e];
+                            bacc[q][4 + e] += v1[e];
                         }
                     }
-                } else if (lt + (q - 1) * 256 < C::NXU) {
-                    *reinterpret_cast<u32x4*>(base + lo_x + (q - 1) * 4096) = __builtin_bit_cast(u32x4, h);
-                    *reinterpret_cast<u32x4*>(base + lo_x + C::XP + (q - 1) * 4096) = __builtin_bit_cast(u32x4, l);
+                } else if (lt + (q - 2) * 256 < C::NXU) {
+                    *reinterpret_cast<u32x4*>(base + lo_x + (q - 2) * 4096) = __builtin_bit_cast(u32x4, h);
+                    *reinterpret_cast<u32x4*>(base + lo_x + C::XP + (q - 2) * 4096) = __builtin_bit_cast(u32x4, l);
                 }
             }
             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((int)(C::CTL + 4 * (WXC_READY + st))), "v"(1) : "memory");
@@ -520,133 +573,112 @@ __global__ __launch_bounds__(512) void wgrad_x3_k4_kernel(const ssr_wgrad_layer*
             load_tile(0, ra);
             load_tile(min(1, last), rb);
         }
-        int st = 0, k = 0;
-        for (; k + 1 < ntile; k += 2) {
-            put(k, st, ra);
-            st = st + 1 == NST ? 0 : st + 1;
+        int k = 0;
+        for (; k + 1 < ntile; k += 2) {                        // even tiles -> stage 0 from ra, odd tiles -> stage 1 from rb
+            put(k, 0, ra);
             load_tile(min(k + 2, last), ra);
-            put(k + 1, st, rb);
-            st = st + 1 == NST ? 0 : st + 1;
+            put(k + 1, 1, rb);
             load_tile(min(k + 3, last), rb);
         }
-        if (k < ntile) put(k, st, ra);
+        if (k < ntile) put(k, 0, ra);
         if (ntile > 0) {                                       // the loads past the end: their registers stay allocated until they have landed
             pass(ra); pass(rb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pass(ra); pass(rb);
         }
-        if (do_bias) {
-            // 64 threads share each channel octet (lane & 3): xor-shuffle tree over the 16 lanes of a wave that hold the octet, then the
-            // four loader waves in turn, then one global add per channel (fixed order)
+        if (bias_a || bias_b) {
+            // 64 threads share each channel octet (lane & 3) of a plane: xor-shuffle tree over the 16 lanes of a wave that hold the octet, then
+            // the four loader waves in turn, then one global add per channel (fixed order)
             volatile float* bl = reinterpret_cast<volatile float*>(ctl + WXC_BIAS);
 #pragma unroll
-            for (int m = 4; m < 64; m <<= 1)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bacc[e] += __shfl_xor(bacc[e], m);
+                for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bacc[p][e] += __shfl_xor(bacc[p][e], m);
             const int lw = lt >> 6;
             while (wx_ld(ctl + WXC_LSYNC) < lw) {}
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (lane < 4) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bl[lane * 8 + e] = lw == 0 ? bacc[e] : bl[lane * 8 + e] + bacc[e];
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bl[p * 32 + lane * 8 + e] = lw == 0 ? bacc[p][e] : bl[p * 32 + lane * 8 + e] + bacc[p][e];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __atomic_fetch_add(ctl + WXC_LSYNC, 1, __ATOMIC_RELAXED);
             while (wx_ld(ctl + WXC_LSYNC) < 4) {}
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lt < 32 && it.co0 + lt < L.Cout) atomicAdd(L.db + it.co0 + lt, L.alpha * bl[lt]);
+            if (lt < 64) {
+                const int h = lt >> 5, c = lt & 31;
+                const ssr_wgrad_layer& LC = h ? LB : L;
+                const int co = (h ? it.co0_b : it.co0) + c;
+                if ((h ? bias_b : bias_a) && co < LC.Cout) atomicAdd(LC.db + co, LC.alpha * bl[lt]);
+            }
         }
         return;
     }
 
-    // =============================== MFMA waves: tap row ky = wave, accumulators kx = 0..3 ===============================
+    // =============================== MFMA waves: tap row ky = wave, accumulators [dY plane][kx] ===============================
     const int g = lane >> 5;
     const int t16 = lane & 15;
     const int src_px = 8 * g + (t16 >> 2);                    // + 4 for the second read of the pair
     const int src_ch = 16 * ((lane >> 4) & 1) + 4 * (t16 & 3);
-    constexpr int DYLO = C::DYP / 2, XLO = C::XP / 2;         // bf16 elements between a hi plane and its lo plane
-    f32x16 acc[KW];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int t = 0; t < KW; ++t)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int st = 0, target = 4;                                    // stage of tile k and its ready target 4 * (uses + 1)
-    for (int k = 0; k < ntile; ++k) {
-        while (wx_ld(ctl + WXC_READY + st) < target) {}
-        const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
-        const __bf16* lx = ldy + C::XBASE / 2;
-        // operand stream of the tile: per k-step s (tile row) dY hi, dY lo, then (X hi, X lo) of the four taps; reads run PF operands ahead
-        constexpr int PER = 2 + 2 * KW, NOP = TH * PER, PF = 8;
-        bf16x8 op[NOP];
-        auto issue = [&](auto nc) {
-            constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
-            if constexpr (r < 2) {
-                const __bf16* ap = ldy + r * DYLO + (s * WG_TW + src_px) * ROW + src_ch;
-                op[n] = wx_tr_pair(ap, ap + 4 * ROW);
-            } else {
-                constexpr int t = (r - 2) >> 1, lo = (r - 2) & 1;
-                const __bf16* bp = lx + lo * XLO + ((s * S + wave) * PW + src_px * S + t) * ROW + src_ch;
-                op[n] = wx_tr_pair(bp, bp + 4 * S * ROW);
-            }
-        };
-        static_for<0, PF>([&](auto nc) { issue(nc); });
-        static_for<0, NOP>([&](auto nc) {
-            constexpr int n = decltype(nc)::value, s = n / PER, r = n % PER;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (n + PF < NOP) issue(std::integral_constant<int, n + PF>{});
-            if constexpr (n + PF == NOP - 1) {
-                if (lane == 0) __atomic_store_n(ctl + WXC_DONE + wave, k + 1, __ATOMIC_RELAXED);   // every read of the stage is issued
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (r >= 2 && ((r - 2) & 1) == 1) {      // the lo fragment of tap t has arrived: its three products
-                constexpr int t = (r - 2) >> 1, a = s * PER;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a + 1], op[n - 1], acc[t], 0, 0, 0);   // dy_lo . x_hi
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[n], acc[t], 0, 0, 0);           // dy_hi . x_lo
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[a], op[n - 1], acc[t], 0, 0, 0);       // dy_hi . x_hi
-            }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 == NST) { st = 0; target += 4; } else ++st;
-    }
+        for (int t = 0; t < KW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+    // one tile loop per instance (with the instances inside ONE loop the register allocator spills accumulators at every join)
+    auto run = [&](auto npc) {
+        int st = 0, target = 4;                                // stage of tile k and its ready target 4 * (uses + 1)
+        int* dw_ = ctl + WXC_DONE + wave;
+        for (int k = 0; k < ntile; ++k) {
+            while (wx_ld(ctl + WXC_READY + st) < target) {}
+            const __bf16* ldy = reinterpret_cast<const __bf16*>(smem + st * C::STAGE);
+            wx4_rows<decltype(npc)::value>(acc, ldy, ldy + C::XBASE / 2, dw_, k, wave, lane, src_px, src_ch);
+            if (st == 1) target += 4;
+            st ^= 1;
+        }
+    };
+    if (pair) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
 
-    // =============================== write-out (wgrad_bf16_kernel's, tap-split form) ===============================
-    // accumulators -> LDS [tap][16 regs][64 lanes] -> LDS out tile [co][ci][tap] -> contiguous fp32 atomic adds (each co row of the tile
-    // is 32 * 16 consecutive floats of dW)
-    constexpr int KK = 16, NOUT = 32 * 32 * KK, PER_T = NOUT / 256;
+    // =============================== write-out, one dY plane after the other ===============================
+    // D[row = co][col = ci] of this wave's four taps -> LDS tile [32 co][32 ci][16 taps] (stride 17 floats between lanes: conflict-free) ->
+    // contiguous fp32 atomic adds (each co row of the tile is 32 * 16 consecutive floats of dW)
+    constexpr int KK = 16, KP = KK + 1, NOUT = 32 * 32 * KK;
+    static_assert(32 * 32 * KP * 4 <= C::CTL, "write-out tile fits in the ring");
     float* red = reinterpret_cast<float*>(smem);
     int phase = 0;
     wx_sync4(ctl + WXC_SYNC, phase, lane);   // all four waves are finished reading the ring
+    const int i = lane & 31;
+    static_for<0, 2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c == 0 || pair) {
+            const ssr_wgrad_layer& LC = c ? LB : L;
+            const int co0 = c ? it.co0_b : it.co0;
+            float al = LC.alpha;
+            asm volatile("" : "+v"(al));                       // the products are not loop invariants to be kept (and spilled)
 #pragma unroll
-    for (int t = 0; t < KW; ++t) {
-        const int slot = wave * KW + t;
+            for (int t = 0; t < KW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(slot * 16 + r) * 64 + lane] = acc[t][r];
-    }
-    wx_sync4(ctl + WXC_SYNC, phase, lane);
-    float sum[PER_T];
-#pragma unroll
-    for (int q = 0; q < PER_T; ++q) {
-        const int e = tid + q * 256;                           // ci fastest: conflict-free reads
-        const int ci = e & 31, tap = (e >> 5) % KK, co = e / (32 * KK);
-        const int r = (co & 3) + 4 * (co >> 3), ln = ((co >> 2) & 1) * 32 + ci;
-        sum[q] = L.alpha * red[(tap * 16 + r) * 64 + ln];
-    }
-    wx_sync4(ctl + WXC_SYNC, phase, lane);   // every partial has been read
-#pragma unroll
-    for (int q = 0; q < PER_T; ++q) {
-        const int e = tid + q * 256;
-        const int ci = e & 31, tap = (e >> 5) % KK, co = e / (32 * KK);
-        red[(co * 32 + ci) * KK + tap] = sum[q];
-    }
-    wx_sync4(ctl + WXC_SYNC, phase, lane);
-    float* __restrict__ dw = L.dw;
-    const int nci = min(32, L.Cin_w - it.ci0);
-#pragma unroll
-    for (int q = 0; q < PER_T; ++q) {
-        const int e = tid + q * 256;                           // (co, ci * 16 + tap): contiguous in dW per co row
-        const int co = e / (32 * KK), rem = e - co * (32 * KK);
-        if (it.co0 + co < L.Cout && rem < nci * KK) atomicAdd(dw + ((size_t)(it.co0 + co) * L.Cin_w + it.ci0) * KK + rem, red[e]);
-    }
+                for (int r = 0; r < 16; ++r) red[(mfma32_row(r, g) * 32 + i) * KP + wave * KW + t] = al * acc[c][t][r];
+            wx_sync4(ctl + WXC_SYNC, phase, lane);
+            float* __restrict__ dw = LC.dw;
+            const int nci = min(32, LC.Cin_w - it.ci0);
+#pragma unroll 8
+            for (int q = 0; q < NOUT / 256; ++q) {
+                const int e = tid + q * 256;                   // (co, ci * 16 + tap): contiguous in dW per co row
+                const int co = e / (32 * KK), rem = e - co * (32 * KK);
+                if (co0 + co < LC.Cout && rem < nci * KK)
+                    atomicAdd(dw + ((size_t)(co0 + co) * LC.Cin_w + it.ci0) * KK + rem, red[(co * 32 + (rem >> 4)) * KP + (rem & 15)]);
+            }
+            if (c == 0 && pair) wx_sync4(ctl + WXC_SYNC, phase, lane);   // the tile is read before the second plane overwrites it
+        }
+    });
 }
 
 }  // namespace

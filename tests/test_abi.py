@@ -40,7 +40,8 @@ def test_struct_layouts_match_header():
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.BF16, 3) == 16 * 2 * 2   # 16x16-pixel tiles
     assert hip.lib().ssr_wgrad_tiles(16, 32, 32, hip.F32X3, 3) == 16 * 4 * 2  # the one-pass fp32x3 kernel: 8x16 (hi AND lo planes in a stage)
     assert hip.lib().ssr_wgrad_ci_tile(hip.F32X3, 3) == 64 and hip.lib().ssr_wgrad_co_tile(hip.F32X3, 3) == 64
-    assert hip.lib().ssr_wgrad_ci_tile(hip.F32X3, 4) == 32                    # 4x4 stride 2 stays on the three bf16 passes
+    assert hip.lib().ssr_wgrad_ci_tile(hip.F32X3, 4) == 32 and hip.lib().ssr_wgrad_co_tile(hip.F32X3, 4) == 64      # one-pass 4x4 stride-2 kernel (round 6): 32-ci items, paired dY blocks
+    assert hip.lib().ssr_wgrad_co_tile(hip.BF16, 4) == 32
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):

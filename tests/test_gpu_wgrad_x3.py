@@ -191,7 +191,7 @@ def test_stride2_4x4_layers_one_pass(layers, B, H, W):
 
 def test_stride2_4x4_pixel_splits_bias_and_deterministic_mode():
     wb, got, ref = _run4([(64, 128, 1.0)], 4, 32, 32, max_tiles=3, with_bias=True)
-    assert max(it.atomic for it in wb.items) == 1 and len(wb.items) > 16
+    assert max(it.atomic for it in wb.items) == 1 and len(wb.items) > 8 and any(it.nco == 2 for it in wb.items)      # paired blocks of one layer
     _check(got, ref, with_bias=True)
     a = _run4([(64, 64, 1.0)], 4, 32, 32, max_tiles=4, det=True, with_bias=True)
     b = _run4([(64, 64, 1.0)], 4, 32, 32, max_tiles=4, det=True, with_bias=True)
@@ -199,6 +199,18 @@ def test_stride2_4x4_pixel_splits_bias_and_deterministic_mode():
     _check(a[1], a[2], with_bias=True)
     for (dw1, db1), (dw2, db2) in zip(a[1], b[1]):
         assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+def test_stride2_4x4_single_items_when_pairing_is_off(monkeypatch):
+    """SSR_WGRAD_PAIR=0: one 32-channel block of dY per item (the kernel's single form), and a layer with an odd number of blocks keeps a single"""
+    monkeypatch.setenv("SSR_WGRAD_PAIR", "0")
+    wb, got, ref = _run4([(64, 128, 1.0)], 2, 32, 32, with_bias=True)
+    assert all(it.nco == 1 for it in wb.items)
+    _check(got, ref, with_bias=True)
+    monkeypatch.delenv("SSR_WGRAD_PAIR")
+    wb, got, ref = _run4([(40, 72, 1.0)], 1, 66, 34)             # three output-channel blocks: one pair + one single per input tile
+    assert any(it.nco == 2 for it in wb.items) and any(it.nco == 1 for it in wb.items)
+    _check(got, ref, with_bias=False)
 
 
 def test_stride2_4x4_agrees_with_three_pass_form():

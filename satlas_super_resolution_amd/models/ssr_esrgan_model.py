@@ -13,6 +13,7 @@ and `old_hr` discriminator inputs.  Anything this path does not implement raises
 option (clip / ssim / ldl losses, other optimizers or schedulers, weight decay) — nothing is silently ignored."""
 from __future__ import annotations
 
+import math
 import os
 from collections import Counter, OrderedDict
 
@@ -201,6 +202,11 @@ class SSRESRGANModel:
 
     def get_current_log(self):
         self.log_dict = self.ts.log()
+        # the fp16-split forward of mode fp32h has fp16's range (include/ssr_hip.h, SSR_F32H): an activation beyond 65504 turns into NaN outputs.
+        # The losses are read from the device here anyway: say what to do instead of logging NaN silently
+        if self.compute_dtype == "fp32h" and any(isinstance(v, float) and not math.isfinite(v) for v in self.log_dict.values()):
+            raise FloatingPointError("non-finite loss in compute_dtype fp32h: its forward convolutions run on fp16-split operands (|activation| < 65504, "
+                                     "|weight| < 64); set `compute_dtype: fp32f` (exact fp32 forward, same gates) for this model")
         return self.log_dict
 
     def update_learning_rate(self, current_iter: int, warmup_iter: int = -1):

@@ -514,3 +514,25 @@ def test_model_plugin_in_its_default_arithmetic_against_the_unmodified_reference
             _close_update(sd_d[k].cpu(), v, fx["d0"][k], ("D", k), 5e-2, steps)
     m.test()
     assert parity_close(m.output.cpu(), fx["test_output"]), rel_err(m.output.cpu(), fx["test_output"])
+
+
+def test_default_arithmetic_reports_an_activation_beyond_fp16_range_instead_of_logging_nan(tmp_path):
+    """compute_dtype fp32h (the plugin's default): an input beyond fp16's 65504 makes the split forward non-finite - get_current_log() raises and
+    names the mode to switch to; the same batch in fp32f trains"""
+    from satlas_super_resolution_amd import models  # noqa: F401
+    from satlas_super_resolution_amd.registry import build_model
+    fx = load_golden("stepref_plain")
+    for mode, ok in (("fp32h", False), ("fp32f", True)):
+        opt = _opt(tmp_path, fx)
+        opt["compute_dtype"] = mode
+        opt["train"].pop("scheduler", None)
+        m = build_model(opt)
+        batch = fx["data"][0]
+        m.feed_data(batch)
+        m.ts.g_plan.xin[0, 0, 0, 0] = 1.0e5                      # one LR sample far outside any image: its hi piece overflows fp16 in conv_first
+        m.optimize_parameters(1)
+        if ok:
+            assert all(v == v for v in m.get_current_log().values())
+        else:
+            with pytest.raises(FloatingPointError, match="fp32f"):
+                m.get_current_log()
